@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""oracle/make_golden.py -- generates tests/golden/*.npz by running the IMPORTED REFERENCE.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU box).
+The reference's Python is imported unmodified behind a 3-module ``sys.modules`` stub that supplies
+``pointnet2_utils.furthest_point_sample`` (the reference's native FPS is CUDA-only and asserts on CPU
+tensors, pointnet2_ops_lib/pointnet2_ops/_ext-src/src/sampling.cpp:82-84); the stub calls the literal
+kernel emulation in oracle/pointnet2_ref.c.  No reference source is copied: fixtures hold inputs'
+seeds, expected outputs and sampled intermediates only.
+
+    python oracle/make_golden.py            # writes tests/golden/{tiny_*,full_forward}.npz + json
+"""
+from __future__ import annotations
+
+import copy
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from nsdp_amd import synth  # noqa: E402
+from oracle import pointnet2_ref, tdnet_ref  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    def fps(xyz, npoint):
+        return torch.from_numpy(pointnet2_ref.furthest_point_sampling(xyz.detach().cpu().numpy(), int(npoint)))
+
+    stub = types.ModuleType("pointnet2_ops_lib.pointnet2_ops.pointnet2_utils")
+    stub.furthest_point_sample = fps
+    for name in ("pointnet2_ops_lib", "pointnet2_ops_lib.pointnet2_ops"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    sys.modules["pointnet2_ops_lib.pointnet2_ops.pointnet2_utils"] = stub
+    sys.modules["pointnet2_ops_lib.pointnet2_ops"].pointnet2_utils = stub
+    sys.path.insert(0, REF)
+    import model as ref_model  # noqa
+    import model.utils as ref_utils  # noqa
+    return ref_model, ref_utils
+
+
+def cfg_for(mtype, npl):
+    cfg = {"model": copy.deepcopy(tdnet_ref.DEFAULT_MODEL_CFG)}
+    cfg["model"]["type"] = mtype
+    cfg["model"]["encoder_kwargs"]["npoints_per_layer"] = list(npl)
+    return cfg
+
+
+def load_procedural(model, seed):
+    template = {k: v for k, v in model.state_dict().items()}
+    state = synth.procedural_state_dict(template, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    return state
+
+
+def capture_hooks(model, tape):
+    """Record the output of every block the oracle also records (names = state_dict prefixes)."""
+    from model.encoder.blocks import TransformerBlock, ElementwiseMLP, TransformerSetAbstraction
+    from model.decoder.blocks import CrossTransformerBlock
+    handles = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, (TransformerBlock, ElementwiseMLP, CrossTransformerBlock)):
+            handles.append(mod.register_forward_hook(
+                lambda m, i, o, name=name: tape.__setitem__(name + ".out", o.detach().clone())))
+        elif isinstance(mod, TransformerSetAbstraction):
+            handles.append(mod.register_forward_hook(
+                lambda m, i, o, name=name: tape.__setitem__(name + ".out", o[1].detach().clone())))
+    return handles
+
+
+def sample_flat(t, n=16):
+    f = t.detach().reshape(-1)
+    if f.numel() <= n:
+        return f.clone().numpy()
+    idx = torch.linspace(0, f.numel() - 1, n).long()
+    return f[idx].numpy()
+
+
+def run_case(ref_model, ref_utils, mtype, npl, batch, ns, nq, seed, name, full_intermediates):
+    cfg = cfg_for(mtype, npl)
+    torch.manual_seed(0)
+    model, train_on_batch, _, _ = ref_model.build_model(cfg, device="cpu")
+    load_procedural(model, seed)
+    data_np = synth.make_batch(seed, batch, ns, nq)
+    data = {k: torch.from_numpy(v) for k, v in data_np.items()}
+    fx = {"meta_seed": np.int64(seed), "meta_batch": np.int64(batch), "meta_ns": np.int64(ns),
+          "meta_nq": np.int64(nq), "meta_npl": np.array(npl, dtype=np.int64)}
+
+    def fwd():
+        if mtype == "arbitrary":
+            s = data["surface_samples_inputs"]
+            return model(data["space_samples_src"], s[:, :, 0:3], s[:, :, 3:6], s[:, :, 6:7])
+        return model(data["space_samples_src"], data["surface_samples_inputs"])
+
+    # ---- eval-mode forward (running statistics) --------------------------------------------------
+    model.eval()
+    tape = {}
+    hooks = capture_hooks(model, tape)
+    with torch.no_grad():
+        out = fwd()
+    for h in hooks:
+        h.remove()
+    fx["eval_out"] = out.numpy()
+    for k, v in tape.items():
+        fx["eval_tap/" + k] = v.numpy() if full_intermediates else sample_flat(v, 64)
+
+    # ---- geometry of the reference path, from the reference's own functions ----------------------
+    if mtype != "arbitrary":
+        ek = cfg["model"]["encoder_kwargs"]
+        xyz0 = data["surface_samples_inputs"][:, :, :3].contiguous()
+        sqd, idxp = ref_utils.square_distance, ref_utils.index_points
+        fps1 = sys.modules["pointnet2_ops_lib.pointnet2_ops.pointnet2_utils"].furthest_point_sample(xyz0, npl[1])
+        xyz1 = idxp(xyz0, fps1.long())
+        fps2 = sys.modules["pointnet2_ops_lib.pointnet2_ops.pointnet2_utils"].furthest_point_sample(xyz1, npl[2])
+        xyz2 = idxp(xyz1, fps2.long())
+        fx["geo/fps1"], fx["geo/fps2"] = fps1.numpy(), fps2.numpy()
+        knn = {
+            "begin": sqd(xyz0, xyz0).argsort()[:, :, :ek["nneighbor_reduced"]],
+            "tsa0": sqd(xyz1, xyz0).argsort()[:, :, :min(ek["nneighbor"], npl[0])],
+            "down0": sqd(xyz1, xyz1).argsort()[:, :, :min(ek["nneighbor"], npl[1])],
+            "tsa1": sqd(xyz2, xyz1).argsort()[:, :, :min(ek["nneighbor"], npl[1])],
+            "down1": sqd(xyz2, xyz2).argsort()[:, :, :min(ek["nneighbor"], npl[2])],
+            "dec": sqd(data["space_samples_src"], xyz2).argsort()[:, :, :cfg["model"]["decoder_kwargs"]["nneigh"]],
+        }
+        for k, v in knn.items():
+            v = v.numpy().astype(np.int32)
+            fx["geo/knn_" + k] = v if full_intermediates else v[:, :: max(1, v.shape[1] // 64)]
+        # bit pattern of square_distance (locks the (dx*dx+dy*dy)+dz*dz no-FMA rule)
+        fx["geo/sqdist_sample"] = sqd(xyz1[:, :8], xyz0[:, :64]).numpy()
+
+    # ---- one training step (batch statistics, Adam lr 5e-4) --------------------------------------
+    model.train()
+    _, optimizer = ref_model.optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200,
+                                                "lr_decay": 0.1, "weight_decay": 0.0},
+                                               model.parameters())
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    loss = train_on_batch(model, optimizer, data, cfg)
+    fx["train_loss"] = np.float64(loss)
+    none_grads = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            none_grads.append(k)
+            continue
+        fx["grad_norm/" + k] = np.float64(p.grad.double().norm().item())
+        fx["grad_sample/" + k] = sample_flat(p.grad, 16)
+        fx["delta_sample/" + k] = sample_flat(p.detach() - before[k], 16)
+    fx["none_grads"] = np.array(none_grads)
+    for k, v in model.state_dict().items():
+        if k.endswith(("running_mean", "running_var")):
+            fx["bn_after/" + k] = sample_flat(v, 16)
+        if k.endswith("num_batches_tracked"):
+            fx["bn_after/" + k] = v.numpy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"wrote {path}: {os.path.getsize(path)/1024:.1f} KiB, loss {loss:.6f}, none_grads {none_grads}")
+    return model
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    pointnet2_ref.build()
+    ref_model, ref_utils = import_reference()
+    torch.set_num_threads(8)
+
+    tiny_npl = [256, 64, 16]
+    for mtype in ("forward", "backward", "arbitrary"):
+        m = run_case(ref_model, ref_utils, mtype, tiny_npl, 2, 256, 128, 1234, "tiny_" + mtype,
+                     mtype != "arbitrary")
+        if mtype in ("forward", "backward"):
+            tmpl = {k: list(v.shape) for k, v in m.state_dict().items()}
+            with open(os.path.join(OUT, f"state_template_{mtype}.json"), "w") as f:
+                json.dump(tmpl, f, indent=0)
+    # BASELINE configs[0]: forward.yaml architecture, B=1, 2048 surface + 8192 query points
+    run_case(ref_model, ref_utils, "forward", [2048, 500, 100], 1, 2048, 8192, 2048, "full_forward", False)
+
+
+if __name__ == "__main__":
+    main()
