@@ -1,0 +1,101 @@
+/*
+ * nsdp_hip.h -- C-ABI of libnsdp_hip.so, the MI355X (gfx950) drop-in for the native boundary of the
+ * NSDP TDNet hot path.
+ *
+ * Conventions (replaces the reference contract described in SURVEY.md section 8 b1):
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - float = IEEE binary32, indices = int32_t; tensors are dense, row-major, contiguous
+ *     (the reference asserts the same: _ext-src/include/utils.h:5-25 CHECK_CONTIGUOUS/IS_FLOAT/IS_INT);
+ *   - outputs and scratch are allocated BY THE CALLER (the reference allocates with torch::zeros in the
+ *     callee, e.g. sampling.cpp:70-76; a C ABI cannot) -- functions that the reference zero-fills
+ *     (`*_grad`, ball_query) zero their output themselves, stream-ordered;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is asynchronous on it,
+ *     mirroring `at::cuda::getCurrentCUDAStream()` (e.g. sampling_gpu.cu:180);
+ *   - return value: 0 on success, a negative NSDP_E* code for bad arguments, or a positive hipError_t.
+ *     Nothing ever calls exit() (the reference does on a launch failure, cuda_utils.h:30-39);
+ *   - re-entrant, no global state besides a thread-local last-error string.
+ */
+#ifndef NSDP_HIP_H_
+#define NSDP_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSDP_EINVAL (-1)  /* bad size / null pointer */
+#define NSDP_ENOSUP (-2)  /* unsupported configuration (message in nsdp_last_error) */
+
+/* Version of this ABI (bumped on any signature change). */
+int nsdp_abi_version(void);
+/* Human-readable description of the last non-zero return on this thread. */
+const char *nsdp_last_error(void);
+/* Number of HIP devices visible (0 when there is none; never fails). */
+int nsdp_device_count(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * pointnet2_ops._ext replacements
+ * (reference binding table: pointnet2_ops_lib/pointnet2_ops/_ext-src/src/bindings.cpp:6-19)
+ * -------------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling(points(B,N,3), nsamples) -> (B,nsamples) i32
+ * replaces sampling.cpp:66-87 + sampling_gpu.cu:69-229.  `tmp` = (B,N) f32 scratch (only touched when
+ * N > 8192; may be NULL otherwise).  Indices are identical to the reference kernel's, ties included
+ * (tie rule of the block_size = opt_n_threads(N) shared-memory tree is reproduced exactly). */
+int nsdp_furthest_point_sampling(const float *xyz, int B, int N, int nsamples, float *tmp,
+                                 int32_t *idx_out, void *stream);
+
+/* gather_points(points(B,C,N), idx(B,M)) -> (B,C,M); sampling.cpp:16-41, sampling_gpu.cu:8-30 */
+int nsdp_gather_points(const float *points, const int32_t *idx, int B, int C, int N, int M,
+                       float *out, void *stream);
+/* gather_points_grad(grad_out(B,C,M), idx(B,M), N) -> (B,C,N); sampling.cpp:43-65, sampling_gpu.cu:34-57 */
+int nsdp_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
+                            float *grad_points, void *stream);
+
+/* group_points(points(B,C,N), idx(B,NP,NS)) -> (B,C,NP,NS); group_points.cpp:14-38, group_points_gpu.cu:8-41 */
+int nsdp_group_points(const float *points, const int32_t *idx, int B, int C, int N, int NP, int NS,
+                      float *out, void *stream);
+/* group_points_grad(grad_out(B,C,NP,NS), idx, N) -> (B,C,N); group_points.cpp:40-65, group_points_gpu.cu:43-75 */
+int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int NP,
+                           int NS, float *grad_points, void *stream);
+
+/* ball_query(new_xyz(B,M,3), xyz(B,N,3), radius, nsample) -> (B,M,nsample) i32;
+ * ball_query.cpp:8-34, ball_query_gpu.cu:9-54 */
+int nsdp_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M, float radius,
+                    int nsample, int32_t *idx_out, void *stream);
+
+/* three_nn(unknown(B,n,3), known(B,m,3)) -> dist2(B,n,3) f32, idx(B,n,3) i32;
+ * interpolate.cpp:17-42, interpolate_gpu.cu:9-70 */
+int nsdp_three_nn(const float *unknown, const float *known, int B, int n, int m, float *dist2,
+                  int32_t *idx, void *stream);
+/* three_interpolate(points(B,c,m), idx(B,n,3), weight(B,n,3)) -> (B,c,n); interpolate.cpp:44-72, interpolate_gpu.cu:72-114 */
+int nsdp_three_interpolate(const float *points, const int32_t *idx, const float *weight, int B,
+                           int c, int m, int n, float *out, void *stream);
+/* three_interpolate_grad(grad_out(B,c,n), idx, weight, m) -> (B,c,m); interpolate.cpp:74-101, interpolate_gpu.cu:116-156 */
+int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight,
+                                int B, int c, int n, int m, float *grad_points, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * ATen call sites of the model that the path replaces with native kernels
+ * -------------------------------------------------------------------------------------------- */
+
+/* kNN: replaces `square_distance(query, source).argsort()[:, :, :k]`
+ * (model/utils.py:39-55; call sites model/encoder/blocks.py:101-102, :287-288, model/decoder/blocks.py:50-52).
+ * query(B,n,3), source(B,m,3) -> idx(B,n,k) i32 ascending by (distance, index); distance is
+ * ((dx*dx + dy*dy) + dz*dz) in fp32 with separately rounded products, bit-identical to the reference.
+ * dist2_out(B,n,k) may be NULL.  Never materialises the n x m matrix.  k <= 64, k <= m. */
+int nsdp_knn(const float *query, const float *source, int B, int n, int m, int k, int32_t *idx_out,
+             float *dist2_out, void *stream);
+
+/* index_points(points(B,N,C), idx(B,S)) -> (B,S,C) (row gather; model/utils.py:58-70) */
+int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int C, int S, float *out,
+                     void *stream);
+/* backward of index_points: grad_points(B,N,C) += scatter of grad_out(B,S,C) (zero-filled first). */
+int nsdp_scatter_add_rows(const float *grad_out, const int32_t *idx, int B, int N, int C, int S,
+                          float *grad_points, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSDP_HIP_H_ */

@@ -1,0 +1,65 @@
+"""Builds libnsdp_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch extension
+machinery, no hipify: plain `hipcc --offload-arch=gfx950` per translation unit, then one shared link.
+
+    python -m nsdp_amd.build [--force]
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+SO = os.path.join(LIBDIR, "libnsdp_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "nsdp_hip.h")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# geometry kernels must keep one rounding per fp32 op (bit-exact distances): contraction off
+EXACT = ["-ffp-contract=off"]
+FAST = ["-ffp-contract=fast"]
+PER_FILE = {
+    "fps.hip": EXACT,
+    "knn.hip": EXACT,
+    "pointnet2_ops.hip": EXACT,
+}
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJDIR, src[:-4] + ".o")
+    path = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
+        return obj, False
+    cmd = [HIPCC] + COMMON + PER_FILE.get(src, FAST) + ["-c", path, "-o", obj]
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJDIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), sources()))
+    objs = [o for o, _ in results]
+    if force or any(c for _, c in results) or not os.path.exists(SO):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs)
+        if verbose:
+            print("linked", SO)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,276 @@
+"""Drop-in for the reference's ``pointnet2_ops_lib/pointnet2_ops/pointnet2_utils.py`` on MI355X.
+
+Same public names, argument order, tensor layouts, dtypes and differentiability as the reference
+(pointnet2_utils.py:34-379): ``furthest_point_sample``, ``gather_operation``, ``three_nn``,
+``three_interpolate``, ``grouping_operation``, ``ball_query`` and the ``QueryAndGroup`` / ``GroupAll``
+modules -- so a call site such as model/encoder/blocks.py:283 works unchanged.  The native side is
+libnsdp_hip.so (hand-written HIP for gfx950) behind the C ABI of include/nsdp_hip.h instead of the
+pybind11 module ``pointnet2_ops._ext`` (_ext-src/src/bindings.cpp:6-19).
+
+Error behaviour mirrors the reference's CHECK_* macros (_ext-src/include/utils.h:5-25): non-contiguous,
+wrong-dtype or CPU tensors raise ``RuntimeError`` (NsdpHipError is a RuntimeError).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import check, fptr, iptr, lib, on_device, optptr, stream_ptr
+
+_c_int = ctypes.c_int
+
+
+# ------------------------------------------------------------------------------------------------
+# thin functional layer over the C ABI (one function per entry point of include/nsdp_hip.h)
+# ------------------------------------------------------------------------------------------------
+def _fps(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    B, N, C = xyz.shape
+    if C != 3:
+        raise _lib.NsdpHipError("xyz must be (B, N, 3)")
+    out = torch.empty((B, int(npoint)), dtype=torch.int32, device=xyz.device)
+    tmp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 8192 else None
+    with on_device(xyz):
+        check(lib().nsdp_furthest_point_sampling(fptr(xyz, "xyz"), _c_int(B), _c_int(N), _c_int(int(npoint)),
+                                                 optptr(tmp), iptr(out), stream_ptr()),
+              "nsdp_furthest_point_sampling")
+    return out
+
+
+def knn(query: torch.Tensor, source: torch.Tensor, k: int, return_dist: bool = False):
+    """``square_distance(query, source).argsort()[:, :, :k]`` without the n x m matrix.
+    query (B,n,3), source (B,m,3) -> idx (B,n,k) int32 ascending by (distance, index)."""
+    B, n, _ = query.shape
+    m = source.shape[1]
+    idx = torch.empty((B, n, int(k)), dtype=torch.int32, device=query.device)
+    d2 = torch.empty((B, n, int(k)), dtype=torch.float32, device=query.device) if return_dist else None
+    with on_device(query):
+        check(lib().nsdp_knn(fptr(query, "query"), fptr(source, "source"), _c_int(B), _c_int(n), _c_int(m),
+                             _c_int(int(k)), iptr(idx), optptr(d2), stream_ptr()), "nsdp_knn")
+    return (idx, d2) if return_dist else idx
+
+
+def gather_rows(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """index_points for a 2-D index: points (B,N,C), idx (B,S) int32 -> (B,S,C)."""
+    B, N, C = points.shape
+    S = idx.shape[1]
+    out = torch.empty((B, S, C), dtype=torch.float32, device=points.device)
+    with on_device(points):
+        check(lib().nsdp_gather_rows(fptr(points, "points"), iptr(idx, "idx"), _c_int(B), _c_int(N),
+                                     _c_int(C), _c_int(S), fptr(out), stream_ptr()), "nsdp_gather_rows")
+    return out
+
+
+def scatter_add_rows(grad_out: torch.Tensor, idx: torch.Tensor, N: int) -> torch.Tensor:
+    B, S, C = grad_out.shape
+    out = torch.empty((B, int(N), C), dtype=torch.float32, device=grad_out.device)
+    with on_device(grad_out):
+        check(lib().nsdp_scatter_add_rows(fptr(grad_out, "grad_out"), iptr(idx, "idx"), _c_int(B), _c_int(int(N)),
+                                          _c_int(C), _c_int(S), fptr(out), stream_ptr()),
+              "nsdp_scatter_add_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions with the reference's names and signatures
+# ------------------------------------------------------------------------------------------------
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, npoint):
+        """xyz (B,N,3) float32 -> (B,npoint) int32 (pointnet2_utils.py:34-62)."""
+        out = _fps(xyz, npoint)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint) int32 -> (B,C,npoint) (pointnet2_utils.py:68-101)."""
+        ctx.save_for_backward(idx, features)
+        B, C, N = features.shape
+        M = idx.shape[1]
+        out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
+        with on_device(features):
+            check(lib().nsdp_gather_points(fptr(features, "features"), iptr(idx, "idx"), _c_int(B), _c_int(C),
+                                           _c_int(N), _c_int(M), fptr(out), stream_ptr()), "nsdp_gather_points")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, features = ctx.saved_tensors
+        B, C, N = features.shape
+        M = idx.shape[1]
+        grad_out = grad_out.contiguous()
+        grad = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+        with on_device(grad_out):
+            check(lib().nsdp_gather_points_grad(fptr(grad_out, "grad_out"), iptr(idx), _c_int(B), _c_int(C),
+                                                _c_int(N), _c_int(M), fptr(grad), stream_ptr()),
+                  "nsdp_gather_points_grad")
+        return grad, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown, known):
+        """unknown (B,n,3), known (B,m,3) -> dist (B,n,3) (sqrt of d2), idx (B,n,3) int32
+        (pointnet2_utils.py:104-136)."""
+        B, n, _ = unknown.shape
+        m = known.shape[1]
+        dist2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+        with on_device(unknown):
+            check(lib().nsdp_three_nn(fptr(unknown, "unknown"), fptr(known, "known"), _c_int(B), _c_int(n),
+                                      _c_int(m), fptr(dist2), iptr(idx), stream_ptr()), "nsdp_three_nn")
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, grad_dist, grad_idx):
+        return ()
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        """features (B,c,m), idx (B,n,3) int32, weight (B,n,3) -> (B,c,n) (pointnet2_utils.py:139-191)."""
+        ctx.save_for_backward(idx, weight, features)
+        B, c, m = features.shape
+        n = idx.shape[1]
+        out = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+        with on_device(features):
+            check(lib().nsdp_three_interpolate(fptr(features, "features"), iptr(idx, "idx"), fptr(weight, "weight"),
+                                               _c_int(B), _c_int(c), _c_int(m), _c_int(n), fptr(out),
+                                               stream_ptr()), "nsdp_three_interpolate")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight, features = ctx.saved_tensors
+        B, c, m = features.shape
+        n = idx.shape[1]
+        grad_out = grad_out.contiguous()
+        grad = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
+        with on_device(grad_out):
+            check(lib().nsdp_three_interpolate_grad(fptr(grad_out, "grad_out"), iptr(idx), fptr(weight), _c_int(B),
+                                                    _c_int(c), _c_int(n), _c_int(m), fptr(grad), stream_ptr()),
+                  "nsdp_three_interpolate_grad")
+        return grad, torch.zeros_like(idx), torch.zeros_like(weight)
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        """features (B,C,N), idx (B,npoint,nsample) int32 -> (B,C,npoint,nsample)
+        (pointnet2_utils.py:194-240)."""
+        ctx.save_for_backward(idx, features)
+        B, C, N = features.shape
+        _, NP, NS = idx.shape
+        out = torch.empty((B, C, NP, NS), dtype=torch.float32, device=features.device)
+        with on_device(features):
+            check(lib().nsdp_group_points(fptr(features, "features"), iptr(idx, "idx"), _c_int(B), _c_int(C),
+                                          _c_int(N), _c_int(NP), _c_int(NS), fptr(out), stream_ptr()),
+                  "nsdp_group_points")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, features = ctx.saved_tensors
+        B, C, N = features.shape
+        _, NP, NS = idx.shape
+        grad_out = grad_out.contiguous()
+        grad = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+        with on_device(grad_out):
+            check(lib().nsdp_group_points_grad(fptr(grad_out, "grad_out"), iptr(idx), _c_int(B), _c_int(C),
+                                               _c_int(N), _c_int(NP), _c_int(NS), fptr(grad), stream_ptr()),
+                  "nsdp_group_points_grad")
+        return grad, torch.zeros_like(idx)
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, new_xyz):
+        """xyz (B,N,3), new_xyz (B,npoint,3) -> (B,npoint,nsample) int32 (pointnet2_utils.py:243-276)."""
+        B, N, _ = xyz.shape
+        M = new_xyz.shape[1]
+        out = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=xyz.device)
+        with on_device(xyz):
+            check(lib().nsdp_ball_query(fptr(new_xyz, "new_xyz"), fptr(xyz, "xyz"), _c_int(B), _c_int(N), _c_int(M),
+                                        ctypes.c_float(float(radius)), _c_int(int(nsample)), iptr(out),
+                                        stream_ptr()), "nsdp_ball_query")
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ()
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Ball query + grouping (pointnet2_utils.py:279-335)."""
+
+    def __init__(self, radius, nsample, use_xyz=True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features
+
+
+class GroupAll(nn.Module):
+    """Groups all features (pointnet2_utils.py:338-379)."""
+
+    def __init__(self, use_xyz=True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz, new_xyz, features=None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            grouped_features = features.unsqueeze(2)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            new_features = grouped_xyz
+        return new_features

@@ -1,0 +1,172 @@
+"""GPU parity of the geometry / pointnet2 operators against the CPU oracle (bit-exact indices)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nsdp_amd import synth
+from oracle import pointnet2_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _cloud(seed, b, n, kind="uniform"):
+    xyz = synth.uniform(seed, f"cloud{kind}", (b, n, 3), -0.5, 0.5)
+    if kind == "origin":       # many points inside the mag <= 1e-3 ball (skipped by the kernel)
+        xyz[:, ::7] *= 0.03
+    elif kind == "dupes":      # exact duplicates -> exact distance ties (fp16-stored real data has them)
+        xyz[:, 1::2] = xyz[:, 0::2][:, : xyz[:, 1::2].shape[1]]
+    elif kind == "grid":       # lattice: massive ties everywhere
+        g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3)
+        xyz = np.tile(((g[:n] - 7.5) / 16.0).astype(np.float32)[None], (b, 1, 1))
+    elif kind == "allorigin":
+        xyz = np.zeros((b, n, 3), np.float32)
+    return np.ascontiguousarray(xyz, dtype=np.float32)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 3), (64, 16), (100, 100), (256, 64), (500, 100), (513, 77),
+                                 (2048, 500), (3000, 300), (5000, 500), (8192, 64), (10000, 40)])
+def test_fps_matches_oracle(n, m):
+    from nsdp_amd import pointnet2_utils as pu
+    xyz = _cloud(n * 7 + m, 3, n)
+    got = pu.furthest_point_sample(_dev(xyz), m)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (3, m)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.furthest_point_sampling(xyz, m))
+
+
+@pytest.mark.parametrize("kind", ["origin", "dupes", "grid", "allorigin"])
+@pytest.mark.parametrize("n,m", [(500, 100), (2048, 500), (4096, 200)])
+def test_fps_edge_cases_match_oracle(kind, n, m):
+    """Skipped near-origin points, exact ties (tie rule of the reference's block tree), degenerate clouds."""
+    from nsdp_amd import pointnet2_utils as pu
+    xyz = _cloud(11, 2, n, kind)
+    got = pu.furthest_point_sample(_dev(xyz), m).cpu().numpy()
+    np.testing.assert_array_equal(got, ref.furthest_point_sampling(xyz, m))
+
+
+def test_fps_golden_pyramid(golden_dir):
+    """FPS pyramid of the golden fixtures (tiny: 256->64->16, full: 2048->500->100)."""
+    from nsdp_amd import pointnet2_utils as pu
+    for name in ("tiny_forward", "full_forward"):
+        fx = np.load(os.path.join(golden_dir, name + ".npz"))
+        seed, b, ns, nq = (int(fx[k]) for k in ("meta_seed", "meta_batch", "meta_ns", "meta_nq"))
+        npl = [int(x) for x in fx["meta_npl"]]
+        xyz0 = _dev(synth.make_batch(seed, b, ns, nq)["surface_samples_inputs"][:, :, :3])
+        fps1 = pu.furthest_point_sample(xyz0, npl[1])
+        xyz1 = pu.gather_rows(xyz0, fps1)
+        fps2 = pu.furthest_point_sample(xyz1, npl[2])
+        np.testing.assert_array_equal(fps1.cpu().numpy(), fx["geo/fps1"])
+        np.testing.assert_array_equal(fps2.cpu().numpy(), fx["geo/fps2"])
+
+
+@pytest.mark.parametrize("n,m,k", [(1, 1, 1), (5, 9, 3), (100, 100, 16), (500, 2048, 16), (2048, 2048, 10),
+                                   (8192, 100, 7), (300, 5000, 16), (64, 1500, 33), (70, 70, 64)])
+def test_knn_matches_oracle(n, m, k):
+    from nsdp_amd import pointnet2_utils as pu
+    q = _cloud(n + k, 2, n)
+    s = q if n == m else _cloud(m + 5 * k, 2, m)
+    idx, d2 = pu.knn(_dev(q), _dev(s), k, return_dist=True)
+    ridx, rd2 = ref.knn(q, s, k, return_dist=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy().view(np.uint32), rd2.view(np.uint32))  # bit-exact distances
+
+
+def test_knn_ties_follow_distance_then_index():
+    from nsdp_amd import pointnet2_utils as pu
+    s = _cloud(3, 2, 512, "grid")
+    idx = pu.knn(_dev(s), _dev(s), 16).cpu().numpy()
+    np.testing.assert_array_equal(idx, ref.knn(s, s, 16))
+
+
+def test_knn_golden_sets(golden_dir):
+    """kNN sets produced by the reference's own square_distance + argsort (tiny fixture, every site)."""
+    from nsdp_amd import pointnet2_utils as pu
+    fx = np.load(os.path.join(golden_dir, "tiny_forward.npz"))
+    seed, b, ns, nq = (int(fx[k]) for k in ("meta_seed", "meta_batch", "meta_ns", "meta_nq"))
+    data = synth.make_batch(seed, b, ns, nq)
+    xyz0 = _dev(data["surface_samples_inputs"][:, :, :3])
+    xyz1 = pu.gather_rows(xyz0, _dev(fx["geo/fps1"]))
+    xyz2 = pu.gather_rows(xyz1, _dev(fx["geo/fps2"]))
+    q = _dev(data["space_samples_src"])
+    sites = {"begin": (xyz0, xyz0, 10), "tsa0": (xyz1, xyz0, 16), "down0": (xyz1, xyz1, 16),
+             "tsa1": (xyz2, xyz1, 16), "down1": (xyz2, xyz2, 16), "dec": (q, xyz2, 7)}
+    for name, (a, s, k) in sites.items():
+        np.testing.assert_array_equal(pu.knn(a, s, k).cpu().numpy(), fx["geo/knn_" + name], err_msg=name)
+
+
+def test_gather_and_group_ops_match_oracle():
+    from nsdp_amd import pointnet2_utils as pu
+    B, C, N, M, NS = 3, 7, 50, 23, 5
+    feats = synth.normal(1, "feats", (B, C, N))
+    idx = (synth.uniform01(2, "idx", (B, M)) * N).astype(np.int32)
+    gidx = (synth.uniform01(3, "gidx", (B, M, NS)) * N).astype(np.int32)
+    f = _dev(feats).requires_grad_(True)
+    out = pu.gather_operation(f, _dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.gather_points(feats, idx))
+    go = synth.normal(4, "go", (B, C, M))
+    out.backward(_dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref.gather_points_grad(go, idx, N), rtol=1e-6, atol=1e-6)
+    f.grad = None
+    out = pu.grouping_operation(f, _dev(gidx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.group_points(feats, gidx))
+    go = synth.normal(5, "go2", (B, C, M, NS))
+    out.backward(_dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref.group_points_grad(go, gidx, N), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("radius,nsample", [(0.2, 8), (0.05, 4), (2.0, 16), (1e-4, 3)])
+def test_ball_query_matches_oracle(radius, nsample):
+    from nsdp_amd import pointnet2_utils as pu
+    xyz = _cloud(21, 2, 1500)
+    new_xyz = _cloud(22, 2, 300)
+    got = pu.ball_query(radius, nsample, _dev(xyz), _dev(new_xyz))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.ball_query(new_xyz, xyz, radius, nsample))
+
+
+def test_three_nn_and_interpolate_match_oracle():
+    from nsdp_amd import pointnet2_utils as pu
+    unknown, known = _cloud(31, 2, 700), _cloud(32, 2, 1300)
+    dist, idx = pu.three_nn(_dev(unknown), _dev(known))
+    rd2, ridx = ref.three_nn(unknown, known)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.sqrt(rd2))
+    feats = synth.normal(33, "f", (2, 9, 1300))
+    w = synth.uniform(34, "w", (2, 700, 3), 0.0, 1.0)
+    f = _dev(feats).requires_grad_(True)
+    out = pu.three_interpolate(f, idx, _dev(w))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.three_interpolate(feats, ridx, w))
+    go = synth.normal(35, "go", (2, 9, 700))
+    out.backward(_dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref.three_interpolate_grad(go, ridx, w, 1300),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_query_and_group_module():
+    from nsdp_amd import pointnet2_utils as pu
+    xyz, new_xyz = _cloud(41, 2, 400), _cloud(42, 2, 50)
+    feats = synth.normal(43, "f", (2, 6, 400))
+    out = pu.QueryAndGroup(0.3, 8)(_dev(xyz), _dev(new_xyz), _dev(feats))
+    idx = ref.ball_query(new_xyz, xyz, 0.3, 8)
+    gx = ref.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx) - new_xyz.transpose(0, 2, 1)[..., None]
+    want = np.concatenate([gx, ref.group_points(feats, idx)], axis=1)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_rows_gather_scatter():
+    from nsdp_amd import pointnet2_utils as pu
+    for C in (3, 120, 256):
+        pts = synth.normal(50 + C, "p", (2, 300, C))
+        idx = (synth.uniform01(51 + C, "i", (2, 90)) * 300).astype(np.int32)
+        out = pu.gather_rows(_dev(pts), _dev(idx)).cpu().numpy()
+        np.testing.assert_array_equal(out, np.take_along_axis(pts, idx[..., None].astype(np.int64), axis=1))
+        go = synth.normal(52 + C, "g", (2, 90, C))
+        want = np.zeros_like(pts)
+        for b in range(2):
+            np.add.at(want[b], idx[b], go[b])
+        got = pu.scatter_add_rows(_dev(go), _dev(idx), 300).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
