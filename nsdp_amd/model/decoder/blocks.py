@@ -1,0 +1,69 @@
+"""Decoder blocks (state-dict compatible mirror of the reference's model/decoder/blocks.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class CrossTransformerBlock(nn.Module):
+    """Cross attention from every query point to its `nneigh` nearest anchors plus one global token
+    (reference model/decoder/blocks.py:12-95, separate_delta=True: delta evaluated twice with the same
+    weights -- identical values, so it is evaluated once here and autograd sums the two uses)."""
+
+    def __init__(self, dim_inp, dim, nneigh=7, reduce_dim=True, separate_delta=True):
+        super().__init__()
+        self.dim = dim
+        self.nneigh = nneigh
+        self.separate_delta = separate_delta
+        self.fc_delta = nn.Sequential(nn.Linear(3, dim), nn.ReLU(), nn.Linear(dim, dim))
+        self.fc_gamma = nn.Sequential(nn.Linear(dim, dim), nn.ReLU(), nn.Linear(dim, dim))
+        self.w_k_global = nn.Linear(dim_inp, dim, bias=False)
+        self.w_v_global = nn.Linear(dim_inp, dim, bias=False)
+        self.w_qs = nn.Linear(dim_inp, dim, bias=False)
+        self.w_ks = nn.Linear(dim_inp, dim, bias=False)
+        self.w_vs = nn.Linear(dim_inp, dim, bias=False)
+        if not reduce_dim:
+            self.fc = nn.Linear(dim, dim_inp)
+        self.reduce_dim = reduce_dim
+
+    def forward(self, xyz_q, lat_rep, xyz, points):
+        assert lat_rep.dim() == 2, "per-query latent codes are not used by any NSDP configuration"
+        idx = ops.knn_indices(xyz_q, xyz, self.nneigh)                       # [B,NQ,k]
+        q = ops.linear(lat_rep, self.w_qs)                                   # [B,D]  (shared by all queries)
+        k_g = ops.linear(lat_rep, self.w_k_global)
+        v_g = ops.linear(lat_rep, self.w_v_global)
+        k_nb = ops.index_points(ops.linear(points, self.w_ks), idx)          # [B,NQ,k,D]
+        v_nb = ops.index_points(ops.linear(points, self.w_vs), idx)
+        rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)                # xyz_q - a_j
+        pos = ops.mlp2(rel, self.fc_delta)                                   # [B,NQ,k,D]
+        logit_nb = ops.mlp2(q[:, None, None, :] - k_nb + pos, self.fc_gamma)
+        logit_g = ops.mlp2(q - k_g, self.fc_gamma)                           # [B,D]: identical for all queries
+        NQ = xyz_q.shape[1]
+        logits = torch.cat([logit_nb, logit_g[:, None, None, :].expand(-1, NQ, 1, -1)], dim=2)
+        w = F.softmax(logits, dim=-2)
+        res = (w[:, :, :-1] * (v_nb + pos)).sum(dim=2) + w[:, :, -1] * v_g[:, None, :]
+        if not self.reduce_dim:
+            res = ops.linear(res, self.fc)
+        return res
+
+
+class ResnetBlockFC(nn.Module):
+    """x + fc_1(relu(fc_0(relu(x))))   (reference model/decoder/blocks.py:99-142)."""
+
+    def __init__(self, size_in, size_out=None, size_h=None):
+        super().__init__()
+        size_out = size_in if size_out is None else size_out
+        size_h = min(size_in, size_out) if size_h is None else size_h
+        self.size_in, self.size_h, self.size_out = size_in, size_h, size_out
+        self.fc_0 = nn.Linear(size_in, size_h)
+        self.fc_1 = nn.Linear(size_h, size_out)
+        self.shortcut = None if size_in == size_out else nn.Linear(size_in, size_out, bias=False)
+        nn.init.zeros_(self.fc_1.weight)
+
+    def forward(self, x):
+        h = ops.linear(torch.relu(x), self.fc_0, relu=True)
+        dx = ops.linear(h, self.fc_1)
+        return (x if self.shortcut is None else ops.linear(x, self.shortcut)) + dx

@@ -1,0 +1,31 @@
+"""Cross-attention decoder (mirror of the reference's model/decoder/crosstransformer_decoder.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .blocks import CrossTransformerBlock, ResnetBlockFC
+
+
+class CrossTransformerDecoder(nn.Module):
+    """xyz_q [B,NQ,3] + encoding -> [B,NQ,out_dim]
+    (reference model/decoder/crosstransformer_decoder.py:24-70)."""
+
+    def __init__(self, dim_inp, dim, nneigh=7, hidden_dim=64, n_blocks=5, out_dim=1):
+        super().__init__()
+        self.dim = dim
+        self.n_blocks = n_blocks
+        self.ct1 = CrossTransformerBlock(dim_inp, dim, nneigh=nneigh)
+        self.init_enc = nn.Linear(dim, hidden_dim)
+        self.blocks = nn.ModuleList([ResnetBlockFC(hidden_dim) for _ in range(n_blocks)])
+        self.fc_c = nn.ModuleList([nn.Linear(dim, hidden_dim) for _ in range(n_blocks)])
+        self.fc_out = nn.Linear(hidden_dim, out_dim)
+
+    def forward(self, xyz_q, encoding):
+        lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
+        net = ops.linear(lat, self.init_enc)
+        for i in range(self.n_blocks):
+            net = net + ops.linear(lat, self.fc_c[i])
+            net = self.blocks[i](net)
+        return ops.linear(torch.relu(net), self.fc_out)

@@ -1,0 +1,64 @@
+"""Deformation network = encoder + decoder, and its step functions
+(mirror of the reference's model/deformation_networks.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .decoder import decoder_dict
+from .encoder import encoder_dict
+from .utils import compute_l2_error
+
+
+class Deformation_Networks(nn.Module):
+    """reference model/deformation_networks.py:12-60 (input-channel logic :17-30)."""
+
+    def __init__(self, cfg, no_input_corr=False):
+        super().__init__()
+        self.no_input_corr = no_input_corr
+        use_normals = cfg["model"]["use_normals"]
+        if no_input_corr:
+            has_features, inp_feat_dim = (True, 3) if use_normals else (False, 0)
+        else:
+            has_features, inp_feat_dim = (True, 7) if use_normals else (True, 4)
+        self.encoder = encoder_dict[cfg["model"]["encoder"]](
+            has_features=has_features, inp_feat_dim=inp_feat_dim, **cfg["model"]["encoder_kwargs"])
+        self.decoder = decoder_dict[cfg["model"]["decoder"]](**cfg["model"]["decoder_kwargs"])
+
+    def forward(self, points, surface_samples_inputs):
+        if self.no_input_corr:
+            encoding = self.encoder(surface_samples_inputs[:, :, 0:3].contiguous())
+        else:
+            encoding = self.encoder(surface_samples_inputs)
+        return self.decoder(points, encoding)
+
+
+def train_on_batch_with_cano(model, optimizer, data_dict, config):
+    """reference model/deformation_networks.py:63-77."""
+    optimizer.zero_grad()
+    pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
+    loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
+    loss.backward()
+    optimizer.step()
+    return loss.item()
+
+
+@torch.no_grad()
+def validate_on_batch_with_cano(model, data_dict, config):
+    """reference model/deformation_networks.py:80-88."""
+    pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
+    return compute_l2_error(pred, data_dict["space_samples_tgt"]).item()
+
+
+@torch.no_grad()
+def test_on_batch_with_cano(model, data_dict, config, compute_loss=False):
+    """Dense inference: surface samples, then all mesh vertices (reference :90-109)."""
+    inputs = data_dict["surface_samples_inputs"]
+    data_dict["surface_samples_tgt_pred"] = model(data_dict["surface_samples_src"], inputs)
+    deformed_verts = model(data_dict["verts_src"], inputs)
+    data_dict["verts_tgt_pred"] = deformed_verts
+    if compute_loss:
+        loss = compute_l2_error(deformed_verts, data_dict["verts_tgt"])
+    else:
+        loss = torch.zeros((1), dtype=torch.float32)
+    return loss.item(), data_dict

@@ -1,0 +1,60 @@
+"""Point-Transformer encoder (mirror of the reference's model/encoder/pointransformer.py)."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from .. import ops
+from .blocks import ElementwiseMLP, TransformerBlock, TransitionDown
+
+
+class PointTransformerEncoder(nn.Module):
+    """input [B,N,3(+F)] -> {'z': [B,d], 'anchors': [B,n_last,3], 'anchor_feats': [B,n_last,d]}
+    (reference model/encoder/pointransformer.py:27-140; same constructor kwargs and state_dict keys)."""
+
+    def __init__(self, npoints_per_layer, nneighbor, nneighbor_reduced, nfinal_transformers,
+                 d_transformer, d_reduced, full_SA=False, has_features=False, inp_feat_dim=1):
+        super().__init__()
+        self.d_reduced = d_reduced
+        self.d_transformer = d_transformer
+        self.has_features = has_features
+        self.fc_middle = nn.Sequential(nn.Linear(d_transformer, d_transformer), nn.ReLU(),
+                                       nn.Linear(d_transformer, d_transformer))
+        if has_features:
+            self.enc_sdf = nn.Linear(inp_feat_dim, d_reduced)
+        self.transformer_begin = TransformerBlock(d_reduced, nneighbor_reduced, pos_only=not has_features)
+        self.transition_downs = nn.ModuleList()
+        self.transformer_downs = nn.ModuleList()
+        self.elementwise = nn.ModuleList()
+        self.elementwise_extras = nn.ModuleList()
+        if d_reduced != d_transformer:
+            self.fc1 = nn.Linear(d_reduced, d_transformer)
+        for i in range(len(npoints_per_layer) - 1):
+            old_n, new_n = npoints_per_layer[i], npoints_per_layer[i + 1]
+            dim = d_reduced if i == 0 else d_transformer
+            self.transition_downs.append(TransitionDown(new_n, min(nneighbor, old_n), dim))
+            self.elementwise_extras.append(ElementwiseMLP(dim))
+            self.transformer_downs.append(TransformerBlock(dim, min(nneighbor, new_n)))
+            self.elementwise.append(ElementwiseMLP(d_transformer))
+        self.final_transformers = nn.ModuleList(
+            [TransformerBlock(d_transformer, 2 * nneighbor, group_all=full_SA) for _ in range(nfinal_transformers)])
+        self.final_elementwise = nn.ModuleList(
+            [ElementwiseMLP(dim=d_transformer) for _ in range(nfinal_transformers)])
+
+    def forward(self, xyz):
+        if self.has_features:
+            feats = ops.linear(xyz[:, :, 3:], self.enc_sdf)
+            xyz = xyz[:, :, :3].contiguous()
+            feats = self.transformer_begin(xyz, feats)
+        else:
+            feats = self.transformer_begin(xyz)
+        for i in range(len(self.transition_downs)):
+            xyz, feats = self.transition_downs[i](xyz, feats)
+            feats = self.elementwise_extras[i](feats)
+            feats = self.transformer_downs[i](xyz, feats)
+            if i == 0 and self.d_reduced != self.d_transformer:
+                feats = ops.linear(feats, self.fc1)
+            feats = self.elementwise[i](feats)
+        for blk, mlp in zip(self.final_transformers, self.final_elementwise):
+            feats = mlp(blk(xyz, feats))
+        lat_vec = feats.max(dim=1)[0]
+        return {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}

@@ -1,0 +1,61 @@
+"""Two-network composition source -> canonical -> target
+(mirror of the reference's model/flow_arbitrary.py)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .utils import compute_l2_error
+
+
+class FlowArbitrary(nn.Module):
+    """reference model/flow_arbitrary.py:8-27."""
+
+    def __init__(self, cfg, model_canonicalize, model_deform):
+        super().__init__()
+        self.model_canonicalize = model_canonicalize
+        self.model_deform = model_deform
+
+    def forward(self, space_samples_src, surface_samples_src, surface_samples_tgt, cano_handle_sample_mask):
+        space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
+        surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
+        deform_in = torch.cat([surf_src2cano, surface_samples_tgt, cano_handle_sample_mask], dim=-1).contiguous()
+        return self.model_deform(space_src2cano, deform_in)
+
+
+def _split(data_dict):
+    s = data_dict["surface_samples_inputs"]
+    return s[:, :, 0:3], s[:, :, 3:6], s[:, :, 6:7]
+
+
+def train_on_batch_with_arbitrary(model, optimizer, data_dict, config):
+    """reference model/flow_arbitrary.py:30-48."""
+    optimizer.zero_grad()
+    src, tgt, mask = _split(data_dict)
+    pred = model(data_dict["space_samples_src"], src, tgt, mask)
+    loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
+    loss.backward()
+    optimizer.step()
+    return loss.item()
+
+
+@torch.no_grad()
+def validate_on_batch_with_arbitrary(model, data_dict, config):
+    """reference model/flow_arbitrary.py:51-63."""
+    src, tgt, mask = _split(data_dict)
+    pred = model(data_dict["space_samples_src"], src, tgt, mask)
+    return compute_l2_error(pred, data_dict["space_samples_tgt"]).item()
+
+
+@torch.no_grad()
+def test_on_batch_with_arbitrary(model, data_dict, config, compute_loss=False):
+    """reference model/flow_arbitrary.py:65-85."""
+    src, tgt, mask = _split(data_dict)
+    data_dict["surface_samples_tgt_pred"] = model(src, src, tgt, mask)
+    deformed_verts = model(data_dict["verts_src"], src, tgt, mask)
+    data_dict["verts_tgt_pred"] = deformed_verts
+    if compute_loss:
+        loss = compute_l2_error(deformed_verts, data_dict["verts_tgt"])
+    else:
+        loss = torch.zeros((1), dtype=torch.float32)
+    return loss.item(), data_dict

@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests."""
+import copy
+import json
+import os
+
+import numpy as np
+import torch
+
+from nsdp_amd import synth
+from oracle import tdnet_ref
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def model_cfg(mtype, npl):
+    cfg = copy.deepcopy(tdnet_ref.DEFAULT_MODEL_CFG)
+    cfg["type"] = mtype
+    cfg["encoder_kwargs"]["npoints_per_layer"] = [int(x) for x in npl]
+    return {"model": cfg}
+
+
+def load_fixture(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def fixture_setup(name, mtype):
+    fx = load_fixture(name)
+    seed, b, ns, nq = (int(fx[k]) for k in ("meta_seed", "meta_batch", "meta_ns", "meta_nq"))
+    cfg = model_cfg(mtype, fx["meta_npl"])
+    data = synth.make_batch(seed, b, ns, nq)
+    return fx, cfg, seed, data
+
+
+def build_product(cfg, seed, device):
+    """The HIP product model with procedural weights (same generator the fixtures were made with)."""
+    from nsdp_amd.model import build_model
+    model, train_fn, val_fn, test_fn = build_model(cfg, device="cpu")
+    state = synth.procedural_state_dict(model.state_dict(), seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    return model.to(device), train_fn, state
+
+
+def to_dev(data, device):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(device) for k, v in data.items()}
+
+
+def run_forward(model, cfg, data):
+    if cfg["model"]["type"] == "arbitrary":
+        s = data["surface_samples_inputs"]
+        return model(data["space_samples_src"], s[:, :, 0:3], s[:, :, 3:6], s[:, :, 6:7])
+    return model(data["space_samples_src"], data["surface_samples_inputs"])
+
+
+def sample_flat(t, n):
+    f = t.detach().reshape(-1).cpu()
+    if f.numel() <= n:
+        return f.numpy()
+    return f[torch.linspace(0, f.numel() - 1, n).long()].numpy()
+
+
+def l2_err(a, b):
+    """max over shapes of sqrt(mean_n ||delta||^2)  (SURVEY.md section 8c parity metric)."""
+    d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
+    return float(np.sqrt((d ** 2).sum(-1).mean(-1)).max())

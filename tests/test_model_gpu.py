@@ -1,0 +1,108 @@
+"""GPU parity of the TDNet hot path against the golden fixtures (imported reference) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_product, fixture_setup, l2_err, model_cfg, run_forward, sample_flat, to_dev
+from nsdp_amd import synth
+from oracle import tdnet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL_L2 = 1e-4  # north-star bar: <= 1e-4 L2 vs the reference CPU path, fp32
+
+
+def _hooks(model, tape):
+    from nsdp_amd.model.decoder.blocks import CrossTransformerBlock
+    from nsdp_amd.model.encoder.blocks import ElementwiseMLP, TransformerBlock, TransformerSetAbstraction
+    hs = []
+    for name, mod in model.named_modules():
+        if isinstance(mod, (TransformerBlock, ElementwiseMLP, CrossTransformerBlock)):
+            hs.append(mod.register_forward_hook(lambda m, i, o, name=name: tape.__setitem__(name + ".out", o.detach())))
+        elif isinstance(mod, TransformerSetAbstraction):
+            hs.append(mod.register_forward_hook(lambda m, i, o, name=name: tape.__setitem__(name + ".out", o[1].detach())))
+    return hs
+
+
+@pytest.mark.parametrize("mtype", ["forward", "backward", "arbitrary"])
+def test_eval_forward_matches_golden(mtype):
+    fx, cfg, seed, data = fixture_setup("tiny_" + mtype, mtype)
+    model, _, _ = build_product(cfg, seed, DEV)
+    model.eval()
+    tape = {}
+    hs = _hooks(model, tape)
+    with torch.no_grad():
+        out = run_forward(model, cfg, to_dev(data, DEV))
+    for h in hs:
+        h.remove()
+    assert l2_err(out.cpu().numpy(), fx["eval_out"]) <= TOL_L2
+    checked = 0
+    for key, ref in fx.items():
+        if key.startswith("eval_tap/"):
+            mine = tape[key[len("eval_tap/"):]]
+            mine = mine.cpu().numpy() if mine.numel() == ref.size and mine.dim() > 1 else sample_flat(mine, 64)
+            np.testing.assert_allclose(mine.reshape(ref.shape), ref, rtol=0, atol=2e-4, err_msg=key)
+            checked += 1
+    assert checked >= 15
+
+
+def test_full_shape_forward_matches_golden():
+    """BASELINE configs[0]/[1] geometry: 2048 surface + 8192 query points, forward.yaml architecture."""
+    fx, cfg, seed, data = fixture_setup("full_forward", "forward")
+    model, _, _ = build_product(cfg, seed, DEV)
+    model.eval()
+    with torch.no_grad():
+        out = run_forward(model, cfg, to_dev(data, DEV))
+    err = l2_err(out.cpu().numpy(), fx["eval_out"])
+    assert err <= TOL_L2, err
+
+
+@pytest.mark.parametrize("mtype", ["forward", "backward", "arbitrary"])
+def test_train_step_matches_golden(mtype):
+    fx, cfg, seed, data = fixture_setup("tiny_" + mtype, mtype)
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    from nsdp_amd.model import optimizer_factory
+    model.train()
+    _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
+                                "weight_decay": 0.0}, model.parameters())
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    loss = train_fn(model, opt, to_dev(data, DEV), cfg)
+    assert abs(loss - float(fx["train_loss"])) <= 2e-5 * max(1.0, abs(loss))
+    none = sorted(k for k, p in model.named_parameters() if p.grad is None)
+    assert none == sorted(str(s) for s in fx["none_grads"])
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        gn = float(fx["grad_norm/" + k])
+        mine = float(p.grad.double().norm())
+        assert abs(mine - gn) <= 1e-3 * gn + 1e-6, (k, mine, gn)
+        np.testing.assert_allclose(sample_flat(p.grad, 16), fx["grad_sample/" + k], rtol=5e-3,
+                                   atol=1e-4 * max(gn, 1e-3), err_msg=k)
+    sd = model.state_dict()
+    for key, ref in fx.items():
+        if key.startswith("bn_after/"):
+            mine = sd[key[len("bn_after/"):]]
+            mine = mine.cpu().numpy() if key.endswith("num_batches_tracked") else sample_flat(mine, 16)
+            np.testing.assert_allclose(mine, ref, rtol=2e-4, atol=2e-6, err_msg=key)
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = fx["grad_sample/" + k]
+        sel = np.abs(g) > 1e-5
+        np.testing.assert_allclose(sample_flat(p.detach() - before[k], 16)[sel], fx["delta_sample/" + k][sel],
+                                   rtol=2e-3, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("mtype,seed", [("forward", 5), ("backward", 6)])
+def test_eval_forward_matches_oracle_other_inputs(mtype, seed):
+    """Same seeded inputs through the HIP path and the CPU oracle (ragged sizes, batch 3)."""
+    npl = [300, 70, 20]
+    cfg = model_cfg(mtype, npl)
+    data = synth.make_batch(seed, 3, 300, 203)
+    model, _, state = build_product(cfg, seed, DEV)
+    model.eval()
+    with torch.no_grad():
+        out = run_forward(model, cfg, to_dev(data, DEV)).cpu().numpy()
+        sd = tdnet_ref.to_torch_state(state)
+        ref = tdnet_ref.model_forward(sd, cfg["model"], {k: torch.from_numpy(v) for k, v in data.items()}).numpy()
+    assert l2_err(out, ref) <= TOL_L2
