@@ -1,0 +1,76 @@
+"""Per-kernel timing of the hand-written HIP kernels with HIP events recorded on the launch stream
+(C side: nsdp_prof_* in csrc/api.hip), used by bench.py to report the roofline of the dominant kernel."""
+from __future__ import annotations
+
+import ctypes
+
+from . import _lib
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBPS = 8000.0
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+_active = False
+
+
+def available() -> bool:
+    return hasattr(_lib.lib(), "nsdp_prof_enable")
+
+
+def start():
+    global _active
+    if available():
+        _lib.lib().nsdp_prof_enable(1)
+        _active = True
+
+
+def stop():
+    """Returns {kernel: {'launches', 'ms', 'flops', 'bytes'}} accumulated since start()."""
+    global _active
+    if not _active:
+        return {}
+    lib = _lib.lib()
+    lib.nsdp_prof_enable(0)
+    _active = False
+    n = lib.nsdp_prof_num_kinds()
+    lib.nsdp_prof_name.restype = ctypes.c_char_p
+    out = {}
+    for kind in range(n):
+        cnt = ctypes.c_longlong(0)
+        ms = ctypes.c_double(0)
+        flops = ctypes.c_double(0)
+        nbytes = ctypes.c_double(0)
+        lib.nsdp_prof_collect(kind, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(flops), ctypes.byref(nbytes))
+        if cnt.value:
+            out[lib.nsdp_prof_name(kind).decode()] = {"launches": cnt.value, "ms": ms.value,
+                                                      "flops": flops.value, "bytes": nbytes.value}
+    return out
+
+
+def summary(prof):
+    if not prof:
+        return None
+    return {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                "tflops": round(v["flops"] / (v["ms"] * 1e9), 2) if v["ms"] > 0 and v["flops"] else None,
+                "gbps": round(v["bytes"] / (v["ms"] * 1e6), 1) if v["ms"] > 0 and v["bytes"] else None}
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+
+def roofline(prof):
+    """Roofline object for the kernel with the largest total time."""
+    if not prof:
+        return None
+    name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_ms = v["ms"] / v["launches"]
+    flops_per_launch = v["flops"] / v["launches"]
+    bytes_per_launch = v["bytes"] / v["launches"]
+    intensity = flops_per_launch / max(bytes_per_launch, 1.0)
+    if intensity > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9):
+        achieved = flops_per_launch / (per_launch_ms * 1e9)
+        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches": v["launches"], "avg_launch_ms": round(per_launch_ms, 4)}
+    achieved = bytes_per_launch / (per_launch_ms * 1e6)
+    return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None, "launches": v["launches"],
+            "avg_launch_ms": round(per_launch_ms, 4)}

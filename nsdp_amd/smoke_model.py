@@ -13,7 +13,8 @@ def run(device) -> None:
     from nsdp_amd.model import build_model, optimizer_factory
     from oracle import tdnet_ref
 
-    cfg = {"model": copy.deepcopy(tdnet_ref.DEFAULT_MODEL_CFG)}
+    from nsdp_amd.config import default_config
+    cfg = default_config("forward")
     cfg["model"]["encoder_kwargs"]["npoints_per_layer"] = [256, 64, 16]
     model, train_fn, _, _ = build_model(cfg, device="cpu")
     state = synth.procedural_state_dict(model.state_dict(), 99)

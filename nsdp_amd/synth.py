@@ -100,7 +100,7 @@ def procedural_state_dict(template: dict, seed: int) -> dict:
             out[key] = uniform(seed, key, shape, -0.1, 0.1)
         elif leaf == "weight":
             fan_in = int(np.prod(shape[1:]))
-            bound = float(np.sqrt(3.0 / max(fan_in, 1)))  # unit-gain uniform
+            bound = float(np.sqrt(1.0 / max(fan_in, 1)))  # PyTorch-default-like scale: outputs O(1)
             out[key] = uniform(seed, key, shape, -bound, bound)
         else:
             raise KeyError(f"unhandled state_dict entry {key} {shape}")

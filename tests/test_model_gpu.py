@@ -53,7 +53,17 @@ def test_full_shape_forward_matches_golden():
     model.eval()
     with torch.no_grad():
         out = run_forward(model, cfg, to_dev(data, DEV))
-    err = l2_err(out.cpu().numpy(), fx["eval_out"])
+    # torch.argsort (the reference's kNN) is not stable: when the k-th and (k+1)-th anchor distances of a
+    # query are bit-equal the reference's neighbour SET is arbitrary; such queries
+    # (1 of 8192 here) are excluded -- everything else must meet the bar.
+    from oracle import pointnet2_ref
+    xyz0 = np.ascontiguousarray(data["surface_samples_inputs"][:, :, :3])
+    xyz1 = np.take_along_axis(xyz0, fx["geo/fps1"][..., None].astype(np.int64), 1)
+    xyz2 = np.take_along_axis(xyz1, fx["geo/fps2"][..., None].astype(np.int64), 1)
+    _, d2 = pointnet2_ref.knn(data["space_samples_src"], xyz2, 8, return_dist=True)
+    keep = d2[0, :, 6] != d2[0, :, 7]
+    assert (~keep).sum() <= 2
+    err = l2_err(out.cpu().numpy()[:, keep], fx["eval_out"][:, keep])
     assert err <= TOL_L2, err
 
 
@@ -75,9 +85,11 @@ def test_train_step_matches_golden(mtype):
             continue
         gn = float(fx["grad_norm/" + k])
         mine = float(p.grad.double().norm())
-        assert abs(mine - gn) <= 1e-3 * gn + 1e-6, (k, mine, gn)
+        # absolute floor: some gradients (e.g. fc_delta.2.bias in front of a train-mode BatchNorm) are
+        # analytically ~0 and consist of fp32 cancellation noise whose value depends on summation order
+        assert abs(mine - gn) <= 1e-3 * gn + 2e-5, (k, mine, gn)
         np.testing.assert_allclose(sample_flat(p.grad, 16), fx["grad_sample/" + k], rtol=5e-3,
-                                   atol=1e-4 * max(gn, 1e-3), err_msg=k)
+                                   atol=1e-4 * gn + 5e-6, err_msg=k)
     sd = model.state_dict()
     for key, ref in fx.items():
         if key.startswith("bn_after/"):
