@@ -18,6 +18,7 @@
 #ifndef NSDP_HIP_H_
 #define NSDP_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -94,6 +95,40 @@ int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int 
 /* backward of index_points: grad_points(B,N,C) += scatter of grad_out(B,S,C) (zero-filled first). */
 int nsdp_scatter_add_rows(const float *grad_out, const int32_t *idx, int B, int N, int C, int S,
                           float *grad_points, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Dense layers of the path on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32)
+ * replace the ATen addmm calls behind nn.Linear / 1x1 nn.Conv1d in model/encoder/blocks.py and
+ * model/decoder/{blocks,crosstransformer_decoder}.py (e.g. blocks.py:114-117, decoder/blocks.py:78-88,
+ * crosstransformer_decoder.py:63-69).
+ * -------------------------------------------------------------------------------------------- */
+
+/* Y[M,N] = post( pre(X)[M,K] * W[N,K]^T + bias[N] (+ residual[M,N]) );
+ * pre(X) = X, relu(X) (relu_in) and/or X * (mask[M,K] > 0) (ReLU backward of the producing layer);
+ * post = ReLU if relu_out, then * (out_mask[M,N] > 0) if out_mask (ReLU backward of a relu_in layer).
+ * bias / residual / mask / out_mask may be NULL.  K % 4 == 0, N <= 256, X/W/mask 16-byte aligned,
+ * dense row-major. */
+int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
+                    const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                    int relu_in, int relu_out, void *stream);
+
+/* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
+ * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.
+ * Deterministic (two-stage
+ * reduction through `workspace`, >= nsdp_linear_wgrad_workspace_bytes(M,N,K) bytes, no atomics). */
+size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K);
+int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                          float *db, long long M, int N, int K, int accumulate, float *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Kernel timing with HIP events on the launch stream (used by bench.py for the roofline object)
+ * -------------------------------------------------------------------------------------------- */
+void nsdp_prof_enable(int on);            /* on=1 clears previous records and starts recording */
+int nsdp_prof_num_kinds(void);
+const char *nsdp_prof_name(int kind);
+/* Sums over all recorded launches of `kind`: count, elapsed ms, algorithmic flops and bytes. */
+int nsdp_prof_collect(int kind, long long *launches, double *total_ms, double *flops, double *bytes);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,13 @@
-// ABI bookkeeping for libnsdp_hip.so: version, thread-local last-error string, device probe.
+// ABI bookkeeping for libnsdp_hip.so: version, thread-local last-error string, device probe, and the
+// optional HIP-event kernel profiler used by bench.py.
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
+#include <vector>
 
 #include "common.h"
+#include "prof.h"
 
 namespace nsdp {
 static thread_local char g_last_error[512] = "";
@@ -13,11 +18,62 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
   va_end(ap);
 }
+
+namespace prof {
+
+namespace {
+struct Record {
+  int kind;
+  hipEvent_t start, stop;
+  double flops, bytes;
+};
+std::atomic<int> g_enabled{0};
+std::mutex g_mu;
+std::vector<Record> g_records;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+const char *kind_name(int kind) {
+  static const char *names[kNumKinds] = {"linear_nt_kernel",  "linear_wgrad_kernel", "fps_kernel",
+                                         "knn_kernel",        "gather_rows_kernel",  "scatter_add_rows_kernel",
+                                         "attn_fwd_kernels",  "attn_bwd_kernels",    "batch_norm_kernels",
+                                         "decoder_fwd_kernel"};
+  return (kind >= 0 && kind < kNumKinds) ? names[kind] : "?";
+}
+
+Scope::Scope(Kind kind, hipStream_t stream, double flops, double bytes) : slot_(-1), stream_(stream) {
+  if (!g_enabled.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_mu);
+  Record r{static_cast<int>(kind), get_event(), get_event(), flops, bytes};
+  if (!r.start || !r.stop) return;
+  (void)hipEventRecord(r.start, stream);
+  g_records.push_back(r);
+  slot_ = static_cast<int>(g_records.size()) - 1;
+}
+
+Scope::~Scope() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (slot_ < static_cast<int>(g_records.size())) (void)hipEventRecord(g_records[slot_].stop, stream_);
+}
+
+}  // namespace prof
 }  // namespace nsdp
 
 extern "C" {
 
-int nsdp_abi_version(void) { return 1; }
+int nsdp_abi_version(void) { return 2; }
 
 const char *nsdp_last_error(void) { return nsdp::g_last_error; }
 
@@ -28,6 +84,45 @@ int nsdp_device_count(void) {
     return 0;
   }
   return n;
+}
+
+void nsdp_prof_enable(int on) {
+  using namespace nsdp::prof;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (on) {
+    for (auto &r : g_records) {
+      g_pool.push_back(r.start);
+      g_pool.push_back(r.stop);
+    }
+    g_records.clear();
+  }
+  g_enabled.store(on ? 1 : 0);
+}
+
+int nsdp_prof_num_kinds(void) { return nsdp::prof::kNumKinds; }
+
+const char *nsdp_prof_name(int kind) { return nsdp::prof::kind_name(kind); }
+
+int nsdp_prof_collect(int kind, long long *launches, double *total_ms, double *flops, double *bytes) {
+  using namespace nsdp::prof;
+  std::lock_guard<std::mutex> lock(g_mu);
+  long long n = 0;
+  double ms = 0, fl = 0, by = 0;
+  for (auto &r : g_records) {
+    if (r.kind != kind) continue;
+    if (hipEventSynchronize(r.stop) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) continue;
+    ++n;
+    ms += t;
+    fl += r.flops;
+    by += r.bytes;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = fl;
+  if (bytes) *bytes = by;
+  return 0;
 }
 
 }  // extern "C"

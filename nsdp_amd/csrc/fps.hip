@@ -20,6 +20,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "prof.h"
 
 #pragma clang fp contract(off)
 
@@ -231,6 +232,7 @@ extern "C" int nsdp_furthest_point_sampling(const float *xyz, int B, int N, int 
   NSDP_REQUIRE(N > 0, "fps: N must be positive (got %d)", N);
   NSDP_REQUIRE((static_cast<long long>(N) >> kRankShift) == 0, "fps: N too large (%d)", N);
   hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kFps, st, 0.0, static_cast<double>(B) * (12.0 * N + 4.0 * nsamples));
   const int BS = opt_n_threads(N);
   int log2BS = 0;
   while ((1 << log2BS) < BS) ++log2BS;

@@ -1,0 +1,429 @@
+// fp32 dense layers on the CDNA4 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, 157 TF peak).
+//
+// Every dense layer of the TDNet hot path is "tall-skinny": rows M = B*n*k is huge (10^5..10^6) while
+// N, K <= 256 (120 / 128 / 200 / 256).  A generic square-tile LDS GEMM is the wrong shape for that, so:
+//
+//   nsdp_linear_f32        Y[M,N] = act( pre(X)[M,K] * W[N,K]^T + b ) (+ residual)
+//       one wave owns MT*16 complete rows and ALL N columns: X is read exactly once (HBM), the
+//       <=256 KiB weight matrix is re-read per wave from L1/L2.  Both operands go global -> VGPR as
+//       float4 (16 B/lane) with a k-permuted fragment convention (lane group g supplies k = 16*kb+4g+s
+//       at MFMA step s for A and B alike), so no LDS staging/transposition is needed at all and a wave
+//       never waits on a barrier.  Prologue fusions: relu(X), X * (mask > 0) (ReLU backward);
+//       epilogue fusions: bias, ReLU, residual add.
+//   nsdp_linear_wgrad_f32  dW[N,K] = pre(dY)[M,N]^T * X[M,K],  db[N] = colsum(pre(dY))
+//       split over row chunks (deterministic two-stage reduction through a workspace, no atomics);
+//       rows are the MFMA k dimension, so both operands are read in their natural row-major layout.
+//
+// Activations stay fp32 end to end: the north-star parity bar (1e-4 L2 vs the CPU reference) leaves no
+// room for bf16 inputs, and gfx950 has no TF32/xf32 path.
+#include <type_traits>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct LinearParams {
+  const float *X, *W, *bias, *residual, *mask, *out_mask;
+  float *Y;
+  long long M;
+  int N, K;
+  int relu_in, relu_out;
+};
+
+// PRE: 0 = plain X, 1 = X * (mask > 0), 2 = relu(X).  All global loads are UNCONDITIONAL (indices are
+// clamped into the tensor instead of predicated): hipcc turns a per-load predicate into a branch plus
+// s_waitcnt vmcnt(0), which serialises the whole operand stream.  Rows >= M and columns >= N compute
+// garbage that is never stored; the ragged last k-block (K % 16 != 0) is handled by zeroing the weight
+// fragment with a select while the activation fragment re-reads in-row (finite) data.
+template <int MT, int NT, int PRE>
+__global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const long long row0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * (MT * 16);
+  if (row0 >= p.M) return;  // whole wave out of range (no barriers in this kernel)
+  const int K = p.K, N = p.N;
+
+  f32x4 acc[MT][NT];
+  if (p.residual) {  // residual add fused as the accumulator's initial value (loads overlap the k loop)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int col = nt * 16 + li;
+        col = col < N ? col : (N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          long long row = row0 + mt * 16 + g * 4 + r;
+          row = row < p.M ? row : (p.M - 1);
+          acc[mt][nt][r] = p.residual[row * N + col];
+        }
+      }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const float *xa[MT];
+  const float *ma[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long long r = row0 + mt * 16 + li;
+    r = r < p.M ? r : (p.M - 1);
+    xa[mt] = p.X + r * K;
+    ma[mt] = PRE == 1 ? p.mask + r * K : nullptr;
+  }
+  const float *wb[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int n = nt * 16 + li;
+    n = n < N ? n : (N - 1);
+    wb[nt] = p.W + static_cast<long long>(n) * K;
+  }
+
+  const int KB = (K + 15) >> 4;
+
+  // Software pipeline, two register buffers.  Phase = { issue the raw loads of block kb+1 ; MFMAs of
+  // block kb }.  hipcc's scheduler otherwise sinks the prefetch loads down to their first use (minimum
+  // register pressure) and the wave then sits in s_waitcnt for a full L2/HBM round trip per k-block,
+  // so the phases are fenced with sched_barrier and the loads are interleaved with the first MFMAs by
+  // sched_group_barrier.  The operand fix-ups (k-tail zeroing, ReLU / mask prologue) run at the START
+  // of the phase that consumes the buffer, a whole MFMA phase after its loads were issued.
+  struct Frag {
+    float4 a[MT];
+    float4 m[PRE == 1 ? MT : 1];
+    float4 b[NT];
+  };
+  auto issue = [&](int kb, Frag &f) {
+    int ko = kb * 16 + 4 * g;
+    ko = ko < K ? ko : (K - 4);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f.a[mt] = *reinterpret_cast<const float4 *>(xa[mt] + ko);
+      if (PRE == 1) f.m[mt] = *reinterpret_cast<const float4 *>(ma[mt] + ko);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f.b[nt] = *reinterpret_cast<const float4 *>(wb[nt] + ko);
+  };
+  auto fixup = [&](int kb, Frag &f) {
+    const bool kv = kb * 16 + 4 * g < K;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float4 v = f.a[mt];
+      if (PRE == 1) {
+        const float4 m = f.m[mt];
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+      }
+      if (PRE == 2) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      f.a[mt] = v;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float4 v = f.b[nt];
+      v.x = kv ? v.x : 0.f; v.y = kv ? v.y : 0.f; v.z = kv ? v.z : 0.f; v.w = kv ? v.w : 0.f;
+      f.b[nt] = v;
+    }
+  };
+  auto mma = [&](const Frag &f) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt].x, f.b[nt].x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt].y, f.b[nt].y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt].z, f.b[nt].z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[mt].w, f.b[nt].w, acc[mt][nt], 0, 0, 0);
+  };
+  constexpr int kLoads = MT * (PRE == 1 ? 2 : 1) + NT;
+  auto interleave = [&]() {  // 1 VMEM read, then 4 MFMAs, kLoads times; the rest of the MFMAs follow
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+  };
+
+  Frag f0, f1;
+  issue(0, f0);
+  __builtin_amdgcn_sched_barrier(0);
+  int kb = 0;
+  for (; kb + 2 <= KB; kb += 2) {
+    fixup(kb, f0);
+    issue(kb + 1, f1);
+    mma(f0);
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+    fixup(kb + 1, f1);
+    // kb + 2 == KB re-loads a valid block whose result is never used: keeps the loop branch-free
+    issue(kb + 2 < KB ? kb + 2 : kb, f0);
+    mma(f1);
+    interleave();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kb < KB) {
+    fixup(kb, f0);
+    mma(f0);
+  }
+
+  // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Loads are unconditional from
+  // clamped indices (see above); only the stores are predicated.
+  const bool full_rows = row0 + MT * 16 <= p.M;  // wave-uniform
+  auto epilogue = [&](auto has_omask) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + li;
+      const bool cv = col < N;
+      const int colc = cv ? col : (N - 1);
+      const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = row0 + mt * 16 + g * 4 + r;
+          const bool rv = full_rows || row < p.M;
+          const long long rowc = rv ? row : (p.M - 1);
+          float v = acc[mt][nt][r] + bv;
+          if (p.relu_out) v = fmaxf(v, 0.f);
+          if (decltype(has_omask)::value) v = p.out_mask[rowc * N + colc] > 0.f ? v : 0.f;
+          if (cv && rv) p.Y[rowc * N + colc] = v;
+        }
+      }
+    }
+  };
+  if (p.out_mask) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+}
+
+template <int MT, int NT>
+int launch_nt(const LinearParams &p, hipStream_t st) {
+  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
+  const long long rows_per_wg = 4LL * MT * 16;
+  const long long grid = (p.M + rows_per_wg - 1) / rows_per_wg;
+  nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
+                          4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
+  const dim3 gr(static_cast<unsigned>(grid));
+  if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0>), gr, dim3(256), 0, st, p);
+  else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1>), gr, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2>), gr, dim3(256), 0, st, p);
+  return nsdp::launch_status("linear_nt_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[N,K] = pre(dY)^T X over a chunk of rows per workgroup
+// ------------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float *dY, *X, *mask;
+  int relu_x;
+  float *ws;      // [S][N*K + N] partials
+  long long M;
+  int N, K;
+  long long rows_per_chunk;  // multiple of 16
+  int want_db;
+};
+
+// kWgN = n-tiles per wave (the workgroup's 4 waves cover 4*kWgN n-tiles >= N/16), TK = k-tiles per wave.
+template <int kWgN, int TK>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = p.N, K = p.K;
+  if (wave * kWgN * 16 >= N) return;  // idle wave (no barriers / LDS in this kernel)
+  const int ktile0 = blockIdx.y * TK;
+  const long long m_begin = static_cast<long long>(blockIdx.x) * p.rows_per_chunk;
+  const long long m_end = min(p.M, m_begin + p.rows_per_chunk);
+
+  f32x4 acc[kWgN][TK];
+#pragma unroll
+  for (int a = 0; a < kWgN; ++a)
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbsum[kWgN];
+#pragma unroll
+  for (int a = 0; a < kWgN; ++a) dbsum[a] = 0.f;
+
+  int ncol[kWgN];  // clamped column indices: out-of-range tiles compute garbage that is never stored
+#pragma unroll
+  for (int a = 0; a < kWgN; ++a) {
+    const int c = (wave * kWgN + a) * 16 + li;
+    ncol[a] = c < N ? c : (N - 1);
+  }
+  int kcol[TK];
+#pragma unroll
+  for (int b = 0; b < TK; ++b) {
+    const int c = (ktile0 + b) * 16 + li;
+    kcol[b] = c < K ? c : (K - 1);
+  }
+
+  for (long long mb = m_begin; mb < m_end; mb += 16) {
+    float av[4][kWgN], bvv[4][TK];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long long m = mb + 4 * g + s;
+      const bool mv = m < m_end;                 // rows past the chunk contribute zero (select, no branch)
+      const long long mc = mv ? m : (p.M - 1);   // ... but are still loaded from a valid address
+#pragma unroll
+      for (int a = 0; a < kWgN; ++a) {
+        float v = p.dY[mc * N + ncol[a]];
+        if (p.mask) {
+          const float mk = p.mask[mc * N + ncol[a]];
+          v = mk > 0.f ? v : 0.f;
+        }
+        av[s][a] = mv ? v : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < TK; ++b) {
+        const float xv_ = p.X[mc * K + kcol[b]];
+        bvv[s][b] = p.relu_x ? fmaxf(xv_, 0.f) : xv_;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int a = 0; a < kWgN; ++a) {
+        dbsum[a] += av[s][a];
+#pragma unroll
+        for (int b = 0; b < TK; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][a], bvv[s][b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+
+  float *out = p.ws + static_cast<long long>(blockIdx.x) * (static_cast<long long>(N) * K + N);
+#pragma unroll
+  for (int a = 0; a < kWgN; ++a) {
+#pragma unroll
+    for (int b = 0; b < TK; ++b) {
+      const int kc = (ktile0 + b) * 16 + li;  // D col = lane & 15 -> k index
+      if (kc >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (wave * kWgN + a) * 16 + g * 4 + r;  // D row -> n index
+        if (n < N) out[static_cast<long long>(n) * K + kc] = acc[a][b][r];
+      }
+    }
+  }
+  if (p.want_db && blockIdx.y == 0) {
+#pragma unroll
+    for (int a = 0; a < kWgN; ++a) {
+      float v = dbsum[a];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const int n = (wave * kWgN + a) * 16 + li;
+      if (g == 0 && n < N) out[static_cast<long long>(N) * K + n] = v;
+    }
+  }
+}
+
+__global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long long stride,
+                                       long long nw, float *__restrict__ dW, long long nb,
+                                       float *__restrict__ db, int accumulate) {
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  if (e >= nw + nb) return;
+  float s = 0.f;
+  for (int c = 0; c < S; ++c) s += ws[c * stride + e];
+  if (e < nw) {
+    dW[e] = accumulate ? dW[e] + s : s;
+  } else if (db) {
+    db[e - nw] = accumulate ? db[e - nw] + s : s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
+                    const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                    int relu_in, int relu_out, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X && W && Y, "linear: null pointer");
+  NSDP_REQUIRE(K > 0 && K % 4 == 0, "linear: K=%d must be a positive multiple of 4", K);
+  NSDP_REQUIRE(N <= 256, "linear: N=%d > 256 is not supported", N);
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0 &&
+                   (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0),
+               "linear: X/W/mask must be 16-byte aligned");
+  LinearParams p{X, W, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out};
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 1) return launch_nt<4, 1>(p, st);
+  if (nt <= 4) return launch_nt<4, 4>(p, st);
+  if (nt <= 8) return launch_nt<4, 8>(p, st);
+  if (nt <= 13) return launch_nt<2, 13>(p, st);
+  return launch_nt<2, 16>(p, st);
+}
+
+size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K) {
+  if (M <= 0) return 0;
+  long long chunks = (M + 1023) / 1024;
+  if (chunks > 512) chunks = 512;
+  if (chunks < 1) chunks = 1;
+  return static_cast<size_t>(chunks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
+}
+
+int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                          float *db, long long M, int N, int K, int accumulate, float *workspace,
+                          size_t workspace_bytes, void *stream) {
+  if (N <= 0 || K <= 0) return 0;
+  NSDP_REQUIRE(dW, "linear_wgrad: null output");
+  NSDP_REQUIRE(N <= 256, "linear_wgrad: N=%d > 256 is not supported", N);
+  hipStream_t st = nsdp::as_stream(stream);
+  if (M <= 0) {
+    if (!accumulate) {
+      NSDP_HIP_TRY(hipMemsetAsync(dW, 0, sizeof(float) * static_cast<size_t>(N) * K, st));
+      if (db) NSDP_HIP_TRY(hipMemsetAsync(db, 0, sizeof(float) * static_cast<size_t>(N), st));
+    }
+    return 0;
+  }
+  NSDP_REQUIRE(dY && X && workspace, "linear_wgrad: null pointer");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_workspace_bytes(M, N, K),
+               "linear_wgrad: workspace too small");
+  long long chunks = (M + 1023) / 1024;
+  if (chunks > 512) chunks = 512;
+  long long rows = (M + chunks - 1) / chunks;
+  rows = (rows + 15) / 16 * 16;
+  chunks = (M + rows - 1) / rows;
+  WgradParams p{dY, X, mask, relu_x, workspace, M, N, K, rows, db != nullptr};
+  const int ktiles = (K + 15) / 16;
+  {
+    nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K,
+                            4.0 * (static_cast<double>(M) * (K + N)));
+    const unsigned gx = static_cast<unsigned>(chunks);
+    if (N <= 64) {
+      hipLaunchKernelGGL((linear_wgrad_kernel<1, 16>), dim3(gx, (ktiles + 15) / 16), dim3(256), 0, st, p);
+    } else if (N <= 128) {
+      hipLaunchKernelGGL((linear_wgrad_kernel<2, 16>), dim3(gx, (ktiles + 15) / 16), dim3(256), 0, st, p);
+    } else if (ktiles <= 4) {
+      hipLaunchKernelGGL((linear_wgrad_kernel<4, 4>), dim3(gx, 1), dim3(256), 0, st, p);
+    } else {
+      hipLaunchKernelGGL((linear_wgrad_kernel<4, 8>), dim3(gx, (ktiles + 7) / 8), dim3(256), 0, st, p);
+    }
+    int rc = nsdp::launch_status("linear_wgrad_kernel");
+    if (rc) return rc;
+  }
+  const long long nw = static_cast<long long>(N) * K;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0,
+                     st, workspace, static_cast<int>(chunks), nw + N, nw, dW, static_cast<long long>(N), db,
+                     accumulate);
+  return nsdp::launch_status("reduce_partials_kernel");
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@
 #include <cfloat>
 
 #include "common.h"
+#include "prof.h"
 
 #pragma clang fp contract(off)
 
@@ -106,6 +107,8 @@ extern "C" int nsdp_knn(const float *query, const float *source, int B, int n, i
   NSDP_REQUIRE(k <= 64, "knn: k=%d > 64 is not supported", k);
   NSDP_REQUIRE(B <= 65535, "knn: batch %d too large for one launch", B);
   hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kKnn, st, 0.0,
+                          static_cast<double>(B) * (12.0 * (n + m) + 4.0 * n * k * (dist2_out ? 2 : 1)));
   if (k <= 8) return launch<8>(query, source, B, n, m, k, idx_out, dist2_out, st);
   if (k <= 16) return launch<16>(query, source, B, n, m, k, idx_out, dist2_out, st);
   if (k <= 32) return launch<32>(query, source, B, n, m, k, idx_out, dist2_out, st);

@@ -7,6 +7,7 @@
 // output index on consecutive lanes (coalesced stores; gathers hit L2).  All of them are HBM-bound byte
 // movers -- no LDS reuse exists except for the ball-query / 3-NN source cloud, which is LDS-tiled.
 #include "common.h"
+#include "prof.h"
 
 #pragma clang fp contract(off)
 
@@ -334,6 +335,8 @@ int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int 
   if (total <= 0) return 0;
   NSDP_REQUIRE(points && idx && out && N > 0, "gather_rows: bad argument");
   hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kGatherRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * S * (1 + C) + static_cast<double>(B) * N * C));
   const bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
   if (vec4) {
     const long long tv = total / 4;
@@ -355,6 +358,8 @@ int nsdp_scatter_add_rows(const float *grad_out, const int32_t *idx, int B, int 
     NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * N * C, st));
   if (total <= 0) return 0;
   NSDP_REQUIRE(grad_out && idx, "scatter_add_rows: null pointer");
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * S * (1 + C) + 2.0 * static_cast<double>(B) * N * C));
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, grad_out,
                      idx, total, N, C, S, grad_points);
   return nsdp::launch_status("scatter_add_rows_kernel");

@@ -1,0 +1,102 @@
+"""Dense layers on the fp32 matrix cores: autograd wrapper over nsdp_linear_f32 / nsdp_linear_wgrad_f32.
+
+``linear(x, weight, bias, relu_in, relu_out, residual)`` computes
+``post(pre(x) @ weight.T + bias (+ residual))`` on channels-last rows; the backward pass runs two more
+hand-written MFMA kernels (dX = dY' @ W with the ReLU masks fused into the operand load / epilogue, and
+the split-row dW = dY'^T X with the bias gradient as a by-product).  No torch/rocBLAS GEMM is involved.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
+
+_ll = ctypes.c_longlong
+_ci = ctypes.c_int
+
+
+def _fwd(x2, w, b, residual, mask, out_mask, relu_in, relu_out):
+    M, K = x2.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_f32(fptr(x2, "x"), fptr(w, "weight"), optptr(b), optptr(residual), optptr(mask),
+                                    optptr(out_mask), fptr(y), _ll(M), _ci(N), _ci(K), _ci(int(relu_in)),
+                                    _ci(int(relu_out)), stream_ptr()), "nsdp_linear_f32")
+    return y
+
+
+def _wgrad(dy2, x2, mask, relu_x, want_db):
+    M, N = dy2.shape
+    K = x2.shape[1]
+    L = lib()
+    L.nsdp_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.nsdp_linear_wgrad_workspace_bytes(_ll(M), _ci(N), _ci(K)))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    with on_device(dy2):
+        check(L.nsdp_linear_wgrad_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
+                                      optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws),
+                                      ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_wgrad_f32")
+    return dw, db
+
+
+def _pad_cols(t, mult=4):
+    r = (-t.shape[-1]) % mult
+    return t if r == 0 else F.pad(t, (0, r))
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, residual, relu_in, relu_out):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        wk = w
+        if K % 4:  # K = 3 (relative coordinates): zero-pad the reduction dimension
+            x2, wk = _pad_cols(x2), _pad_cols(w)
+        wk = wk if wk.is_contiguous() else wk.contiguous()
+        res2 = None
+        if residual is not None:
+            res2 = residual.reshape(-1, w.shape[0])
+            res2 = res2 if res2.is_contiguous() else res2.contiguous()
+        y = _fwd(x2, wk, b, res2, None, None, relu_in, relu_out)
+        ctx.relu_in, ctx.relu_out = relu_in, relu_out
+        ctx.has_bias, ctx.has_res = b is not None, residual is not None
+        ctx.x_shape, ctx.k_orig = x.shape, K
+        ctx.save_for_backward(x2, wk, y if relu_out else None)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wk, y = ctx.saved_tensors
+        N = wk.shape[0]
+        dy2 = dy.reshape(-1, N)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            wt = wk.t().contiguous()                      # [K, N]: dX = dY' @ W  ==  dY' @ (W^T)^T
+            dyk, mk = dy2, y
+            if N % 4:                                      # N = 3 (fc_out): pad the reduction dimension
+                dyk, wt = _pad_cols(dy2), _pad_cols(wt)
+                mk = _pad_cols(y) if y is not None else None
+            dx = _fwd(dyk, wt, None, None, mk, x2 if ctx.relu_in else None, False, False)
+            dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _wgrad(dy2, x2, y, ctx.relu_in, ctx.has_bias)
+            if dw.shape[1] != ctx.k_orig:
+                dw = dw[:, :ctx.k_orig].contiguous()
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy2 if y is None else dy2 * (y > 0)
+            dres = dres.reshape(dy.shape)
+        return dx, dw, db, dres, None, None
+
+
+def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None):
+    if weight.dim() == 3:  # 1x1 Conv1d weight [out, in, 1]
+        weight = weight.squeeze(-1)
+    return _LinearFn.apply(x, weight, bias, residual, bool(relu_in), bool(relu_out))

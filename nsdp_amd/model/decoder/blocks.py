@@ -64,6 +64,6 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        h = ops.linear(torch.relu(x), self.fc_0, relu=True)
-        dx = ops.linear(h, self.fc_1)
-        return (x if self.shortcut is None else ops.linear(x, self.shortcut)) + dx
+        h = ops.linear(x, self.fc_0, relu_in=True, relu=True)             # relu(fc_0(relu(x)))
+        x_s = x if self.shortcut is None else ops.linear(x, self.shortcut)
+        return ops.linear(h, self.fc_1, residual=x_s)                     # x_s + fc_1(h), fused epilogue

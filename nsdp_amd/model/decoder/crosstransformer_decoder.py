@@ -26,6 +26,6 @@ class CrossTransformerDecoder(nn.Module):
         lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
         net = ops.linear(lat, self.init_enc)
         for i in range(self.n_blocks):
-            net = net + ops.linear(lat, self.fc_c[i])
+            net = ops.linear(lat, self.fc_c[i], residual=net)             # net + fc_c[i](lat)
             net = self.blocks[i](net)
-        return ops.linear(torch.relu(net), self.fc_out)
+        return ops.linear(net, self.fc_out, relu_in=True)                 # fc_out(relu(net))

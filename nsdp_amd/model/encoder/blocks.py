@@ -106,7 +106,8 @@ class TransformerSetAbstraction(nn.Module):
         k1 = ops.index_points(ops.linear(points, self.w_ks), idx)
         v1 = ops.index_points(ops.linear(points, self.w_vs), idx)
         res1, pos = ops.vector_attention(rel, q1, k1, v1, self.fc_delta1, self.fc_gamma1)
-        res1 = res1 + ops.linear(torch.relu(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1)), self.conv2)
+        res1 = ops.linear(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1), self.conv2, relu_in=True,
+                          residual=res1)
         res1 = ops.batch_norm(res1, self.bnorm0)
 
         q2 = ops.linear(res1, self.w_qs2)

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip_linear
 from .. import pointnet2_utils as pu
 
 
@@ -53,13 +54,10 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # dense layers
 # ---------------------------------------------------------------------------------------------
-def linear(x: torch.Tensor, lin, relu: bool = False) -> torch.Tensor:
-    """nn.Linear / 1x1 nn.Conv1d applied to channels-last rows."""
-    w = lin.weight
-    if w.dim() == 3:
-        w = w.squeeze(-1)
-    y = F.linear(x, w, lin.bias)
-    return F.relu(y) if relu else y
+def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None) -> torch.Tensor:
+    """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
+    relu?( relu_in?(x) @ W^T + b (+ residual) )."""
+    return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual)
 
 
 def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:

@@ -1,0 +1,71 @@
+"""fp32-MFMA dense layer kernels vs a plain PyTorch fp32 reference of the same op (forward + backward)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _ref(x, w, b, relu_in, relu_out, residual):
+    xi = F.relu(x) if relu_in else x
+    y = F.linear(xi.double(), w.double(), None if b is None else b.double())
+    if residual is not None:
+        y = y + residual.double()
+    return F.relu(y) if relu_out else y
+
+
+CASES = [  # (M, K, N, bias, relu_in, relu_out, residual)
+    (1, 4, 16, True, False, False, False),
+    (37, 120, 120, True, False, True, False),
+    (1000, 128, 256, False, False, False, False),
+    (513, 200, 200, True, False, True, False),
+    (777, 200, 128, True, False, False, True),
+    (300, 128, 128, True, True, True, False),
+    (300, 128, 3, True, True, False, False),
+    (2048, 3, 120, True, False, True, False),
+    (129, 256, 256, True, False, False, True),
+    (5000, 4, 120, True, False, False, False),
+    (64, 256, 200, False, False, False, False),
+    (4099, 120, 256, True, False, False, False),
+]
+
+
+@pytest.mark.parametrize("M,K,N,bias,relu_in,relu_out,res", CASES)
+def test_linear_forward_backward(M, K, N, bias, relu_in, relu_out, res):
+    from nsdp_amd.hip_linear import linear
+    g = torch.Generator(device="cpu").manual_seed(M * 131 + K * 7 + N)
+    x = torch.randn(M, K, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(DEV).requires_grad_(True) if bias else None
+    r = torch.randn(M, N, generator=g).to(DEV).requires_grad_(True) if res else None
+    y = linear(x, w, b, relu_in=relu_in, relu_out=relu_out, residual=r)
+    yr = _ref(x, w, b, relu_in, relu_out, r)
+    scale = float(yr.abs().max()) + 1e-6
+    assert float((y.double() - yr).abs().max()) <= 2e-6 * scale * max(1.0, K ** 0.5 / 4)
+    go = torch.randn(M, N, generator=g).to(DEV)
+    grads = torch.autograd.grad(y, [t for t in (x, w, b, r) if t is not None], go)
+    grads_ref = torch.autograd.grad(yr, [t for t in (x, w, b, r) if t is not None], go.double())
+    for a, e in zip(grads, grads_ref):
+        s = float(e.abs().max()) + 1e-6
+        assert float((a.double() - e.double()).abs().max()) <= 1e-5 * s, (a.shape, float((a.double() - e).abs().max()), s)
+
+
+def test_linear_3d_input_and_conv_weight():
+    from nsdp_amd.hip_linear import linear
+    x = torch.randn(3, 50, 120, device=DEV)
+    conv = torch.nn.Conv1d(120, 120, 1).to(DEV)
+    y = linear(x, conv.weight, conv.bias)
+    ref = conv(x.permute(0, 2, 1)).permute(0, 2, 1)
+    assert float((y - ref).abs().max()) < 1e-4
+
+
+def test_wgrad_is_deterministic():
+    from nsdp_amd.hip_linear import _wgrad
+    dy = torch.randn(100000, 128, device=DEV)
+    x = torch.randn(100000, 200, device=DEV)
+    a, da = _wgrad(dy, x, None, False, True)
+    b, db = _wgrad(dy, x, None, False, True)
+    assert torch.equal(a, b) and torch.equal(da, db)
+    ref = dy.double().t() @ x.double()
+    assert float((a.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

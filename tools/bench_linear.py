@@ -1,0 +1,21 @@
+import os, sys, torch, torch.nn.functional as F
+sys.path.insert(0, os.getcwd())
+from nsdp_amd.hip_linear import _fwd, _wgrad
+dev = torch.device('cuda:0')
+def timeit(fn, n=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for (M, K, N) in [(1835008, 200, 200), (1835008, 208, 208), (655360, 120, 120), (655360, 128, 128), (262144, 200, 128), (262144, 128, 128), (320000, 256, 256), (256000, 256, 256), (65536, 120, 120)]:
+    x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
+    dy = torch.randn(M, N, device=dev)
+    t1 = timeit(lambda: _fwd(x, w, b, None, None, None, False, True))
+    t2 = timeit(lambda: F.relu(F.linear(x, w, b)))
+    t3 = timeit(lambda: _wgrad(dy, x, None, False, True))
+    t4 = timeit(lambda: (dy.t() @ x, dy.sum(0)))
+    fl = 2.0 * M * N * K
+    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | hip wgrad {t3:.3f} ms {fl/t3/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
