@@ -32,6 +32,8 @@ extern "C" {
 int nsdp_abi_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *nsdp_last_error(void);
+/* Tuning/debug knob (not part of the reference contract): key 1 = wgrad software pipelining (-1/0/1). */
+void nsdp_debug_set(int key, int value);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int nsdp_device_count(void);
 

@@ -240,8 +240,12 @@ struct WgradParams {
   int want_db;
 };
 
-// kWgN = n-tiles per wave (the workgroup's 4 waves cover 4*kWgN n-tiles >= N/16), TK = k-tiles per wave.
-template <int kWgN, int TK>
+// kWgN = n-tiles per wave (the workgroup's 4 waves cover 4*kWgN n-tiles >= N/16), TK = k-tiles per wave
+// (grid.y covers K).  Rows are the MFMA reduction dimension: lane (li, g) feeds row 16*blk + 4g + s at
+// step s to both operands, so dY and X are read in their natural row-major layout (64-B segments).
+// Loads are unconditional from clamped indices and software-pipelined one 16-row block ahead (same
+// reasons as linear_nt_kernel); rows past the chunk end are zeroed by a select on the dY operand.
+template <int kWgN, int TK, bool PIPE>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -273,37 +277,86 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
     kcol[b] = c < K ? c : (K - 1);
   }
 
-  for (long long mb = m_begin; mb < m_end; mb += 16) {
-    float av[4][kWgN], bvv[4][TK];
+  struct Frag {
+    float a[4][kWgN];
+    float m[4][kWgN];
+    float b[4][TK];
+  };
+  const bool has_mask = p.mask != nullptr;
+  auto issue = [&](long long mb, Frag &f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const long long m = mb + 4 * g + s;
-      const bool mv = m < m_end;                 // rows past the chunk contribute zero (select, no branch)
-      const long long mc = mv ? m : (p.M - 1);   // ... but are still loaded from a valid address
+      long long m = mb + 4 * g + s;
+      m = m < p.M ? m : (p.M - 1);
 #pragma unroll
       for (int a = 0; a < kWgN; ++a) {
-        float v = p.dY[mc * N + ncol[a]];
-        if (p.mask) {
-          const float mk = p.mask[mc * N + ncol[a]];
-          v = mk > 0.f ? v : 0.f;
-        }
-        av[s][a] = mv ? v : 0.f;
+        f.a[s][a] = p.dY[m * N + ncol[a]];
+        if (has_mask) f.m[s][a] = p.mask[m * N + ncol[a]];
       }
 #pragma unroll
-      for (int b = 0; b < TK; ++b) {
-        const float xv_ = p.X[mc * K + kcol[b]];
-        bvv[s][b] = p.relu_x ? fmaxf(xv_, 0.f) : xv_;
+      for (int b = 0; b < TK; ++b) f.b[s][b] = p.X[m * K + kcol[b]];
+    }
+  };
+  auto fixup = [&](long long mb, Frag &f) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool mv = mb + 4 * g + s < m_end;
+#pragma unroll
+      for (int a = 0; a < kWgN; ++a) {
+        float v = f.a[s][a];
+        if (has_mask) v = f.m[s][a] > 0.f ? v : 0.f;
+        f.a[s][a] = mv ? v : 0.f;
+      }
+      if (p.relu_x) {
+#pragma unroll
+        for (int b = 0; b < TK; ++b) f.b[s][b] = fmaxf(f.b[s][b], 0.f);
       }
     }
+  };
+  auto mma = [&](const Frag &f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int a = 0; a < kWgN; ++a) {
-        dbsum[a] += av[s][a];
+        dbsum[a] += f.a[s][a];
 #pragma unroll
         for (int b = 0; b < TK; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][a], bvv[s][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[s][a], f.b[s][b], acc[a][b], 0, 0, 0);
       }
+    }
+  };
+
+  if (PIPE) {
+    Frag f0, f1;
+    issue(m_begin, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    long long mb = m_begin;
+    for (; mb + 32 <= m_end; mb += 32) {
+      fixup(mb, f0);
+      issue(mb + 16, f1);
+      mma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      fixup(mb + 16, f1);
+      issue(mb + 32, f0);  // may run past the chunk: clamped to a valid row, zeroed by fixup or unused
+      mma(f1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (mb < m_end) {  // one or two trailing 16-row blocks
+      fixup(mb, f0);
+      if (mb + 16 < m_end) issue(mb + 16, f1);
+      mma(f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (mb + 16 < m_end) {
+        fixup(mb + 16, f1);
+        mma(f1);
+      }
+    }
+  } else {  // register-lean form: two waves per SIMD hide the load latency instead
+    for (long long mb = m_begin; mb < m_end; mb += 16) {
+      Frag f;
+      issue(mb, f);
+      fixup(mb, f);
+      mma(f);
     }
   }
 
@@ -313,11 +366,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
 #pragma unroll
     for (int b = 0; b < TK; ++b) {
       const int kc = (ktile0 + b) * 16 + li;  // D col = lane & 15 -> k index
-      if (kc >= K) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = (wave * kWgN + a) * 16 + g * 4 + r;  // D row -> n index
-        if (n < N) out[static_cast<long long>(n) * K + kc] = acc[a][b][r];
+        if (n < N && kc < K) out[static_cast<long long>(n) * K + kc] = acc[a][b][r];
       }
     }
   }
@@ -331,6 +383,28 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
       if (g == 0 && n < N) out[static_cast<long long>(N) * K + n] = v;
     }
   }
+}
+
+int g_wgrad_pipe = 0;  // measured on MI355X: the register-lean form wins at every layer shape of the path
+                       // (52-65 vs 38-48 TF); 1 = software-pipelined form (nsdp_debug_set(1, v))
+
+template <int kWgN, int TK>
+void launch_wgrad(const WgradParams &p, unsigned chunks, int ktiles, hipStream_t st) {
+  const bool pipe = g_wgrad_pipe > 0;
+  const dim3 grid(chunks, (ktiles + TK - 1) / TK);
+  if (pipe) hipLaunchKernelGGL((linear_wgrad_kernel<kWgN, TK, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((linear_wgrad_kernel<kWgN, TK, false>), grid, dim3(256), 0, st, p);
+}
+
+template <int kWgN>
+void dispatch_wgrad_k(const WgradParams &p, unsigned chunks, int ktiles, hipStream_t st) {
+  // TK chosen so that ceil(ktiles / TK) * TK wastes the fewest tiles while kWgN * TK <= 32 accumulators
+  constexpr int kMaxTK = 32 / kWgN > 16 ? 16 : 32 / kWgN;
+  if (ktiles <= 1) return launch_wgrad<kWgN, 1>(p, chunks, ktiles, st);
+  if (ktiles <= 4) return launch_wgrad<kWgN, 4>(p, chunks, ktiles, st);
+  if (ktiles == 13 || ktiles == 7) return launch_wgrad<kWgN, 7>(p, chunks, ktiles, st);
+  if (ktiles <= 8 || kMaxTK == 8) return launch_wgrad<kWgN, 8>(p, chunks, ktiles, st);
+  return launch_wgrad<kWgN, 16>(p, chunks, ktiles, st);
 }
 
 __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long long stride,
@@ -350,6 +424,10 @@ __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long
 }  // namespace
 
 extern "C" {
+
+void nsdp_debug_set(int key, int value) {
+  if (key == 1) g_wgrad_pipe = value;
+}
 
 int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
                     const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
@@ -371,12 +449,45 @@ int nsdp_linear_f32(const float *X, const float *W, const float *bias, const flo
   return launch_nt<2, 16>(p, st);
 }
 
+}  // extern "C"
+
+namespace {
+// Row chunking of the weight-gradient reduction: one residency wave of workgroups (2 per CU with the
+// register-lean kernel = 512 slots) so that no tail wave runs at low occupancy, >= 128 rows per chunk.
+struct WgradPlan {
+  long long chunks, rows;
+  int grid_y;
+};
+WgradPlan plan_wgrad(long long M, int N, int K) {
+  const int ktiles = (K + 15) / 16;
+  const int wn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+  const int max_tk = 32 / wn > 16 ? 16 : 32 / wn;
+  int tk;
+  if (ktiles <= 1) tk = 1;
+  else if (ktiles <= 4) tk = 4;
+  else if (ktiles == 13 || ktiles == 7) tk = 7;
+  else if (ktiles <= 8 || max_tk == 8) tk = 8;
+  else tk = 16;
+  WgradPlan pl;
+  pl.grid_y = (ktiles + tk - 1) / tk;
+  long long max_chunks = 512 / pl.grid_y;
+  long long chunks = (M + 127) / 128;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  long long rows = (M + chunks - 1) / chunks;
+  rows = (rows + 15) / 16 * 16;
+  pl.rows = rows;
+  pl.chunks = (M + rows - 1) / rows;
+  return pl;
+}
+}  // namespace
+
+extern "C" {
+
 size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K) {
   if (M <= 0) return 0;
-  long long chunks = (M + 1023) / 1024;
-  if (chunks > 512) chunks = 512;
-  if (chunks < 1) chunks = 1;
-  return static_cast<size_t>(chunks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
+  const WgradPlan pl = plan_wgrad(M, N, K);
+  return static_cast<size_t>(pl.chunks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
 int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
@@ -396,26 +507,17 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
   NSDP_REQUIRE(dY && X && workspace, "linear_wgrad: null pointer");
   NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_workspace_bytes(M, N, K),
                "linear_wgrad: workspace too small");
-  long long chunks = (M + 1023) / 1024;
-  if (chunks > 512) chunks = 512;
-  long long rows = (M + chunks - 1) / chunks;
-  rows = (rows + 15) / 16 * 16;
-  chunks = (M + rows - 1) / rows;
+  const WgradPlan pl = plan_wgrad(M, N, K);
+  const long long chunks = pl.chunks, rows = pl.rows;
   WgradParams p{dY, X, mask, relu_x, workspace, M, N, K, rows, db != nullptr};
   const int ktiles = (K + 15) / 16;
   {
     nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K,
                             4.0 * (static_cast<double>(M) * (K + N)));
     const unsigned gx = static_cast<unsigned>(chunks);
-    if (N <= 64) {
-      hipLaunchKernelGGL((linear_wgrad_kernel<1, 16>), dim3(gx, (ktiles + 15) / 16), dim3(256), 0, st, p);
-    } else if (N <= 128) {
-      hipLaunchKernelGGL((linear_wgrad_kernel<2, 16>), dim3(gx, (ktiles + 15) / 16), dim3(256), 0, st, p);
-    } else if (ktiles <= 4) {
-      hipLaunchKernelGGL((linear_wgrad_kernel<4, 4>), dim3(gx, 1), dim3(256), 0, st, p);
-    } else {
-      hipLaunchKernelGGL((linear_wgrad_kernel<4, 8>), dim3(gx, (ktiles + 7) / 8), dim3(256), 0, st, p);
-    }
+    if (N <= 64) dispatch_wgrad_k<1>(p, gx, ktiles, st);
+    else if (N <= 128) dispatch_wgrad_k<2>(p, gx, ktiles, st);
+    else dispatch_wgrad_k<4>(p, gx, ktiles, st);
     int rc = nsdp::launch_status("linear_wgrad_kernel");
     if (rc) return rc;
   }

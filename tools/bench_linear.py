@@ -15,7 +15,10 @@ for (M, K, N) in [(1835008, 200, 200), (1835008, 208, 208), (655360, 120, 120), 
     dy = torch.randn(M, N, device=dev)
     t1 = timeit(lambda: _fwd(x, w, b, None, None, None, False, True))
     t2 = timeit(lambda: F.relu(F.linear(x, w, b)))
-    t3 = timeit(lambda: _wgrad(dy, x, None, False, True))
+    from nsdp_amd._lib import lib
+    lib().nsdp_debug_set(1, 0); t3 = timeit(lambda: _wgrad(dy, x, None, False, True))
+    lib().nsdp_debug_set(1, 1); t3b = timeit(lambda: _wgrad(dy, x, None, False, True))
+    lib().nsdp_debug_set(1, -1)
     t4 = timeit(lambda: (dy.t() @ x, dy.sum(0)))
     fl = 2.0 * M * N * K
-    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | hip wgrad {t3:.3f} ms {fl/t3/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
+    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | hip wgrad nopipe {t3:.3f} ms {fl/t3/1e9:.1f} TF pipe {t3b:.3f} ms {fl/t3b/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
