@@ -124,6 +124,34 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
                           size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Point-Transformer vector attention glue (everything between the dense layers of one block), replacing
+ * the materialised ATen gather / sub / add / softmax / einsum sequence of model/encoder/blocks.py:104-124,
+ * :290-308 and model/decoder/blocks.py:72-91.  Channels-last fp32, d <= 256:
+ *   q (B,n,d) per-centre queries;  kf, vf (B,N,d) projected source features;  idx (B,n,k) i32 neighbours
+ *   pos, u, a (B,n,k,d) per-(centre,neighbour) tensors;  a_g, v_g (B,d) optional global token (decoder).
+ * -------------------------------------------------------------------------------------------- */
+
+/* u = q[:, :, None] - kf[idx] + pos;  q_per_shape = 1: q is (B,1,d), one query vector per shape shared
+ * by all centres (decoder: q = w_qs(z), model/decoder/blocks.py:63-66) */
+int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
+                      int N, int k, int d, int q_per_shape, float *u, void *stream);
+/* dq = sum_j du (summed over the centres too when q_per_shape);  dkf (zero-filled here) -= scatter(du) */
+int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
+                      int q_per_shape, float *dq, float *dkf, void *stream);
+/* y = sum_j softmax_j(a) * (vf[idx] + pos) [+ softmax weight of a_g * v_g] [+ residual];
+ * lse (B,n,d) = log-sum-exp of the logits (kept for the backward pass).
+ * vf == NULL: values are `pos` alone (pos_only block); a_g/v_g, residual may be NULL. */
+int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const int32_t *idx,
+                       const float *a_g, const float *v_g, const float *residual, int B, int n, int N,
+                       int k, int d, float *y, float *lse, void *stream);
+/* da = w dy (s - y_att), dpos = w dy, dvf (zero-filled here) += scatter(dpos), da_g/dv_g (zero-filled
+ * here) = global-token gradients; y/residual/lse as produced by / passed to nsdp_attn_post_fwd. */
+int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const float *pos,
+                       const int32_t *idx, const float *a_g, const float *v_g, const float *y,
+                       const float *residual, const float *lse, int B, int n, int N, int k, int d,
+                       float *da, float *dpos, float *dvf, float *da_g, float *dv_g, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Kernel timing with HIP events on the launch stream (used by bench.py for the roofline object)
  * -------------------------------------------------------------------------------------------- */
 void nsdp_prof_enable(int on);            /* on=1 clears previous records and starts recording */

@@ -18,7 +18,10 @@ SO = os.path.join(LIBDIR, "libnsdp_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nsdp_hip.h")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -munsafe-fp-atomics: fp32 atomicAdd lowers to the hardware global_atomic_add_f32 instead of a CAS loop
+# (all buffers are ordinary coarse-grained device allocations)
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-munsafe-fp-atomics"]
 # geometry kernels must keep one rounding per fp32 op (bit-exact distances): contraction off
 EXACT = ["-ffp-contract=off"]
 FAST = ["-ffp-contract=fast"]

@@ -1,0 +1,94 @@
+"""Autograd wrappers of the fused vector-attention glue kernels (csrc/attention.hip)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import check, fptr, iptr, lib, on_device, optptr, stream_ptr
+
+_ci = ctypes.c_int
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _AttnPre(torch.autograd.Function):
+    """u = q[:, :, None] - kf[idx] + pos."""
+
+    @staticmethod
+    def forward(ctx, q, kf, pos, idx):
+        q, kf, pos = _c(q), _c(kf), _c(pos)
+        B, n, k, d = pos.shape
+        N = kf.shape[1]
+        qb = int(q.shape[1] == 1 and n != 1)  # (B,1,d): one query vector per shape
+        u = torch.empty_like(pos)
+        with on_device(pos):
+            check(lib().nsdp_attn_pre_fwd(fptr(q, "q"), fptr(kf, "kf"), fptr(pos, "pos"), iptr(idx, "idx"), _ci(B),
+                                          _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb), fptr(u), stream_ptr()),
+                  "nsdp_attn_pre_fwd")
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, n, N, k, d, qb)
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        (idx,) = ctx.saved_tensors
+        B, n, N, k, d, qb = ctx.dims
+        du = _c(du)
+        dq = torch.empty((B, 1 if qb else n, d), dtype=torch.float32, device=du.device)
+        dkf = torch.empty((B, N, d), dtype=torch.float32, device=du.device)
+        with on_device(du):
+            check(lib().nsdp_attn_pre_bwd(fptr(du, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
+                                          fptr(dq), fptr(dkf), stream_ptr()), "nsdp_attn_pre_bwd")
+        return dq, dkf, du, None
+
+
+class _AttnPost(torch.autograd.Function):
+    """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
+
+    @staticmethod
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual):
+        a, pos = _c(a), _c(pos)
+        vf = None if vf is None else _c(vf)
+        a_g = None if a_g is None else _c(a_g)
+        v_g = None if v_g is None else _c(v_g)
+        residual = None if residual is None else _c(residual)
+        B, n, k, d = a.shape
+        N = vf.shape[1] if vf is not None else 1
+        y = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
+        lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
+        with on_device(a):
+            check(lib().nsdp_attn_post_fwd(fptr(a, "a"), optptr(vf), fptr(pos, "pos"), iptr(idx, "idx"), optptr(a_g),
+                                           optptr(v_g), optptr(residual), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
+                                           fptr(y), fptr(lse), stream_ptr()), "nsdp_attn_post_fwd")
+        ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse)
+        ctx.dims = (B, n, N, k, d)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, vf, pos, idx, a_g, v_g, y, residual, lse = ctx.saved_tensors
+        B, n, N, k, d = ctx.dims
+        dy = _c(dy)
+        dev = dy.device
+        da = torch.empty_like(a)
+        dpos = torch.empty_like(a)
+        dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if vf is not None else None
+        da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
+        dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
+        with on_device(dy):
+            check(lib().nsdp_attn_post_bwd(fptr(dy, "dy"), fptr(a), optptr(vf), fptr(pos), iptr(idx), optptr(a_g),
+                                           optptr(v_g), fptr(y), optptr(residual), fptr(lse), _ci(B), _ci(n), _ci(N),
+                                           _ci(k), _ci(d), fptr(da), fptr(dpos), optptr(dvf), optptr(da_g),
+                                           optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None)
+
+
+def attn_pre(q, kf, pos, idx):
+    return _AttnPre.apply(q, kf, pos, idx)
+
+
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None):
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual)

@@ -35,16 +35,12 @@ class CrossTransformerBlock(nn.Module):
         q = ops.linear(lat_rep, self.w_qs)                                   # [B,D]  (shared by all queries)
         k_g = ops.linear(lat_rep, self.w_k_global)
         v_g = ops.linear(lat_rep, self.w_v_global)
-        k_nb = ops.index_points(ops.linear(points, self.w_ks), idx)          # [B,NQ,k,D]
-        v_nb = ops.index_points(ops.linear(points, self.w_vs), idx)
+        kf = ops.linear(points, self.w_ks)                                   # [B,A,D] anchor tables
+        vf = ops.linear(points, self.w_vs)
         rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)                # xyz_q - a_j
-        pos = ops.mlp2(rel, self.fc_delta)                                   # [B,NQ,k,D]
-        logit_nb = ops.mlp2(q[:, None, None, :] - k_nb + pos, self.fc_gamma)
         logit_g = ops.mlp2(q - k_g, self.fc_gamma)                           # [B,D]: identical for all queries
-        NQ = xyz_q.shape[1]
-        logits = torch.cat([logit_nb, logit_g[:, None, None, :].expand(-1, NQ, 1, -1)], dim=2)
-        w = F.softmax(logits, dim=-2)
-        res = (w[:, :, :-1] * (v_nb + pos)).sum(dim=2) + w[:, :, -1] * v_g[:, None, :]
+        res, _ = ops.vector_attention(rel, q.unsqueeze(1), kf, vf, idx, self.fc_delta,
+                                      self.fc_gamma, a_g=logit_g, v_g=v_g)
         if not self.reduce_dim:
             res = ops.linear(res, self.fc)
         return res

@@ -43,13 +43,12 @@ class TransformerBlock(nn.Module):
             idx = ops.knn_indices(xyz, xyz, self.k)
         rel = xyz.unsqueeze(2) - ops.index_points(xyz, idx)          # xyz_i - xyz_j
         if self.pos_only:
-            res, _ = ops.vector_attention(rel, None, None, None, self.fc_delta, self.fc_gamma)
+            res, _ = ops.vector_attention(rel, None, None, None, idx, self.fc_delta, self.fc_gamma)
         else:
             q = ops.linear(feats, self.w_qs)
-            k_nb = ops.index_points(ops.linear(feats, self.w_ks), idx)
-            v_nb = ops.index_points(ops.linear(feats, self.w_vs), idx)
-            res, _ = ops.vector_attention(rel, q, k_nb, v_nb, self.fc_delta, self.fc_gamma)
-            res = res + feats
+            kf = ops.linear(feats, self.w_ks)
+            vf = ops.linear(feats, self.w_vs)
+            res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats)
         return ops.batch_norm(res, self.bn)
 
 
@@ -103,19 +102,18 @@ class TransformerSetAbstraction(nn.Module):
         # the reference projects all N points with w_qs and then gathers the centres; gathering first
         # is the same values with N/npoint fewer rows through the GEMM
         q1 = ops.linear(ops.index_points(points, fps_idx), self.w_qs)
-        k1 = ops.index_points(ops.linear(points, self.w_ks), idx)
-        v1 = ops.index_points(ops.linear(points, self.w_vs), idx)
-        res1, pos = ops.vector_attention(rel, q1, k1, v1, self.fc_delta1, self.fc_gamma1)
+        res1, pos = ops.vector_attention(rel, q1, ops.linear(points, self.w_ks), ops.linear(points, self.w_vs), idx,
+                                         self.fc_delta1, self.fc_gamma1)
         res1 = ops.linear(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1), self.conv2, relu_in=True,
                           residual=res1)
         res1 = ops.batch_norm(res1, self.bnorm0)
 
         q2 = ops.linear(res1, self.w_qs2)
-        k2 = ops.index_points(ops.linear(points, self.w_ks2), idx)
-        v2 = ops.index_points(ops.linear(points, self.w_vs2), idx)
-        res2 = ops.attention_with_pos(pos, q2, k2, v2, self.fc_gamma2)
+        # second attention re-uses pos; "res1 + res2" is fused as the kernel's residual add
+        res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2), ops.linear(points, self.w_vs2), idx,
+                                        None, self.fc_gamma2, residual=res1, pos=pos)
 
-        new_points = ops.batch_norm(res1 + res2, self.bnorm1) + ops.index_points(points, fps_idx)
+        new_points = ops.batch_norm(res12, self.bnorm1) + ops.index_points(points, fps_idx)
         return new_xyz, ops.batch_norm(new_points, self.bnorm2)
 
 

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip_linear
+from .. import hip_attention, hip_linear
 from .. import pointnet2_utils as pu
 
 
@@ -78,22 +78,22 @@ def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # point-transformer vector attention
 # ---------------------------------------------------------------------------------------------
-def vector_attention(rel: torch.Tensor, q, k_nb, v_nb, fc_delta, fc_gamma):
-    """softmax over the neighbour axis, independently per channel, of gamma(q - k + delta(rel)),
-    applied to (v + delta(rel)).  rel [B,n,k,3]; q [B,n,d] or None (pos_only); k_nb, v_nb [B,n,k,d].
-    Returns (aggregate [B,n,d], pos_encode [B,n,k,d])."""
-    pos = mlp2(rel, fc_delta)
+def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None):
+    """sum_j softmax_j[gamma(q_i - kf[idx_ij] + delta(rel_ij))] * (vf[idx_ij] + delta(rel_ij)) (+ residual),
+    softmax over the neighbour axis independently per channel (vector attention).
+
+    rel [B,n,k,3] relative coordinates; q [B,n,d] (None: pos_only block -- logits = gamma(delta), values =
+    delta); kf, vf [B,N,d] projected source features (gathered inside the fused kernels, never materialised
+    as [B,n,k,d]); idx [B,n,k] int32; ``pos`` re-uses an already computed delta(rel) (second attention of the
+    set abstraction); a_g / v_g [B,d]: logits / values of a per-shape global token (decoder).
+    Returns (aggregate [B,n,d], pos [B,n,k,d])."""
+    if pos is None:
+        pos = mlp2(rel, fc_delta)                              # 2 dense layers on [B*n*k] rows
     if q is None:
         logits = mlp2(pos, fc_gamma)
-        val = pos
+        out = hip_attention.attn_post(logits, None, pos, idx, residual=residual)
     else:
-        logits = mlp2(q.unsqueeze(2) - k_nb + pos, fc_gamma)
-        val = v_nb + pos
-    w = F.softmax(logits, dim=-2)
-    return (w * val).sum(dim=2), pos
-
-
-def attention_with_pos(pos, q, k_nb, v_nb, fc_gamma):
-    """Second attention of TransformerSetAbstraction: re-uses an already computed pos_encode."""
-    w = F.softmax(mlp2(q.unsqueeze(2) - k_nb + pos, fc_gamma), dim=-2)
-    return (w * (v_nb + pos)).sum(dim=2)
+        u = hip_attention.attn_pre(q, kf, pos, idx)            # q_i - kf[idx] + pos, gather fused
+        logits = mlp2(u, fc_gamma)
+        out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual)
+    return out, pos

@@ -1,0 +1,94 @@
+"""Fused vector-attention glue kernels vs a plain PyTorch composition of the same ops (fwd + bwd)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _gather(x, idx):  # x [B,N,d], idx [B,n,k] -> [B,n,k,d]
+    B, n, k = idx.shape
+    return torch.gather(x, 1, idx.reshape(B, n * k, 1).expand(-1, -1, x.shape[-1]).long()).reshape(B, n, k, -1)
+
+
+def _ref_pre(q, kf, pos, idx):
+    return q.unsqueeze(2) - _gather(kf, idx) + pos
+
+
+def _ref_post(a, vf, pos, idx, a_g, v_g, residual):
+    val = pos if vf is None else _gather(vf, idx) + pos
+    if a_g is not None:
+        B, n, k, d = a.shape
+        a = torch.cat([a, a_g[:, None, None, :].expand(B, n, 1, d)], dim=2)
+        val = torch.cat([val, v_g[:, None, None, :].expand(B, n, 1, d)], dim=2)
+    y = (F.softmax(a, dim=2) * val).sum(dim=2)
+    return y if residual is None else y + residual
+
+
+@pytest.mark.parametrize("B,n,N,k,d", [(2, 37, 50, 10, 120), (3, 16, 16, 16, 256), (1, 100, 100, 100, 256),
+                                       (2, 130, 20, 7, 200), (1, 5, 9, 3, 8)])
+def test_attn_pre(B, n, N, k, d):
+    from nsdp_amd.hip_attention import attn_pre
+    g = torch.Generator().manual_seed(B * 1000 + n + d)
+    q = torch.randn(B, n, d, generator=g).to(DEV).double().requires_grad_(True)
+    kf = torch.randn(B, N, d, generator=g).to(DEV).double().requires_grad_(True)
+    pos = torch.randn(B, n, k, d, generator=g).to(DEV).double().requires_grad_(True)
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    ref = _ref_pre(q, kf, pos, idx)
+    qf, kff, posf = (t.detach().float().requires_grad_(True) for t in (q, kf, pos))
+    out = attn_pre(qf, kff, posf, idx)
+    assert float((out.double() - ref).abs().max()) < 1e-5
+    go = torch.randn(B, n, k, d, generator=g).to(DEV)
+    gr = torch.autograd.grad(ref, [q, kf, pos], go.double())
+    gm = torch.autograd.grad(out, [qf, kff, posf], go)
+    for a_, e_ in zip(gm, gr):
+        assert float((a_.double() - e_).abs().max()) <= 1e-5 * (float(e_.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("B,n,N,k,d,has_v,has_g,has_res", [
+    (2, 37, 50, 10, 120, True, False, True), (2, 33, 40, 10, 120, False, False, False),
+    (3, 16, 16, 16, 256, True, False, True), (1, 100, 100, 100, 256, True, False, True),
+    (2, 130, 20, 7, 200, True, True, False), (1, 5, 9, 3, 8, True, True, True)])
+def test_attn_post(B, n, N, k, d, has_v, has_g, has_res):
+    from nsdp_amd.hip_attention import attn_post
+    g = torch.Generator().manual_seed(B * 77 + n + d + k)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV).double().requires_grad_(True)
+    a, pos = mk(B, n, k, d), mk(B, n, k, d)
+    vf = mk(B, N, d) if has_v else None
+    a_g, v_g = (mk(B, d), mk(B, d)) if has_g else (None, None)
+    res = mk(B, n, d) if has_res else None
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    ref = _ref_post(a, vf, pos, idx, a_g, v_g, res)
+    f32 = lambda t: None if t is None else t.detach().float().requires_grad_(True)
+    af, vff, posf, agf, vgf, resf = map(f32, (a, vf, pos, a_g, v_g, res))
+    out = attn_post(af, vff, posf, idx, agf, vgf, resf)
+    assert float((out.double() - ref).abs().max()) < 2e-5
+    go = torch.randn(B, n, d, generator=g).to(DEV)
+    ins64 = [t for t in (a, vf, pos, a_g, v_g, res) if t is not None]
+    ins32 = [t for t in (af, vff, posf, agf, vgf, resf) if t is not None]
+    gr = torch.autograd.grad(ref, ins64, go.double())
+    gm = torch.autograd.grad(out, ins32, go)
+    for a_, e_ in zip(gm, gr):
+        assert float((a_.double() - e_).abs().max()) <= 2e-5 * (float(e_.abs().max()) + 1.0), a_.shape
+
+
+def test_attn_pre_query_per_shape():
+    """Decoder form: one query vector per shape, (B,1,d), shared by all centres."""
+    from nsdp_amd.hip_attention import attn_pre
+    g = torch.Generator().manual_seed(5)
+    B, n, N, k, d = 3, 300, 100, 7, 200
+    q = torch.randn(B, 1, d, generator=g).to(DEV).requires_grad_(True)
+    kf = torch.randn(B, N, d, generator=g).to(DEV).requires_grad_(True)
+    pos = torch.randn(B, n, k, d, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    out = attn_pre(q, kf, pos, idx)
+    q64, kf64, pos64 = (t.detach().double().requires_grad_(True) for t in (q, kf, pos))
+    ref = _ref_pre(q64.expand(B, n, d), kf64, pos64, idx)
+    assert float((out.double() - ref).abs().max()) < 1e-5
+    go = torch.randn(B, n, k, d, generator=g).to(DEV)
+    gm = torch.autograd.grad(out, [q, kf, pos], go)
+    gr = torch.autograd.grad(ref, [q64, kf64, pos64], go.double())
+    for a_, e_ in zip(gm, gr):
+        assert a_.shape == e_.shape
+        assert float((a_.double() - e_).abs().max()) <= 2e-5 * (float(e_.abs().max()) + 1.0)
