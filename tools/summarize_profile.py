@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Condenses rocprofv3 CSV output (gpurun_out/) into the small tracked summaries under profiles/.
+
+    python tools/summarize_profile.py <round-tag>   # e.g. r1
+"""
+import csv
+import collections
+import json
+import os
+import re
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_dir = os.path.join(root, "profiles")
+os.makedirs(out_dir, exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(<[^>]*>)?)", name)
+    return (m.group(1) if m else name)[:90]
+
+
+stats = os.path.join(root, "gpurun_out", f"prof_{tag}", f"{tag}_kernel_stats.csv")
+if os.path.exists(stats):
+    rows = list(csv.DictReader(open(stats)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.md"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats ({tag}): python bench.py --steps 5 --warmup 2 --no-cpu-baseline\n\n")
+        f.write(f"total kernel time {total/1e6:.1f} ms over 7 steps (2 warm-up + 5 timed), B=32 shapes\n\n")
+        f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
+        for r in rows[:45]:
+            f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
+                    f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    # keep the raw stats CSV too (small)
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+        f.write(open(stats).read())
+
+pmc = {}
+for key, sub, pre in (("FETCH_SIZE", "pmc_fetch", "f"), ("WRITE_SIZE", "pmc_write", "w")):
+    path = os.path.join(root, "gpurun_out", sub, f"{pre}_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != key:
+            continue
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] = max(a[2], float(r["Counter_Value"]))
+    pmc[key] = agg
+if pmc:
+    names = sorted(set().union(*[set(v) for v in pmc.values()]),
+                   key=lambda n: -sum(pmc[k][n][1] for k in pmc if n in pmc[k]))
+    with open(os.path.join(out_dir, f"{tag}_pmc_hbm.md"), "w") as f:
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 --batch 8\n\n")
+        f.write("Counter unit = KiB as reported.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
+                "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n")
+        f.write("| kernel | launches | FETCH_SIZE sum KiB | fetch x2 MiB | WRITE_SIZE sum KiB | max launch fetch KiB | max launch write KiB |\n|---|---:|---:|---:|---:|---:|---:|\n")
+        for n in names[:40]:
+            fe = pmc.get("FETCH_SIZE", {}).get(n, [0, 0, 0])
+            wr = pmc.get("WRITE_SIZE", {}).get(n, [0, 0, 0])
+            f.write(f"| `{n}` | {fe[0] or wr[0]} | {fe[1]:.0f} | {2*fe[1]/1024:.1f} | {wr[1]:.0f} | {fe[2]:.0f} | {wr[2]:.0f} |\n")
+    json.dump({k: {n: v for n, v in agg.items()} for k, agg in pmc.items()},
+              open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=0)
+for name in ("bench_default.json", f"prof_{tag}_bench.json"):
+    src = os.path.join(root, "gpurun_out", name)
+    if os.path.exists(src):
+        open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
+print("wrote", sorted(os.listdir(out_dir)))
