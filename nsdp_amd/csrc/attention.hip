@@ -12,9 +12,9 @@
 //     attn_post_fwd:  y_i = sum_j softmax_j(a)_j * (vf[idx] + pos) (+ global token) (+ residual), lse_i
 //     attn_post_bwd:  da_j = w_j dy (s_j - y);  ds_j = w_j dy;  dvf[idx] += ds_j   (w recomputed from lse)
 //     attn_pre_bwd :  dq_i = sum_j du_j;  dkf[idx] -= du_j
-// Layout: channels-last; a workgroup walks a chunk of points with one lane per channel, so every global
-// access is a contiguous d*4-byte row (fully coalesced) and the softmax over the k neighbours is a
-// per-lane online reduction (no cross-lane traffic at all).  All of it is HBM-bound byte movement:
+// Layout: channels-last; a lane owns 4 consecutive channels of one point (float4 accesses, whole rows
+// coalesced) and walks the k neighbours, so the softmax over the neighbours is a per-lane online
+// reduction (no cross-lane traffic at all).  All of it is HBM-bound byte movement:
 // algorithmic bytes are 2-3 [R,d] tensors per kernel instead of the reference's ~10.
 #include "common.h"
 #include "prof.h"
@@ -26,104 +26,180 @@ struct AttnShape {
   int qb;             // 1: q is one vector per shape, (B,1,d), shared by all centres (decoder)
 };
 
-constexpr int kPointsPerBlock = 16;
+// Work decomposition shared by the four kernels: a lane owns 4 consecutive channels (one float4, so a
+// wave-level access is up to 1 KiB -- 4x the bytes in flight of a dword-per-lane mapping), d/4 lanes form a
+// point, floor(64 / (d/4)) points share a wave, and every wave walks kIters such point groups.
+constexpr int kIters = 8;
+
+struct Lane {
+  bool active;
+  int cq;        // channel quad: channels 4*cq .. 4*cq+3
+  int sub;       // which of the wave's concurrent points
+  int ppw;       // points per wave per iteration
+  long long p0;  // first flattened point (b*n + i) of this wave
+};
+
+__device__ __forceinline__ Lane lane_setup(const AttnShape &s) {
+  Lane L;
+  const int lane = threadIdx.x & 63;
+  const int lpp = s.d >> 2;
+  L.ppw = 64 / lpp;
+  L.sub = lane / lpp;
+  L.cq = lane - L.sub * lpp;
+  L.active = L.sub < L.ppw;
+  const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  L.p0 = wave * (static_cast<long long>(L.ppw) * kIters);
+  return L;
+}
+
+// The two backward kernels scatter with fp32 atomics.  With the float4 mapping one atomic instruction
+// would touch 64 words spread over 1 KiB (7-8 cache lines, 16 B stride); there a lane instead owns the 4
+// channels {cq, cq+lpp, cq+2lpp, cq+3lpp} ("strided quad"): every load/store/atomic instruction then
+// covers one contiguous lpp*4-byte run (2 lines), with the same number of bytes in flight per lane.
+struct Quad {
+  float x, y, z, w;
+};
+__device__ __forceinline__ Quad ldq(const float *row, int cq, int lpp) {
+  return Quad{row[cq], row[cq + lpp], row[cq + 2 * lpp], row[cq + 3 * lpp]};
+}
+__device__ __forceinline__ void stq(float *row, int cq, int lpp, Quad v) {
+  row[cq] = v.x; row[cq + lpp] = v.y; row[cq + 2 * lpp] = v.z; row[cq + 3 * lpp] = v.w;
+}
+__device__ __forceinline__ void atomic_addq(float *row, int cq, int lpp, Quad v) {
+  atomicAdd(row + cq, v.x); atomicAdd(row + cq + lpp, v.y);
+  atomicAdd(row + cq + 2 * lpp, v.z); atomicAdd(row + cq + 3 * lpp, v.w);
+}
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void atomic_add4(float *p, float4 v) {
+  atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
 
 // u[b,i,j,c] = q[b,i,c] - kf[b,idx[b,i,j],c] + pos[b,i,j,c]
-template <int T>
-__global__ __launch_bounds__(T) void attn_pre_fwd_kernel(AttnShape s, const float *__restrict__ q,
-                                                         const float *__restrict__ kf,
-                                                         const float *__restrict__ pos,
-                                                         const int32_t *__restrict__ idx,
-                                                         float *__restrict__ u) {
-  const int c = threadIdx.x;
-  if (c >= s.d) return;
-  const int b = blockIdx.y;
-  const int i0 = blockIdx.x * kPointsPerBlock;
-  const int i1 = min(s.n, i0 + kPointsPerBlock);
-  const float *kfb = kf + static_cast<size_t>(b) * s.N * s.d;
-  for (int i = i0; i < i1; ++i) {
-    const size_t pt = static_cast<size_t>(b) * s.n + i;
-    const float qv = s.qb ? q[static_cast<size_t>(b) * s.d + c] : q[pt * s.d + c];
+__global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const float *__restrict__ q,
+                                                           const float *__restrict__ kf,
+                                                           const float *__restrict__ pos,
+                                                           const int32_t *__restrict__ idx,
+                                                           float *__restrict__ u) {
+  const Lane L = lane_setup(s);
+  if (!L.active) return;
+  const long long total = static_cast<long long>(s.B) * s.n;
+  for (int it = 0; it < kIters; ++it) {
+    const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+    if (pt >= total) return;
+    const int b = static_cast<int>(pt / s.n);
+    const float4 qv = ld4(q + (s.qb ? static_cast<long long>(b) : pt) * s.d + 4 * L.cq);
+    const float *kfb = kf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq;
     const int32_t *ip = idx + pt * s.k;
-    const size_t row0 = pt * s.k;
+    const long long e0 = pt * s.k * s.d + 4 * L.cq;
+#pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
-      const size_t e = (row0 + j) * s.d + c;
-      u[e] = qv - kfb[static_cast<size_t>(ip[j]) * s.d + c] + pos[e];
+      const float4 kv = ld4(kfb + static_cast<long long>(ip[j]) * s.d);
+      const float4 pv = ld4(pos + e0 + static_cast<long long>(j) * s.d);
+      st4(u + e0 + static_cast<long long>(j) * s.d,
+          make_float4(qv.x - kv.x + pv.x, qv.y - kv.y + pv.y, qv.z - kv.z + pv.z, qv.w - kv.w + pv.w));
     }
   }
 }
 
-// dq[b,i,c] = sum_j du[b,i,j,c];  dkf[b,idx,c] -= du   (dkf zero-filled by the host wrapper)
-template <int T>
-__global__ __launch_bounds__(T) void attn_pre_bwd_kernel(AttnShape s, const float *__restrict__ du,
-                                                         const int32_t *__restrict__ idx,
-                                                         float *__restrict__ dq, float *__restrict__ dkf) {
-  const int c = threadIdx.x;
-  if (c >= s.d) return;
-  const int b = blockIdx.y;
-  const int i0 = blockIdx.x * kPointsPerBlock;
-  const int i1 = min(s.n, i0 + kPointsPerBlock);
-  float *dkfb = dkf + static_cast<size_t>(b) * s.N * s.d;
-  float qb_acc = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const size_t pt = static_cast<size_t>(b) * s.n + i;
+// dq[b,i,c] = sum_j du[b,i,j,c];  dkf[b,idx,c] -= du   (dkf / per-shape dq zero-filled by the host wrapper)
+__global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const float *__restrict__ du,
+                                                           const int32_t *__restrict__ idx,
+                                                           float *__restrict__ dq, float *__restrict__ dkf) {
+  const Lane L = lane_setup(s);
+  if (!L.active) return;
+  const int lpp = s.d >> 2, cq = L.cq;
+  const long long total = static_cast<long long>(s.B) * s.n;
+  Quad qb_acc{0.f, 0.f, 0.f, 0.f};
+  int qb_b = -1;
+  for (int it = 0; it < kIters; ++it) {
+    const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+    if (pt >= total) break;
+    const int b = static_cast<int>(pt / s.n);
+    float *dkfb = dkf + static_cast<long long>(b) * s.N * s.d;
     const int32_t *ip = idx + pt * s.k;
-    const size_t row0 = pt * s.k;
-    float acc = 0.f;
+    const float *dur = du + pt * s.k * s.d;
+    Quad acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
-      const float g = du[(row0 + j) * s.d + c];
-      acc += g;
-      atomicAdd(dkfb + static_cast<size_t>(ip[j]) * s.d + c, -g);
+      const Quad g = ldq(dur + static_cast<long long>(j) * s.d, cq, lpp);
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      atomic_addq(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
     }
-    if (s.qb) qb_acc += acc;
-    else dq[pt * s.d + c] = acc;
+    if (s.qb) {
+      if (b != qb_b) {
+        if (qb_b >= 0) atomic_addq(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
+        qb_acc = Quad{0.f, 0.f, 0.f, 0.f};
+        qb_b = b;
+      }
+      qb_acc.x += acc.x; qb_acc.y += acc.y; qb_acc.z += acc.z; qb_acc.w += acc.w;
+    } else {
+      stq(dq + pt * s.d, cq, lpp, acc);
+    }
   }
-  if (s.qb) atomicAdd(dq + static_cast<size_t>(b) * s.d + c, qb_acc);  // dq (B,1,d) zero-filled by the host
+  if (s.qb && qb_b >= 0) atomic_addq(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
 }
+
+#define NSDP_ONLINE_STEP(C)                      \
+  {                                              \
+    const float mn = fmaxf(m.C, av.C);           \
+    const float sc = __expf(m.C - mn);           \
+    const float w = __expf(av.C - mn);           \
+    l.C = l.C * sc + w;                          \
+    acc.C = acc.C * sc + w * sv.C;               \
+    m.C = mn;                                    \
+  }
 
 // y = sum_j softmax_j(a) (vf[idx] + pos) [+ w_g v_g] [+ residual];  lse = log-sum-exp of the logits.
 // HAS_V = false: pos_only block (values = pos).  a_g / v_g: per-shape global token (decoder) or NULL.
-template <int T, bool HAS_V>
-__global__ __launch_bounds__(T) void attn_post_fwd_kernel(AttnShape s, const float *__restrict__ a,
-                                                          const float *__restrict__ vf,
-                                                          const float *__restrict__ pos,
-                                                          const int32_t *__restrict__ idx,
-                                                          const float *__restrict__ a_g,
-                                                          const float *__restrict__ v_g,
-                                                          const float *__restrict__ residual,
-                                                          float *__restrict__ y, float *__restrict__ lse) {
-  const int c = threadIdx.x;
-  if (c >= s.d) return;
-  const int b = blockIdx.y;
-  const int i0 = blockIdx.x * kPointsPerBlock;
-  const int i1 = min(s.n, i0 + kPointsPerBlock);
-  const float *vfb = HAS_V ? vf + static_cast<size_t>(b) * s.N * s.d : nullptr;
+template <bool HAS_V>
+__global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const float *__restrict__ a,
+                                                            const float *__restrict__ vf,
+                                                            const float *__restrict__ pos,
+                                                            const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ a_g,
+                                                            const float *__restrict__ v_g,
+                                                            const float *__restrict__ residual,
+                                                            float *__restrict__ y, float *__restrict__ lse) {
+  const Lane L = lane_setup(s);
+  if (!L.active) return;
+  const long long total = static_cast<long long>(s.B) * s.n;
   const bool has_g = a_g != nullptr;
-  const float ag = has_g ? a_g[static_cast<size_t>(b) * s.d + c] : 0.f;
-  const float vg = has_g ? v_g[static_cast<size_t>(b) * s.d + c] : 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const size_t pt = static_cast<size_t>(b) * s.n + i;
+  for (int it = 0; it < kIters; ++it) {
+    const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+    if (pt >= total) return;
+    const int b = static_cast<int>(pt / s.n);
+    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq : nullptr;
     const int32_t *ip = idx + pt * s.k;
-    const size_t row0 = pt * s.k;
-    float m = has_g ? ag : -INFINITY;
-    float l = has_g ? 1.f : 0.f;
-    float acc = has_g ? vg : 0.f;
-    for (int j = 0; j < s.k; ++j) {
-      const size_t e = (row0 + j) * s.d + c;
-      const float av = a[e];
-      float sv = pos[e];
-      if (HAS_V) sv += vfb[static_cast<size_t>(ip[j]) * s.d + c];
-      const float mn = fmaxf(m, av);
-      const float sc = __expf(m - mn);   // exp(-inf) = 0 on the first neighbour
-      const float w = __expf(av - mn);
-      l = l * sc + w;
-      acc = acc * sc + w * sv;
-      m = mn;
+    const long long e0 = pt * s.k * s.d + 4 * L.cq;
+    float4 m, l, acc;
+    if (has_g) {
+      m = ld4(a_g + static_cast<long long>(b) * s.d + 4 * L.cq);
+      acc = ld4(v_g + static_cast<long long>(b) * s.d + 4 * L.cq);
+      l = make_float4(1.f, 1.f, 1.f, 1.f);
+    } else {
+      m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      l = make_float4(0.f, 0.f, 0.f, 0.f);
+      acc = l;
     }
-    float out = acc / l;
-    lse[pt * s.d + c] = m + __logf(l);
-    if (residual) out += residual[pt * s.d + c];
-    y[pt * s.d + c] = out;
+#pragma unroll 4
+    for (int j = 0; j < s.k; ++j) {
+      const float4 av = ld4(a + e0 + static_cast<long long>(j) * s.d);
+      float4 sv = ld4(pos + e0 + static_cast<long long>(j) * s.d);
+      if (HAS_V) {
+        const float4 vv = ld4(vfb + static_cast<long long>(ip[j]) * s.d);
+        sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
+      }
+      NSDP_ONLINE_STEP(x) NSDP_ONLINE_STEP(y) NSDP_ONLINE_STEP(z) NSDP_ONLINE_STEP(w)
+    }
+    float4 out = make_float4(acc.x / l.x, acc.y / l.y, acc.z / l.z, acc.w / l.w);
+    st4(lse + pt * s.d + 4 * L.cq,
+        make_float4(m.x + __logf(l.x), m.y + __logf(l.y), m.z + __logf(l.z), m.w + __logf(l.w)));
+    if (residual) {
+      const float4 r = ld4(residual + pt * s.d + 4 * L.cq);
+      out.x += r.x; out.y += r.y; out.z += r.z; out.w += r.w;
+    }
+    st4(y + pt * s.d + 4 * L.cq, out);
   }
 }
 
@@ -131,79 +207,98 @@ __global__ __launch_bounds__(T) void attn_post_fwd_kernel(AttnShape s, const flo
 //   w_j = exp(a_j - lse);  s_j = vf[idx_j] + pos_j;  yb = y - residual (the attention output itself,
 //   recovered from the saved forward output so that no second [B,n,d] tensor has to be kept)
 //   da_j = w_j dy (s_j - yb);  ds_j = w_j dy  (written to dpos, scattered into dvf)
-//   global token: da_g += sum_i w_g dy (v_g - yb), dv_g += sum_i w_g dy   (one atomic per block+channel)
-template <int T, bool HAS_V>
-__global__ __launch_bounds__(T) void attn_post_bwd_kernel(
+//   global token: da_g += sum_i w_g dy (v_g - yb), dv_g += sum_i w_g dy   (register partial sums over the
+//   wave's points, one atomic per lane and shape)
+template <bool HAS_V>
+__global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     AttnShape s, const float *__restrict__ dy, const float *__restrict__ a, const float *__restrict__ vf,
     const float *__restrict__ pos, const int32_t *__restrict__ idx, const float *__restrict__ a_g,
     const float *__restrict__ v_g, const float *__restrict__ y, const float *__restrict__ residual,
-    const float *__restrict__ lse, float *__restrict__ da, float *__restrict__ dpos, float *__restrict__ dvf, float *__restrict__ da_g,
-    float *__restrict__ dv_g) {
-  const int c = threadIdx.x;
-  if (c >= s.d) return;
-  const int b = blockIdx.y;
-  const int i0 = blockIdx.x * kPointsPerBlock;
-  const int i1 = min(s.n, i0 + kPointsPerBlock);
-  const float *vfb = HAS_V ? vf + static_cast<size_t>(b) * s.N * s.d : nullptr;
-  float *dvfb = HAS_V ? dvf + static_cast<size_t>(b) * s.N * s.d : nullptr;
+    const float *__restrict__ lse, float *__restrict__ da, float *__restrict__ dpos,
+    float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
+  const Lane L = lane_setup(s);
+  if (!L.active) return;
+  const int lpp = s.d >> 2, cq = L.cq;
+  const long long total = static_cast<long long>(s.B) * s.n;
   const bool has_g = a_g != nullptr;
-  const float ag = has_g ? a_g[static_cast<size_t>(b) * s.d + c] : 0.f;
-  const float vg = has_g ? v_g[static_cast<size_t>(b) * s.d + c] : 0.f;
-  float dag_acc = 0.f, dvg_acc = 0.f;
-  for (int i = i0; i < i1; ++i) {
-    const size_t pt = static_cast<size_t>(b) * s.n + i;
+  Quad dag{0.f, 0.f, 0.f, 0.f}, dvg{0.f, 0.f, 0.f, 0.f};
+  int gb = -1;
+  for (int it = 0; it < kIters; ++it) {
+    const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+    if (pt >= total) break;
+    const int b = static_cast<int>(pt / s.n);
+    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d : nullptr;
+    float *dvfb = HAS_V ? dvf + static_cast<long long>(b) * s.N * s.d : nullptr;
     const int32_t *ip = idx + pt * s.k;
-    const size_t row0 = pt * s.k;
-    const float g = dy[pt * s.d + c];
-    const float yb = y[pt * s.d + c] - (residual ? residual[pt * s.d + c] : 0.f);
-    const float L = lse[pt * s.d + c];
+    const long long r0 = pt * s.k * s.d;
+    const Quad g = ldq(dy + pt * s.d, cq, lpp);
+    Quad yb = ldq(y + pt * s.d, cq, lpp);
+    if (residual) {
+      const Quad r = ldq(residual + pt * s.d, cq, lpp);
+      yb.x -= r.x; yb.y -= r.y; yb.z -= r.z; yb.w -= r.w;
+    }
+    const Quad Lse = ldq(lse + pt * s.d, cq, lpp);
+#pragma unroll 2
     for (int j = 0; j < s.k; ++j) {
-      const size_t e = (row0 + j) * s.d + c;
-      const float w = __expf(a[e] - L);
-      float sv = pos[e];
-      if (HAS_V) sv += vfb[static_cast<size_t>(ip[j]) * s.d + c];
-      const float ds = w * g;
-      da[e] = ds * (sv - yb);
-      dpos[e] = ds;
-      if (HAS_V) atomicAdd(dvfb + static_cast<size_t>(ip[j]) * s.d + c, ds);
+      const long long rj = r0 + static_cast<long long>(j) * s.d;
+      const Quad av = ldq(a + rj, cq, lpp);
+      Quad sv = ldq(pos + rj, cq, lpp);
+      if (HAS_V) {
+        const Quad vv = ldq(vfb + static_cast<long long>(ip[j]) * s.d, cq, lpp);
+        sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
+      }
+      const Quad ds{__expf(av.x - Lse.x) * g.x, __expf(av.y - Lse.y) * g.y, __expf(av.z - Lse.z) * g.z,
+                    __expf(av.w - Lse.w) * g.w};
+      stq(da + rj, cq, lpp,
+          Quad{ds.x * (sv.x - yb.x), ds.y * (sv.y - yb.y), ds.z * (sv.z - yb.z), ds.w * (sv.w - yb.w)});
+      stq(dpos + rj, cq, lpp, ds);
+      if (HAS_V) atomic_addq(dvfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, ds);
     }
     if (has_g) {
-      const float ds = __expf(ag - L) * g;
-      dag_acc += ds * (vg - yb);
-      dvg_acc += ds;
+      if (b != gb) {
+        if (gb >= 0) {
+          atomic_addq(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
+          atomic_addq(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
+        }
+        dag = Quad{0.f, 0.f, 0.f, 0.f};
+        dvg = dag;
+        gb = b;
+      }
+      const Quad ag = ldq(a_g + static_cast<long long>(b) * s.d, cq, lpp);
+      const Quad vg = ldq(v_g + static_cast<long long>(b) * s.d, cq, lpp);
+      const Quad ds{__expf(ag.x - Lse.x) * g.x, __expf(ag.y - Lse.y) * g.y, __expf(ag.z - Lse.z) * g.z,
+                    __expf(ag.w - Lse.w) * g.w};
+      dag.x += ds.x * (vg.x - yb.x); dag.y += ds.y * (vg.y - yb.y);
+      dag.z += ds.z * (vg.z - yb.z); dag.w += ds.w * (vg.w - yb.w);
+      dvg.x += ds.x; dvg.y += ds.y; dvg.z += ds.z; dvg.w += ds.w;
     }
   }
-  if (has_g) {
-    atomicAdd(da_g + static_cast<size_t>(b) * s.d + c, dag_acc);
-    atomicAdd(dv_g + static_cast<size_t>(b) * s.d + c, dvg_acc);
+  if (has_g && gb >= 0) {
+    atomic_addq(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
+    atomic_addq(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
   }
 }
 
 inline bool shape_ok(const AttnShape &s) {
-  return s.B > 0 && s.n > 0 && s.N > 0 && s.k > 0 && s.d > 0 && s.d <= 256 && s.B <= 65535;
+  return s.B > 0 && s.n > 0 && s.N > 0 && s.k > 0 && s.d >= 4 && s.d <= 256 && s.d % 4 == 0;
 }
 
 inline double rows(const AttnShape &s) { return static_cast<double>(s.B) * s.n * s.k; }
 
 }  // namespace
 
-#define NSDP_ATTN_LAUNCH(KERNEL, ...)                                                      \
-  do {                                                                                     \
-    const dim3 grid(nsdp::ceil_div(s.n, kPointsPerBlock), s.B);                            \
-    if (s.d <= 128) hipLaunchKernelGGL((KERNEL<128>), grid, dim3(128), 0, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<256>), grid, dim3(256), 0, st, __VA_ARGS__);            \
-  } while (0)
+inline dim3 attn_grid(const AttnShape &s) {
+  const long long ppw = 64 / (s.d >> 2);
+  const long long per_block = 4 * ppw * kIters;  // 4 waves per workgroup
+  return dim3(static_cast<unsigned>((static_cast<long long>(s.B) * s.n + per_block - 1) / per_block));
+}
 
-#define NSDP_ATTN_LAUNCH_V(KERNEL, HASV, ...)                                                     \
-  do {                                                                                            \
-    const dim3 grid(nsdp::ceil_div(s.n, kPointsPerBlock), s.B);                                   \
-    if (s.d <= 128) {                                                                             \
-      if (HASV) hipLaunchKernelGGL((KERNEL<128, true>), grid, dim3(128), 0, st, __VA_ARGS__);     \
-      else hipLaunchKernelGGL((KERNEL<128, false>), grid, dim3(128), 0, st, __VA_ARGS__);         \
-    } else {                                                                                      \
-      if (HASV) hipLaunchKernelGGL((KERNEL<256, true>), grid, dim3(256), 0, st, __VA_ARGS__);     \
-      else hipLaunchKernelGGL((KERNEL<256, false>), grid, dim3(256), 0, st, __VA_ARGS__);         \
-    }                                                                                             \
+#define NSDP_ATTN_LAUNCH(KERNEL, ...) hipLaunchKernelGGL(KERNEL, attn_grid(s), dim3(256), 0, st, __VA_ARGS__)
+
+#define NSDP_ATTN_LAUNCH_V(KERNEL, HASV, ...)                                                   \
+  do {                                                                                          \
+    if (HASV) hipLaunchKernelGGL((KERNEL<true>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<false>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);      \
   } while (0)
 
 extern "C" {
@@ -212,7 +307,7 @@ int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const i
                       int N, int k, int d, int q_per_shape, float *u, void *stream) {
   const AttnShape s{B, n, N, k, d, q_per_shape};
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
-  NSDP_REQUIRE(shape_ok(s), "attn_pre_fwd: unsupported shape (d=%d must be <= 256)", d);
+  NSDP_REQUIRE(shape_ok(s), "attn_pre_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(q && kf && pos && idx && u, "attn_pre_fwd: null pointer");
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kAttnFwd, st, 0.0,
@@ -230,7 +325,7 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   if (dkf && static_cast<long long>(B) * N * d > 0)
     NSDP_HIP_TRY(hipMemsetAsync(dkf, 0, sizeof(float) * static_cast<size_t>(B) * N * d, st));
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
-  NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be <= 256)", d);
+  NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           4.0 * (rows(s) * (d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
@@ -243,7 +338,7 @@ int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const 
                        int k, int d, float *y, float *lse, void *stream) {
   const AttnShape s{B, n, N, k, d, 0};
   if (static_cast<long long>(B) * n * d <= 0) return 0;
-  NSDP_REQUIRE(shape_ok(s), "attn_post_fwd: unsupported shape (d=%d must be <= 256)", d);
+  NSDP_REQUIRE(shape_ok(s), "attn_post_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(a && pos && idx && y && lse, "attn_post_fwd: null pointer");
   NSDP_REQUIRE((a_g == nullptr) == (v_g == nullptr), "attn_post_fwd: a_g and v_g go together");
   hipStream_t st = nsdp::as_stream(stream);
@@ -267,7 +362,7 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
     NSDP_HIP_TRY(hipMemsetAsync(dv_g, 0, sizeof(float) * static_cast<size_t>(B) * d, st));
   }
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
-  NSDP_REQUIRE(shape_ok(s), "attn_post_bwd: unsupported shape (d=%d must be <= 256)", d);
+  NSDP_REQUIRE(shape_ok(s), "attn_post_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(dy && a && pos && idx && y && lse && da && dpos, "attn_post_bwd: null pointer");
   NSDP_REQUIRE((vf == nullptr) == (dvf == nullptr), "attn_post_bwd: vf and dvf go together");
   NSDP_REQUIRE((a_g == nullptr) == (da_g == nullptr) && (a_g == nullptr) == (v_g == nullptr) &&

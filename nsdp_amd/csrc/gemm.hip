@@ -412,8 +412,15 @@ __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long
                                        float *__restrict__ db, int accumulate) {
   const long long e = blockIdx.x * 256LL + threadIdx.x;
   if (e >= nw + nb) return;
-  float s = 0.f;
-  for (int c = 0; c < S; ++c) s += ws[c * stride + e];
+  // 8 independent partial sums keep 8 loads in flight per lane (a single dependent chain is latency-bound)
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= S; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += ws[(c + u) * stride + e];
+  }
+  for (; c < S; ++c) acc[0] += ws[c * stride + e];
+  const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
   if (e < nw) {
     dW[e] = accumulate ? dW[e] + s : s;
   } else if (db) {
@@ -471,6 +478,10 @@ WgradPlan plan_wgrad(long long M, int N, int K) {
   WgradPlan pl;
   pl.grid_y = (ktiles + tk - 1) / tk;
   long long max_chunks = 512 / pl.grid_y;
+  // the partial buffers cost 2 * chunks * N*K*4 bytes of extra traffic (write + reduce-read): keep that
+  // below ~1/4 of the operand traffic M*(N+K)*4, i.e. chunks <= M*(N+K) / (8*N*K)
+  const long long traffic_cap = (M * static_cast<long long>(N + K)) / (8LL * N * K);
+  if (max_chunks > traffic_cap) max_chunks = traffic_cap < 96 ? 96 / pl.grid_y : traffic_cap;  // small M: latency, not traffic
   long long chunks = (M + 127) / 128;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
