@@ -25,9 +25,13 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+int g_nt_dbg = 0;
+int g_nt_pipe = 1;  // nsdp_debug_set(3, v): 1 = fenced two-buffer software pipeline, 0 = register-lean loop
+
 struct LinearParams {
   const float *X, *W, *bias, *residual, *mask, *out_mask;
   float *Y;
+  int dbg;  // experiment knob (nsdp_debug_set(4, v)): 1 = skip epilogue stores, 2 = A rows all the same (L2-hot X)
   long long M;
   int N, K;
   int relu_in, relu_out;
@@ -38,7 +42,7 @@ struct LinearParams {
 // s_waitcnt vmcnt(0), which serialises the whole operand stream.  Rows >= M and columns >= N compute
 // garbage that is never stored; the ragged last k-block (K % 16 != 0) is handled by zeroing the weight
 // fragment with a select while the activation fragment re-reads in-row (finite) data.
-template <int MT, int NT, int PRE>
+template <int MT, int NT, int PRE, bool PIPE>
 __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   for (int mt = 0; mt < MT; ++mt) {
     long long r = row0 + mt * 16 + li;
     r = r < p.M ? r : (p.M - 1);
+    if (p.dbg == 2) r = r & 4095;
     xa[mt] = p.X + r * K;
     ma[mt] = PRE == 1 ? p.mask + r * K : nullptr;
   }
@@ -162,31 +167,224 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
     }
   };
 
-  Frag f0, f1;
-  issue(0, f0);
-  __builtin_amdgcn_sched_barrier(0);
-  int kb = 0;
-  for (; kb + 2 <= KB; kb += 2) {
-    fixup(kb, f0);
-    issue(kb + 1, f1);
-    mma(f0);
-    interleave();
+  if (PIPE) {
+    Frag f0, f1;
+    issue(0, f0);
     __builtin_amdgcn_sched_barrier(0);
-    fixup(kb + 1, f1);
-    // kb + 2 == KB re-loads a valid block whose result is never used: keeps the loop branch-free
-    issue(kb + 2 < KB ? kb + 2 : kb, f0);
-    mma(f1);
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  if (kb < KB) {
-    fixup(kb, f0);
-    mma(f0);
+    int kb = 0;
+    for (; kb + 2 <= KB; kb += 2) {
+      fixup(kb, f0);
+      issue(kb + 1, f1);
+      mma(f0);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+      fixup(kb + 1, f1);
+      // kb + 2 == KB re-loads a valid block whose result is never used: keeps the loop branch-free
+      issue(kb + 2 < KB ? kb + 2 : kb, f0);
+      mma(f1);
+      interleave();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kb < KB) {
+      fixup(kb, f0);
+      mma(f0);
+    }
+  } else {  // register-lean form: no explicit prefetch, two waves per SIMD overlap each other's loads
+    for (int kb = 0; kb < KB; ++kb) {
+      Frag f;
+      issue(kb, f);
+      fixup(kb, f);
+      mma(f);
+    }
   }
 
   // epilogue: C/D layout col = lane & 15, row = (lane >> 4) * 4 + reg.  Loads are unconditional from
-  // clamped indices (see above); only the stores are predicated.
-  const bool full_rows = row0 + MT * 16 <= p.M;  // wave-uniform
+  // clamped indices (see above).  Fast path (wave-uniform): all MT*16 rows in range -> the stores of
+  // every complete 16-column tile are unconditional straight-line code; only the ragged last tile
+  // (N % 16 != 0) and the last row block of the matrix take the predicated form.
+  const bool full_rows = row0 + MT * 16 <= p.M;
+  auto tile = [&](int nt, auto has_omask, auto guarded) {
+    const int col = nt * 16 + li;
+    const bool cv = col < N;
+    const int colc = cv ? col : (N - 1);
+    const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + mt * 16 + g * 4 + r;
+        const bool rv = !decltype(guarded)::value || row < p.M;
+        const long long rowc = rv ? row : (p.M - 1);
+        float v = acc[mt][nt][r] + bv;
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        if (decltype(has_omask)::value) v = p.out_mask[rowc * N + colc] > 0.f ? v : 0.f;
+        if (decltype(guarded)::value) {
+          if (cv && rv && p.dbg != 1) p.Y[rowc * N + colc] = v;
+        } else {
+          p.Y[row * N + col] = v;
+        }
+      }
+    }
+  };
+  auto epilogue = [&](auto has_omask) {
+    const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
+    if (full_rows && p.dbg != 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt < full_tiles) tile(nt, has_omask, std::false_type{});
+        else if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
+    }
+  };
+  if (p.out_mask) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variant: the weight k-block (NT KiB) is DMA'd into LDS once per workgroup
+// (global_load_lds_dwordx4, one 1 KiB piece per wave-instruction, lane-linear = exactly the MFMA
+// fragment order) instead of being re-loaded into registers by each of the 4 waves, and the
+// activations take the same route through a wave-private LDS slot.  A wave then issues 2 + NT/4 DMA
+// pieces per k-block instead of 2 + NT register loads (VMEM issue competes with MFMA issue inside a
+// wave), holds only one B fragment at a time (two workgroups per CU fit), and the loop is the
+// two-buffer STAGE -> ds_read + MFMA -> vmcnt(0) + barrier structure.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+template <int MT, int NT, int PRE>
+__global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
+  constexpr int kASlots = (PRE == 1 ? 2 : 1) * MT;          // activation (+ mask) tiles per wave
+  __shared__ __attribute__((aligned(16))) float lds[2 * (NT + 4 * kASlots) * 256];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const long long row0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * (MT * 16);
+  const int K = p.K, N = p.N;
+  const int KB = (K + 15) >> 4;
+  const bool ragged_k = (K & 15) != 0;
+  constexpr int kBufFloats = (NT + 4 * kASlots) * 256;
+  float *bslot = lds;                                        // [buf][NT][256]
+  float *aslot = lds + NT * 256 + wave * kASlots * 256;      // [buf][wave][kASlots][256]
+
+  f32x4 acc[MT][NT];
+  if (p.residual) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        int col = nt * 16 + li;
+        col = col < N ? col : (N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          long long row = row0 + mt * 16 + g * 4 + r;
+          row = row < p.M ? row : (p.M - 1);
+          acc[mt][nt][r] = p.residual[row * N + col];
+        }
+      }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // per-lane global source rows (clamped into the tensors: out-of-range rows/columns are never stored)
+  const float *xa[MT];
+  const float *ma[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    long long r = row0 + mt * 16 + li;
+    r = r < p.M ? r : (p.M - 1);
+    xa[mt] = p.X + r * K;
+    ma[mt] = PRE == 1 ? p.mask + r * K : nullptr;
+  }
+  constexpr int kMyB = (NT + 3) / 4;                          // weight tiles DMA'd by this wave
+  const float *wb[kMyB];
+#pragma unroll
+  for (int t = 0; t < kMyB; ++t) {
+    int nt = wave + 4 * t;
+    nt = nt < NT ? nt : (NT - 1);
+    int n = nt * 16 + li;
+    n = n < N ? n : (N - 1);
+    wb[t] = p.W + static_cast<long long>(n) * K;
+  }
+
+  auto stage = [&](int kb, int buf) {
+    int ko = kb * 16 + 4 * g;
+    ko = ko < K ? ko : (K - 4);
+    float *bb = bslot + buf * kBufFloats;
+    float *ab = aslot + buf * kBufFloats;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xa[mt] + ko), (lds_ptr_t)(ab + mt * 256), 16, 0, 0);
+      if (PRE == 1)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ma[mt] + ko), (lds_ptr_t)(ab + (MT + mt) * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < kMyB; ++t) {
+      const int nt = wave + 4 * t;
+      if (nt < NT)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wb[t] + ko), (lds_ptr_t)(bb + nt * 256), 16, 0, 0);
+    }
+  };
+  auto compute = [&](int kb, int buf) {
+    const float *bb = bslot + buf * kBufFloats;
+    const float *ab = aslot + buf * kBufFloats;
+    float4 a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float4 v = *reinterpret_cast<const float4 *>(ab + mt * 256 + lane * 4);
+      if (PRE == 1) {
+        const float4 m = *reinterpret_cast<const float4 *>(ab + (MT + mt) * 256 + lane * 4);
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+      }
+      if (PRE == 2) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      a[mt] = v;
+    }
+    const bool zero_tail = ragged_k && kb == KB - 1 && (kb * 16 + 4 * g >= K);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float4 b = *reinterpret_cast<const float4 *>(bb + nt * 256 + lane * 4);
+      if (ragged_k) {  // uniform; the select only bites in the last block
+        b.x = zero_tail ? 0.f : b.x; b.y = zero_tail ? 0.f : b.y;
+        b.z = zero_tail ? 0.f : b.z; b.w = zero_tail ? 0.f : b.w;
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b.x, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b.y, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b.z, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b.w, acc[mt][nt], 0, 0, 0);
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kb = 0; kb < KB; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < KB) stage(kb + 1, cur ^ 1);   // DMA of the next block runs under this block's MFMAs
+    compute(kb, cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (row0 >= p.M) return;  // (after the last barrier)
+  const bool full_rows = row0 + MT * 16 <= p.M;
   auto epilogue = [&](auto has_omask) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -221,9 +419,19 @@ int launch_nt(const LinearParams &p, hipStream_t st) {
   nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   const dim3 gr(static_cast<unsigned>(grid));
-  if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0>), gr, dim3(256), 0, st, p);
-  else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1>), gr, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2>), gr, dim3(256), 0, st, p);
+  if (g_nt_pipe == 2) {
+    if (pre == 0) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 0>), gr, dim3(256), 0, st, p);
+    else if (pre == 1) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 1>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 2>), gr, dim3(256), 0, st, p);
+  } else if (g_nt_pipe) {
+    if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0, true>), gr, dim3(256), 0, st, p);
+    else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1, true>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2, true>), gr, dim3(256), 0, st, p);
+  } else {
+    if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0, false>), gr, dim3(256), 0, st, p);
+    else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1, false>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2, false>), gr, dim3(256), 0, st, p);
+  }
   return nsdp::launch_status("linear_nt_kernel");
 }
 
@@ -434,6 +642,8 @@ extern "C" {
 
 void nsdp_debug_set(int key, int value) {
   if (key == 1) g_wgrad_pipe = value;
+  if (key == 3) g_nt_pipe = value;
+  if (key == 4) g_nt_dbg = value;
 }
 
 int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
@@ -446,7 +656,7 @@ int nsdp_linear_f32(const float *X, const float *W, const float *bias, const flo
   NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) == 0 &&
                    (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0),
                "linear: X/W/mask must be 16-byte aligned");
-  LinearParams p{X, W, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out};
+  LinearParams p{X, W, bias, residual, mask, out_mask, Y, g_nt_dbg, M, N, K, relu_in, relu_out};
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
   if (nt <= 1) return launch_nt<4, 1>(p, st);

@@ -1,5 +1,5 @@
 import os, sys, torch, torch.nn.functional as F
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nsdp_amd.hip_linear import _fwd, _wgrad
 dev = torch.device('cuda:0')
 def timeit(fn, n=10):
@@ -13,7 +13,9 @@ def timeit(fn, n=10):
 for (M, K, N) in [(1835008, 200, 200), (1835008, 208, 208), (655360, 120, 120), (655360, 128, 128), (262144, 200, 128), (262144, 128, 128), (320000, 256, 256), (256000, 256, 256), (65536, 120, 120)]:
     x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev)
     dy = torch.randn(M, N, device=dev)
+    from nsdp_amd._lib import lib
     t1 = timeit(lambda: _fwd(x, w, b, None, None, None, False, True))
+    lib().nsdp_debug_set(4, 1); t1a = timeit(lambda: _fwd(x, w, b, None, None, None, False, True)); lib().nsdp_debug_set(4, 2); t1b = timeit(lambda: _fwd(x, w, b, None, None, None, False, True)); lib().nsdp_debug_set(4, 0)
     t2 = timeit(lambda: F.relu(F.linear(x, w, b)))
     from nsdp_amd._lib import lib
     lib().nsdp_debug_set(1, 0); t3 = timeit(lambda: _wgrad(dy, x, None, False, True))
@@ -21,4 +23,4 @@ for (M, K, N) in [(1835008, 200, 200), (1835008, 208, 208), (655360, 120, 120), 
     lib().nsdp_debug_set(1, -1)
     t4 = timeit(lambda: (dy.t() @ x, dy.sum(0)))
     fl = 2.0 * M * N * K
-    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | hip wgrad nopipe {t3:.3f} ms {fl/t3/1e9:.1f} TF pipe {t3b:.3f} ms {fl/t3b/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
+    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF nostore {fl/t1a/1e9:.1f} hotX {fl/t1b/1e9:.1f} | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | hip wgrad nopipe {t3:.3f} ms {fl/t3/1e9:.1f} TF pipe {t3b:.3f} ms {fl/t3b/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
