@@ -385,26 +385,41 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 
   if (row0 >= p.M) return;  // (after the last barrier)
   const bool full_rows = row0 + MT * 16 <= p.M;
-  auto epilogue = [&](auto has_omask) {
+  auto tile = [&](int nt, auto has_omask, auto guarded) {
+    const int col = nt * 16 + li;
+    const bool cv = col < N;
+    const int colc = cv ? col : (N - 1);
+    const float bv = p.bias ? p.bias[colc] : 0.f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = nt * 16 + li;
-      const bool cv = col < N;
-      const int colc = cv ? col : (N - 1);
-      const float bv = p.bias ? p.bias[colc] : 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const long long row = row0 + mt * 16 + g * 4 + r;
-          const bool rv = full_rows || row < p.M;
-          const long long rowc = rv ? row : (p.M - 1);
-          float v = acc[mt][nt][r] + bv;
-          if (p.relu_out) v = fmaxf(v, 0.f);
-          if (decltype(has_omask)::value) v = p.out_mask[rowc * N + colc] > 0.f ? v : 0.f;
-          if (cv && rv) p.Y[rowc * N + colc] = v;
+      for (int r = 0; r < 4; ++r) {
+        const long long row = row0 + mt * 16 + g * 4 + r;
+        const bool rv = !decltype(guarded)::value || row < p.M;
+        const long long rowc = rv ? row : (p.M - 1);
+        float v = acc[mt][nt][r] + bv;
+        if (p.relu_out) v = fmaxf(v, 0.f);
+        if (decltype(has_omask)::value) v = p.out_mask[rowc * N + colc] > 0.f ? v : 0.f;
+        if (decltype(guarded)::value) {
+          if (cv && rv && p.dbg != 1) p.Y[rowc * N + colc] = v;
+        } else {
+          p.Y[row * N + col] = v;
         }
       }
+    }
+  };
+  auto epilogue = [&](auto has_omask) {
+    const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
+    if (full_rows && p.dbg != 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (nt < full_tiles) tile(nt, has_omask, std::false_type{});
+        else if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
     }
   };
   if (p.out_mask) epilogue(std::true_type{});
@@ -593,8 +608,114 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
   }
 }
 
+int g_wgrad_vec4 = 1;  // nsdp_debug_set(5, v): 1 = float4-operand weight-gradient kernel (default), 0 = dword form
 int g_wgrad_pipe = 0;  // measured on MI355X: the register-lean form wins at every layer shape of the path
                        // (52-65 vs 38-48 TF); 1 = software-pipelined form (nsdp_debug_set(1, v))
+
+// Vector-load form of the weight-gradient kernel.  MFMA tiles are free to cover ANY 16 rows/columns of
+// the output, so a group of 4 tiles is defined over 64 consecutive columns with tile t owning columns
+// {4*li + t}: a lane then reads its 4 tiles' operands with ONE float4 (dY[m][64*ng + 4*li .. +3], and the
+// same for X) -- 4x fewer VMEM instructions than one dword per tile, whole 256-B row segments per 16
+// lanes.  Output element (tile t, D row i = g*4 + r) is dW row n = 64*ng + 4*i + t; D column j of k-tile
+// t' is k = 64*kg + 4*j + t'.
+// Waves: waves_n = ceil(N/64) of them split the columns; the remaining factor row_split = 4/waves_n
+// splits the chunk's 16-row blocks, each row split writing its own partial slot.
+template <int TK4>
+__global__ __launch_bounds__(256) void linear_wgrad4_kernel(WgradParams p, int waves_n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = p.N, K = p.K;
+  const int row_split = 4 / waves_n;
+  const int ng = wave % waves_n, rs = wave / waves_n;
+  const int kg0 = blockIdx.y * TK4;
+  const long long m_begin = static_cast<long long>(blockIdx.x) * p.rows_per_chunk;
+  const long long m_end = min(p.M, m_begin + p.rows_per_chunk);
+
+  f32x4 acc[4][4 * TK4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4 * TK4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float4 dbsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // clamped float4 column offsets (N, K are multiples of 4): out-of-range columns feed tiles never stored
+  int ncol = 64 * ng + 4 * li;
+  ncol = ncol < N ? ncol : (N - 4);
+  int kcol[TK4];
+#pragma unroll
+  for (int b = 0; b < TK4; ++b) {
+    const int c = 64 * (kg0 + b) + 4 * li;
+    kcol[b] = c < K ? c : (K - 4);
+  }
+  const bool has_mask = p.mask != nullptr;
+
+  for (long long mb = m_begin + 16LL * rs; mb < m_end; mb += 16LL * row_split) {
+    float4 av[4], mv4[4], bv[4][TK4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      long long m = mb + 4 * g + s4;
+      m = m < p.M ? m : (p.M - 1);
+      av[s4] = *reinterpret_cast<const float4 *>(p.dY + m * N + ncol);
+      if (has_mask) mv4[s4] = *reinterpret_cast<const float4 *>(p.mask + m * N + ncol);
+#pragma unroll
+      for (int b = 0; b < TK4; ++b) bv[s4][b] = *reinterpret_cast<const float4 *>(p.X + m * K + kcol[b]);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const bool ok = mb + 4 * g + s4 < m_end;  // rows past the chunk contribute zero
+      float4 a4 = av[s4];
+      if (has_mask) {
+        a4.x = mv4[s4].x > 0.f ? a4.x : 0.f; a4.y = mv4[s4].y > 0.f ? a4.y : 0.f;
+        a4.z = mv4[s4].z > 0.f ? a4.z : 0.f; a4.w = mv4[s4].w > 0.f ? a4.w : 0.f;
+      }
+      a4.x = ok ? a4.x : 0.f; a4.y = ok ? a4.y : 0.f; a4.z = ok ? a4.z : 0.f; a4.w = ok ? a4.w : 0.f;
+      dbsum.x += a4.x; dbsum.y += a4.y; dbsum.z += a4.z; dbsum.w += a4.w;
+      const float aa[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int b = 0; b < TK4; ++b) {
+        float4 x4 = bv[s4][b];
+        if (p.relu_x) {
+          x4.x = fmaxf(x4.x, 0.f); x4.y = fmaxf(x4.y, 0.f); x4.z = fmaxf(x4.z, 0.f); x4.w = fmaxf(x4.w, 0.f);
+        }
+        const float bb[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb)
+            acc[ta][4 * b + tb] =
+                __builtin_amdgcn_mfma_f32_16x16x4f32(aa[ta], bb[tb], acc[ta][4 * b + tb], 0, 0, 0);
+      }
+    }
+  }
+
+  float *out = p.ws + (static_cast<long long>(blockIdx.x) * row_split + rs) * (static_cast<long long>(N) * K + N);
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta) {
+#pragma unroll
+    for (int b = 0; b < TK4; ++b) {
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        const int kc = 64 * (kg0 + b) + 4 * li + tb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = 64 * ng + 4 * (g * 4 + r) + ta;
+          if (n < N && kc < K) out[static_cast<long long>(n) * K + kc] = acc[ta][4 * b + tb][r];
+        }
+      }
+    }
+  }
+  if (p.want_db && blockIdx.y == 0) {
+    // lane (li, g) holds the column sums of columns 64*ng + 4*li + {0..3} over its rows (4g+s): fold the 4 g groups
+    float v[4] = {dbsum.x, dbsum.y, dbsum.z, dbsum.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[t] += __shfl_xor(v[t], 16);
+      v[t] += __shfl_xor(v[t], 32);
+      const int n = 64 * ng + 4 * li + t;
+      if (g == 0 && n < N) out[static_cast<long long>(N) * K + n] = v[t];
+    }
+  }
+}
 
 template <int kWgN, int TK>
 void launch_wgrad(const WgradParams &p, unsigned chunks, int ktiles, hipStream_t st) {
@@ -644,6 +765,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 1) g_wgrad_pipe = value;
   if (key == 3) g_nt_pipe = value;
   if (key == 4) g_nt_dbg = value;
+  if (key == 5) g_wgrad_vec4 = value;
 }
 
 int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
@@ -672,33 +794,50 @@ namespace {
 // Row chunking of the weight-gradient reduction: one residency wave of workgroups (2 per CU with the
 // register-lean kernel = 512 slots) so that no tail wave runs at low occupancy, >= 128 rows per chunk.
 struct WgradPlan {
-  long long chunks, rows;
+  long long chunks, rows, slots;  // slots = partial buffers written (chunks x row splits)
   int grid_y;
+  bool vec4;
+  int tk4, waves_n;
 };
 WgradPlan plan_wgrad(long long M, int N, int K) {
   const int ktiles = (K + 15) / 16;
-  const int wn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
-  const int max_tk = 32 / wn > 16 ? 16 : 32 / wn;
-  int tk;
-  if (ktiles <= 1) tk = 1;
-  else if (ktiles <= 4) tk = 4;
-  else if (ktiles == 13 || ktiles == 7) tk = 7;
-  else if (ktiles <= 8 || max_tk == 8) tk = 8;
-  else tk = 16;
   WgradPlan pl;
-  pl.grid_y = (ktiles + tk - 1) / tk;
+  pl.vec4 = (g_wgrad_vec4 != 0) && K > 16 && (N % 4 == 0) && (K % 4 == 0) && N >= 4;
+  long long slots_per_chunk = 1;
+  if (pl.vec4) {
+    const int kgroups = (K + 63) / 64;
+    pl.tk4 = kgroups >= 2 ? 2 : 1;
+    pl.grid_y = (kgroups + pl.tk4 - 1) / pl.tk4;
+    pl.waves_n = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+    slots_per_chunk = 4 / pl.waves_n;
+  } else {
+    const int wn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
+    const int max_tk = 32 / wn > 16 ? 16 : 32 / wn;
+    int tk;
+    if (ktiles <= 1) tk = 1;
+    else if (ktiles <= 4) tk = 4;
+    else if (ktiles == 13 || ktiles == 7) tk = 7;
+    else if (ktiles <= 8 || max_tk == 8) tk = 8;
+    else tk = 16;
+    pl.grid_y = (ktiles + tk - 1) / tk;
+    pl.tk4 = 0;
+    pl.waves_n = 0;
+  }
   long long max_chunks = 512 / pl.grid_y;
-  // the partial buffers cost 2 * chunks * N*K*4 bytes of extra traffic (write + reduce-read): keep that
-  // below ~1/4 of the operand traffic M*(N+K)*4, i.e. chunks <= M*(N+K) / (8*N*K)
-  const long long traffic_cap = (M * static_cast<long long>(N + K)) / (8LL * N * K);
-  if (max_chunks > traffic_cap) max_chunks = traffic_cap < 96 ? 96 / pl.grid_y : traffic_cap;  // small M: latency, not traffic
-  long long chunks = (M + 127) / 128;
+  // the partial buffers cost 2 * slots * N*K*4 bytes of extra traffic (write + reduce-read): keep that
+  // below ~1/4 of the operand traffic M*(N+K)*4, i.e. slots <= M*(N+K) / (8*N*K)
+  const long long traffic_cap = (M * static_cast<long long>(N + K)) / (8LL * N * K) / slots_per_chunk;
+  if (max_chunks > traffic_cap) max_chunks = traffic_cap < 96 / slots_per_chunk ? 96 / slots_per_chunk / pl.grid_y : traffic_cap;
+  if (max_chunks < 1) max_chunks = 1;
+  const long long min_rows = 128 * slots_per_chunk;
+  long long chunks = (M + min_rows - 1) / min_rows;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
   long long rows = (M + chunks - 1) / chunks;
   rows = (rows + 15) / 16 * 16;
   pl.rows = rows;
   pl.chunks = (M + rows - 1) / rows;
+  pl.slots = pl.chunks * slots_per_chunk;
   return pl;
 }
 }  // namespace
@@ -708,7 +847,7 @@ extern "C" {
 size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K) {
   if (M <= 0) return 0;
   const WgradPlan pl = plan_wgrad(M, N, K);
-  return static_cast<size_t>(pl.chunks) * (static_cast<size_t>(N) * K + N) * sizeof(float);
+  return static_cast<size_t>(pl.slots) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
 int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
@@ -736,7 +875,11 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
     nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K,
                             4.0 * (static_cast<double>(M) * (K + N)));
     const unsigned gx = static_cast<unsigned>(chunks);
-    if (N <= 64) dispatch_wgrad_k<1>(p, gx, ktiles, st);
+    if (pl.vec4) {
+      const dim3 grid(gx, pl.grid_y);
+      if (pl.tk4 == 2) hipLaunchKernelGGL((linear_wgrad4_kernel<2>), grid, dim3(256), 0, st, p, pl.waves_n);
+      else hipLaunchKernelGGL((linear_wgrad4_kernel<1>), grid, dim3(256), 0, st, p, pl.waves_n);
+    } else if (N <= 64) dispatch_wgrad_k<1>(p, gx, ktiles, st);
     else if (N <= 128) dispatch_wgrad_k<2>(p, gx, ktiles, st);
     else dispatch_wgrad_k<4>(p, gx, ktiles, st);
     int rc = nsdp::launch_status("linear_wgrad_kernel");
@@ -744,7 +887,7 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
   }
   const long long nw = static_cast<long long>(N) * K;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0,
-                     st, workspace, static_cast<int>(chunks), nw + N, nw, dW, static_cast<long long>(N), db,
+                     st, workspace, static_cast<int>(pl.slots), nw + N, nw, dW, static_cast<long long>(N), db,
                      accumulate);
   return nsdp::launch_status("reduce_partials_kernel");
 }
