@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -108,7 +110,7 @@ def main():
     model.to(device).train()
     _, optimizer = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
                                       "weight_decay": 0.0}, model.parameters())
-    reducer = GradAllReducer(model, world) if world > 1 else None
+    reducer = GradAllReducer(model, world) if (world > 1 or args.force_reducer) else None
     data = {k: torch.from_numpy(v).to(device)
             for k, v in synth.make_batch(1000 + rank, args.batch, N_SURF, N_QUERY).items()}
 

@@ -119,3 +119,55 @@ def test_eval_forward_matches_oracle_other_inputs(mtype, seed):
         sd = tdnet_ref.to_torch_state(state)
         ref = tdnet_ref.model_forward(sd, cfg["model"], {k: torch.from_numpy(v) for k, v in data.items()}).numpy()
     assert l2_err(out, ref) <= TOL_L2
+
+
+def test_dense_inference_step_matches_oracle():
+    """test_on_batch_with_cano (reference deformation_networks.py:90-109): surface samples, then all mesh
+    vertices through the same encoder input -- the dense-inference call pattern of BASELINE config 5."""
+    from nsdp_amd.model import build_model
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = synth.make_batch(31, 1, 256, 5)
+    model, _, state = build_product(cfg, 31, DEV)
+    _, _, _, test_fn = build_model(cfg, device="cpu")
+    model.eval()
+    verts = synth.uniform(31, "verts", (1, 3001, 3), -0.5, 0.5)
+    dd = to_dev(data, DEV)
+    dd["surface_samples_src"] = dd["surface_samples_inputs"][:, :, :3].contiguous()
+    dd["verts_src"] = torch.from_numpy(verts).to(DEV)
+    dd["verts_tgt"] = dd["verts_src"]
+    loss, out = test_fn(model, dd, cfg, compute_loss=True)
+    sd = tdnet_ref.to_torch_state(state)
+    with torch.no_grad():
+        ref_v = tdnet_ref.model_forward(sd, cfg["model"], {"surface_samples_inputs": torch.from_numpy(data["surface_samples_inputs"]),
+                                                            "q": torch.from_numpy(verts)}, queries_key="q").numpy()
+        ref_s = tdnet_ref.model_forward(sd, cfg["model"], {"surface_samples_inputs": torch.from_numpy(data["surface_samples_inputs"]),
+                                                            "q": torch.from_numpy(data["surface_samples_inputs"][:, :, :3].copy())},
+                                        queries_key="q").numpy()
+    assert l2_err(out["verts_tgt_pred"].cpu().numpy(), ref_v) <= TOL_L2
+    assert l2_err(out["surface_samples_tgt_pred"].cpu().numpy(), ref_s) <= TOL_L2
+    assert abs(loss - float(((ref_v - verts) ** 2).sum(-1).mean() / 2)) < 1e-5
+
+
+def test_flat_bucket_gradients_equal_plain_gradients_on_gpu():
+    """GradAllReducer's .grad views (the data-parallel path) must receive exactly what plain autograd
+    produces, including through the hand-written backward kernels."""
+    from nsdp_amd.parallel import GradAllReducer
+    from nsdp_amd.model.utils import compute_l2_error
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = to_dev(synth.make_batch(8, 2, 256, 128), DEV)
+    model, _, _ = build_product(cfg, 8, DEV)
+    model.train()
+    torch.manual_seed(0)
+    compute_l2_error(model(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"]).backward()
+    plain = {k: p.grad.clone() for k, p in model.named_parameters()}
+    model2, _, _ = build_product(cfg, 8, DEV)
+    model2.train()
+    red = GradAllReducer(model2, 1)
+    red.zero_grad()
+    compute_l2_error(model2(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"]).backward()
+    red.all_reduce_mean()
+    for k, p in model2.named_parameters():
+        assert p.grad.data_ptr() == dict(zip([n for n, _ in red.named], red.views))[k].data_ptr()
+        g = plain[k]
+        # two runs differ by fp32 atomic-ordering noise in the scatter-adds
+        assert float((p.grad - g).abs().max()) <= 2e-3 * float(g.abs().max()) + 1e-6, k
