@@ -24,12 +24,13 @@ namespace {
 struct AttnShape {
   int B, n, N, k, d;  // n centres per shape, N source points per shape, k neighbours, d channels
   int qb;             // 1: q is one vector per shape, (B,1,d), shared by all centres (decoder)
+  int iters;          // point groups walked per wave (fewer for large k so that the grid still fills the chip)
 };
 
 // Work decomposition shared by the four kernels: a lane owns 4 consecutive channels (one float4, so a
 // wave-level access is up to 1 KiB -- 4x the bytes in flight of a dword-per-lane mapping), d/4 lanes form a
 // point, floor(64 / (d/4)) points share a wave, and every wave walks kIters such point groups.
-constexpr int kIters = 8;
+inline int iters_for(int k) { return k >= 64 ? 1 : (k >= 32 ? 2 : (k >= 16 ? 4 : 8)); }
 
 struct Lane {
   bool active;
@@ -48,7 +49,7 @@ __device__ __forceinline__ Lane lane_setup(const AttnShape &s) {
   L.cq = lane - L.sub * lpp;
   L.active = L.sub < L.ppw;
   const long long wave = static_cast<long long>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  L.p0 = wave * (static_cast<long long>(L.ppw) * kIters);
+  L.p0 = wave * (static_cast<long long>(L.ppw) * s.iters);
   return L;
 }
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const fl
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const long long total = static_cast<long long>(s.B) * s.n;
-  for (int it = 0; it < kIters; ++it) {
+  for (int it = 0; it < s.iters; ++it) {
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) return;
     const int b = static_cast<int>(pt / s.n);
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const fl
   const long long total = static_cast<long long>(s.B) * s.n;
   Quad qb_acc{0.f, 0.f, 0.f, 0.f};
   int qb_b = -1;
-  for (int it = 0; it < kIters; ++it) {
+  for (int it = 0; it < s.iters; ++it) {
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) break;
     const int b = static_cast<int>(pt / s.n);
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const f
   if (!L.active) return;
   const long long total = static_cast<long long>(s.B) * s.n;
   const bool has_g = a_g != nullptr;
-  for (int it = 0; it < kIters; ++it) {
+  for (int it = 0; it < s.iters; ++it) {
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) return;
     const int b = static_cast<int>(pt / s.n);
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
   const bool has_g = a_g != nullptr;
   Quad dag{0.f, 0.f, 0.f, 0.f}, dvg{0.f, 0.f, 0.f, 0.f};
   int gb = -1;
-  for (int it = 0; it < kIters; ++it) {
+  for (int it = 0; it < s.iters; ++it) {
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) break;
     const int b = static_cast<int>(pt / s.n);
@@ -279,6 +280,186 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-privatised scatter variants of the two backward kernels, used when the scatter target of one shape
+// (N x d floats) fits in LDS -- the decoder (100 anchors x 200) and the 100-anchor encoder blocks.  A
+// workgroup of 8 waves owns a chunk of centres of ONE shape, accumulates the scattered gradient into an
+// LDS table with ds_add_f32 (conflict-free: consecutive lanes = consecutive channels) and flushes the
+// table with one global atomic per entry: ~n/chunk times fewer global atomics on the few hot rows that
+// every query of a shape hits (the decoder has 57 k (query, neighbour) pairs per anchor row).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLdsThreads = 512;
+
+// contiguous-quad accessors (lane owns channels 4cq..4cq+3) for the LDS-table kernels: global traffic is
+// float4, the LDS adds tolerate the 4-way bank conflict (they are two orders of magnitude off the critical path)
+__device__ __forceinline__ Quad ldc(const float *row, int cq) {
+  const float4 v = *reinterpret_cast<const float4 *>(row + 4 * cq);
+  return Quad{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void stc(float *row, int cq, Quad v) {
+  *reinterpret_cast<float4 *>(row + 4 * cq) = make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void atomic_addc(float *row, int cq, Quad v) {
+  atomicAdd(row + 4 * cq, v.x); atomicAdd(row + 4 * cq + 1, v.y);
+  atomicAdd(row + 4 * cq + 2, v.z); atomicAdd(row + 4 * cq + 3, v.w);
+}
+
+struct BlockLane {
+  bool active;
+  int cq, sub, ppw;
+  long long p0, pend;  // flattened point range [p0 + ..., pend) of this wave inside shape blockIdx.y
+};
+
+__device__ __forceinline__ BlockLane block_lane_setup(const AttnShape &s) {
+  BlockLane L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpp = s.d >> 2;
+  L.ppw = 64 / lpp;
+  L.sub = lane / lpp;
+  L.cq = lane - L.sub * lpp;
+  L.active = L.sub < L.ppw;
+  const int per_wave = L.ppw * s.iters;
+  const int per_block = per_wave * (kLdsThreads / 64);
+  const long long base = static_cast<long long>(blockIdx.y) * s.n;
+  const long long i0 = static_cast<long long>(blockIdx.x) * per_block + static_cast<long long>(wave) * per_wave;
+  L.p0 = base + i0;
+  L.pend = base + s.n;
+  return L;
+}
+
+__global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape s, const float *__restrict__ du,
+                                                                       const int32_t *__restrict__ idx,
+                                                                       float *__restrict__ dq,
+                                                                       float *__restrict__ dkf) {
+  extern __shared__ __attribute__((aligned(16))) float table[];  // [N][d] partial of -sum du
+  const int b = blockIdx.y;
+  const int tsz = s.N * s.d;
+  for (int e = threadIdx.x; e < tsz; e += kLdsThreads) table[e] = 0.f;
+  __syncthreads();
+  const BlockLane L = block_lane_setup(s);
+  const int cq = L.cq;
+  Quad qb_acc{0.f, 0.f, 0.f, 0.f};
+  if (L.active) {
+    for (int it = 0; it < s.iters; ++it) {
+      const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+      if (pt >= L.pend) break;
+      const int32_t *ip = idx + pt * s.k;
+      const float *dur = du + pt * s.k * s.d;
+      Quad acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int j = 0; j < s.k; ++j) {
+        const Quad g = ldc(dur + static_cast<long long>(j) * s.d, cq);
+        acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        atomic_addc(table + ip[j] * s.d, cq, Quad{-g.x, -g.y, -g.z, -g.w});
+      }
+      if (s.qb) {
+        qb_acc.x += acc.x; qb_acc.y += acc.y; qb_acc.z += acc.z; qb_acc.w += acc.w;
+      } else {
+        stc(dq + pt * s.d, cq, acc);
+      }
+    }
+    if (s.qb) atomic_addc(dq + static_cast<long long>(b) * s.d, cq, qb_acc);
+  }
+  __syncthreads();
+  float *out = dkf + static_cast<long long>(b) * tsz;
+  for (int e = threadIdx.x; e < tsz; e += kLdsThreads) {
+    const float v = table[e];
+    if (v != 0.f) atomicAdd(out + e, v);
+  }
+}
+
+template <bool HAS_V>
+__global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
+    AttnShape s, const float *__restrict__ dy, const float *__restrict__ a, const float *__restrict__ vf,
+    const float *__restrict__ pos, const int32_t *__restrict__ idx, const float *__restrict__ a_g,
+    const float *__restrict__ v_g, const float *__restrict__ y, const float *__restrict__ residual,
+    const float *__restrict__ lse, float *__restrict__ da, float *__restrict__ dpos,
+    float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
+  extern __shared__ __attribute__((aligned(16))) float table[];  // [N][d] partial of dvf
+  const int b = blockIdx.y;
+  const int tsz = s.N * s.d;
+  if (HAS_V) {
+    for (int e = threadIdx.x; e < tsz; e += kLdsThreads) table[e] = 0.f;
+    __syncthreads();
+  }
+  const BlockLane L = block_lane_setup(s);
+  const int cq = L.cq;
+  const bool has_g = a_g != nullptr;
+  if (L.active) {
+    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * tsz : nullptr;
+    Quad dag{0.f, 0.f, 0.f, 0.f}, dvg{0.f, 0.f, 0.f, 0.f};
+    Quad ag{0.f, 0.f, 0.f, 0.f}, vg{0.f, 0.f, 0.f, 0.f};
+    if (has_g) {
+      ag = ldc(a_g + static_cast<long long>(b) * s.d, cq);
+      vg = ldc(v_g + static_cast<long long>(b) * s.d, cq);
+    }
+    for (int it = 0; it < s.iters; ++it) {
+      const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+      if (pt >= L.pend) break;
+      const int32_t *ip = idx + pt * s.k;
+      const long long r0 = pt * s.k * s.d;
+      const Quad g = ldc(dy + pt * s.d, cq);
+      Quad yb = ldc(y + pt * s.d, cq);
+      if (residual) {
+        const Quad r = ldc(residual + pt * s.d, cq);
+        yb.x -= r.x; yb.y -= r.y; yb.z -= r.z; yb.w -= r.w;
+      }
+      const Quad Lse = ldc(lse + pt * s.d, cq);
+#pragma unroll 2
+      for (int j = 0; j < s.k; ++j) {
+        const long long rj = r0 + static_cast<long long>(j) * s.d;
+        const Quad av = ldc(a + rj, cq);
+        Quad sv = ldc(pos + rj, cq);
+        if (HAS_V) {
+          const Quad vv = ldc(vfb + static_cast<long long>(ip[j]) * s.d, cq);
+          sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
+        }
+        const Quad ds{__expf(av.x - Lse.x) * g.x, __expf(av.y - Lse.y) * g.y, __expf(av.z - Lse.z) * g.z,
+                      __expf(av.w - Lse.w) * g.w};
+        stc(da + rj, cq,
+            Quad{ds.x * (sv.x - yb.x), ds.y * (sv.y - yb.y), ds.z * (sv.z - yb.z), ds.w * (sv.w - yb.w)});
+        stc(dpos + rj, cq, ds);
+        if (HAS_V) atomic_addc(table + ip[j] * s.d, cq, ds);
+      }
+      if (has_g) {
+        const Quad ds{__expf(ag.x - Lse.x) * g.x, __expf(ag.y - Lse.y) * g.y, __expf(ag.z - Lse.z) * g.z,
+                      __expf(ag.w - Lse.w) * g.w};
+        dag.x += ds.x * (vg.x - yb.x); dag.y += ds.y * (vg.y - yb.y);
+        dag.z += ds.z * (vg.z - yb.z); dag.w += ds.w * (vg.w - yb.w);
+        dvg.x += ds.x; dvg.y += ds.y; dvg.z += ds.z; dvg.w += ds.w;
+      }
+    }
+    if (has_g) {
+      atomic_addc(da_g + static_cast<long long>(b) * s.d, cq, dag);
+      atomic_addc(dv_g + static_cast<long long>(b) * s.d, cq, dvg);
+    }
+  }
+  if (HAS_V) {
+    __syncthreads();
+    float *out = dvf + static_cast<long long>(b) * tsz;
+    for (int e = threadIdx.x; e < tsz; e += kLdsThreads) {
+      const float v = table[e];
+      if (v != 0.f) atomicAdd(out + e, v);
+    }
+  }
+}
+
+inline bool lds_table_fits(const AttnShape &s) {
+  return static_cast<long long>(s.N) * s.d * 4 <= 110 * 1024 && s.B <= 65535 && s.n >= 4 * s.N;
+}
+
+inline dim3 lds_grid(const AttnShape &s) {
+  const int per_block = (64 / (s.d >> 2)) * s.iters * (kLdsThreads / 64);
+  return dim3((s.n + per_block - 1) / per_block, s.B);
+}
+
+template <typename Kern>
+inline void allow_big_lds(Kern kern, size_t bytes) {
+  if (bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(bytes));
+}
+
 inline bool shape_ok(const AttnShape &s) {
   return s.B > 0 && s.n > 0 && s.N > 0 && s.k > 0 && s.d >= 4 && s.d <= 256 && s.d % 4 == 0;
 }
@@ -289,7 +470,7 @@ inline double rows(const AttnShape &s) { return static_cast<double>(s.B) * s.n *
 
 inline dim3 attn_grid(const AttnShape &s) {
   const long long ppw = 64 / (s.d >> 2);
-  const long long per_block = 4 * ppw * kIters;  // 4 waves per workgroup
+  const long long per_block = 4 * ppw * s.iters;  // 4 waves per workgroup
   return dim3(static_cast<unsigned>((static_cast<long long>(s.B) * s.n + per_block - 1) / per_block));
 }
 
@@ -305,7 +486,7 @@ extern "C" {
 
 int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
                       int N, int k, int d, int q_per_shape, float *u, void *stream) {
-  const AttnShape s{B, n, N, k, d, q_per_shape};
+  const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_pre_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(q && kf && pos && idx && u, "attn_pre_fwd: null pointer");
@@ -318,7 +499,7 @@ int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const i
 
 int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
                       int q_per_shape, float *dq, float *dkf, void *stream) {
-  const AttnShape s{B, n, N, k, d, q_per_shape};
+  const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
   if (q_per_shape && dq && static_cast<long long>(B) * d > 0)
     NSDP_HIP_TRY(hipMemsetAsync(dq, 0, sizeof(float) * static_cast<size_t>(B) * d, st));
@@ -329,6 +510,12 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           4.0 * (rows(s) * (d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
+  if (lds_table_fits(s)) {
+    const size_t lds = static_cast<size_t>(N) * d * 4;
+    allow_big_lds(attn_pre_bwd_lds_kernel, lds);
+    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, lds_grid(s), dim3(kLdsThreads), lds, st, s, du, idx, dq, dkf);
+    return nsdp::launch_status("attn_pre_bwd_lds_kernel");
+  }
   NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf);
   return nsdp::launch_status("attn_pre_bwd_kernel");
 }
@@ -336,7 +523,7 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
 int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const int32_t *idx,
                        const float *a_g, const float *v_g, const float *residual, int B, int n, int N,
                        int k, int d, float *y, float *lse, void *stream) {
-  const AttnShape s{B, n, N, k, d, 0};
+  const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   if (static_cast<long long>(B) * n * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_post_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(a && pos && idx && y && lse, "attn_post_fwd: null pointer");
@@ -353,7 +540,7 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        const int32_t *idx, const float *a_g, const float *v_g, const float *y,
                        const float *residual, const float *lse, int B, int n, int N, int k, int d, float *da, float *dpos,
                        float *dvf, float *da_g, float *dv_g, void *stream) {
-  const AttnShape s{B, n, N, k, d, 0};
+  const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
   if (dvf && static_cast<long long>(B) * N * d > 0)
     NSDP_HIP_TRY(hipMemsetAsync(dvf, 0, sizeof(float) * static_cast<size_t>(B) * N * d, st));
@@ -371,6 +558,13 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           4.0 * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + (vf ? 2.0 * N : 0)) * d));
   const bool has_v = vf != nullptr;
+  if (lds_table_fits(s) && has_v) {
+    const size_t lds = static_cast<size_t>(N) * d * 4;
+    allow_big_lds(attn_post_bwd_lds_kernel<true>, lds);
+    hipLaunchKernelGGL((attn_post_bwd_lds_kernel<true>), lds_grid(s), dim3(kLdsThreads), lds, st, s, dy, a, vf, pos,
+                       idx, a_g, v_g, y, residual, lse, da, dpos, dvf, da_g, dv_g);
+    return nsdp::launch_status("attn_post_bwd_lds_kernel");
+  }
   NSDP_ATTN_LAUNCH_V(attn_post_bwd_kernel, has_v, s, dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, da, dpos,
                      dvf, da_g, dv_g);
   return nsdp::launch_status("attn_post_bwd_kernel");
