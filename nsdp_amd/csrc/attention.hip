@@ -307,7 +307,8 @@ __device__ __forceinline__ void atomic_addc(float *row, int cq, Quad v) {
 struct BlockLane {
   bool active;
   int cq, sub, ppw;
-  long long p0, pend;  // flattened point range [p0 + ..., pend) of this wave inside shape blockIdx.y
+  long long p0, pend;  // first centre of this wave and end of this workgroup's range inside shape blockIdx.y
+  int stride;          // centres advanced per iteration (all 8 waves move together)
 };
 
 __device__ __forceinline__ BlockLane block_lane_setup(const AttnShape &s) {
@@ -318,12 +319,13 @@ __device__ __forceinline__ BlockLane block_lane_setup(const AttnShape &s) {
   L.sub = lane / lpp;
   L.cq = lane - L.sub * lpp;
   L.active = L.sub < L.ppw;
-  const int per_wave = L.ppw * s.iters;
-  const int per_block = per_wave * (kLdsThreads / 64);
+  const int per_iter = L.ppw * (kLdsThreads / 64);
   const long long base = static_cast<long long>(blockIdx.y) * s.n;
-  const long long i0 = static_cast<long long>(blockIdx.x) * per_block + static_cast<long long>(wave) * per_wave;
-  L.p0 = base + i0;
-  L.pend = base + s.n;
+  const long long i0 = static_cast<long long>(blockIdx.x) * per_iter * s.iters + static_cast<long long>(wave) * L.ppw;
+  L.p0 = base + i0;                                  // iteration `it` adds it * per_iter (see stride below)
+  const long long blk_end = static_cast<long long>(blockIdx.x + 1) * per_iter * s.iters;
+  L.pend = base + (blk_end < s.n ? blk_end : s.n);
+  L.stride = per_iter;
   return L;
 }
 
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape
   Quad qb_acc{0.f, 0.f, 0.f, 0.f};
   if (L.active) {
     for (int it = 0; it < s.iters; ++it) {
-      const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+      const long long pt = L.p0 + static_cast<long long>(it) * L.stride + L.sub;
       if (pt >= L.pend) break;
       const int32_t *ip = idx + pt * s.k;
       const float *dur = du + pt * s.k * s.d;
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
       vg = ldc(v_g + static_cast<long long>(b) * s.d, cq);
     }
     for (int it = 0; it < s.iters; ++it) {
-      const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
+      const long long pt = L.p0 + static_cast<long long>(it) * L.stride + L.sub;
       if (pt >= L.pend) break;
       const int32_t *ip = idx + pt * s.k;
       const long long r0 = pt * s.k * s.d;
@@ -448,9 +450,18 @@ inline bool lds_table_fits(const AttnShape &s) {
   return static_cast<long long>(s.N) * s.d * 4 <= 110 * 1024 && s.B <= 65535 && s.n >= 4 * s.N;
 }
 
-inline dim3 lds_grid(const AttnShape &s) {
-  const int per_block = (64 / (s.d >> 2)) * s.iters * (kLdsThreads / 64);
-  return dim3((s.n + per_block - 1) / per_block, s.B);
+// The table flush costs N*d global atomics per workgroup, so the LDS variants use FEW, LONG workgroups:
+// about 512 in total (two per CU would not fit in LDS anyway), each walking ~n*B/512 centres.
+inline void lds_plan(AttnShape &s, dim3 &grid) {
+  const int ppw = 64 / (s.d >> 2);
+  const int per_iter = ppw * (kLdsThreads / 64);             // centres per workgroup iteration
+  int blocks_per_shape = 512 / s.B;
+  if (blocks_per_shape < 1) blocks_per_shape = 1;
+  const int max_blocks = (s.n + per_iter - 1) / per_iter;
+  if (blocks_per_shape > max_blocks) blocks_per_shape = max_blocks;
+  const int pts_per_block = (s.n + blocks_per_shape - 1) / blocks_per_shape;
+  s.iters = (pts_per_block + per_iter - 1) / per_iter;
+  grid = dim3((s.n + s.iters * per_iter - 1) / (s.iters * per_iter), s.B);
 }
 
 template <typename Kern>
@@ -513,7 +524,10 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   if (lds_table_fits(s)) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
     allow_big_lds(attn_pre_bwd_lds_kernel, lds);
-    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, lds_grid(s), dim3(kLdsThreads), lds, st, s, du, idx, dq, dkf);
+    AttnShape sl = s;
+    dim3 grid;
+    lds_plan(sl, grid);
+    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf);
     return nsdp::launch_status("attn_pre_bwd_lds_kernel");
   }
   NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf);
@@ -561,7 +575,10 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
   if (lds_table_fits(s) && has_v) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
     allow_big_lds(attn_post_bwd_lds_kernel<true>, lds);
-    hipLaunchKernelGGL((attn_post_bwd_lds_kernel<true>), lds_grid(s), dim3(kLdsThreads), lds, st, s, dy, a, vf, pos,
+    AttnShape sl = s;
+    dim3 grid;
+    lds_plan(sl, grid);
+    hipLaunchKernelGGL((attn_post_bwd_lds_kernel<true>), grid, dim3(kLdsThreads), lds, st, sl, dy, a, vf, pos,
                        idx, a_g, v_g, y, residual, lse, da, dpos, dvf, da_g, dv_g);
     return nsdp::launch_status("attn_post_bwd_lds_kernel");
   }
