@@ -152,6 +152,28 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        float *da, float *dpos, float *dvf, float *da_g, float *dv_g, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * BatchNorm1d on channels-last rows x[R,C] (R = B*n, C % 4 == 0, C <= 1024), replacing the 35
+ * nn.BatchNorm1d calls of the encoder (model/encoder/blocks.py:132, :158, :300-312) together with the
+ * residual add in front of them (`addend`, may be NULL: the norm acts on x + addend) and the ReLU behind
+ * them (`relu`).  `workspace` >= nsdp_bn_workspace_bytes(C) bytes.
+ * -------------------------------------------------------------------------------------------- */
+size_t nsdp_bn_workspace_bytes(int C);
+/* training statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); running_mean/var (may be NULL)
+ * updated with `momentum` and the unbiased variance, exactly like nn.BatchNorm1d in training mode. */
+int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
+                  float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
+                  void *stream);
+/* y = ((x + addend) - mean) * invstd * gamma + beta, then ReLU if relu */
+int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
+                  const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream);
+/* backward of the above: dy' = dy * (y_relu > 0) when y_relu != NULL (the forward output of a relu norm);
+ * dgamma = sum dy' xhat, dbeta = sum dy'; dx (= gradient of both x and addend) with the batch-statistics
+ * terms when training != 0, plain gamma*invstd*dy' otherwise (eval: statistics are constants). */
+int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const float *addend,
+                     const float *mean, const float *invstd, const float *gamma, long long R, int C,
+                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Kernel timing with HIP events on the launch stream (used by bench.py for the roofline object)
  * -------------------------------------------------------------------------------------------- */
 void nsdp_prof_enable(int on);            /* on=1 clears previous records and starts recording */

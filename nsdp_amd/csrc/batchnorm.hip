@@ -1,0 +1,312 @@
+// BatchNorm1d over channels-last rows for gfx950 -- replaces the 35 nn.BatchNorm1d calls of the encoder
+// (reference model/encoder/blocks.py:132, :158, :300-312: each one permutes to [B,C,n], runs 3-4 ATen
+// kernels forward and 3 backward, plus separate ReLU / residual-add kernels around it).
+//
+// x is [R, C] (R = B*n rows, C = 120 or 256 channels, C % 4 == 0).  Per direction: one column-reduction
+// kernel (float4 per lane, register partial sums, one LDS hop, per-workgroup partials) + a tiny finalize
+// + one elementwise apply kernel.  The residual add in FRONT of the norm (bn(x + addend)) and the ReLU
+// BEHIND it are fused into both passes, so the sum tensor and the pre-ReLU tensor never exist.
+// Everything here is HBM-bound byte movement: 1 read for the statistics, 1 read + 1 write for the apply.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxParts = 256;  // row chunks (one workgroup each) of the column reductions
+
+struct Geo {
+  int lpr;    // lanes per row = C / 4
+  int rpi;    // rows handled per workgroup iteration = kThreads / lpr
+};
+__device__ __forceinline__ Geo geo(int C) {
+  Geo g;
+  g.lpr = C >> 2;
+  g.rpi = kThreads / g.lpr;
+  return g;
+}
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+// column sums of v and v*v (v = x [+ addend]) over this workgroup's row chunk -> part[blk][2][C]
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ addend, long long R,
+                                                            int C, long long rows_per_blk,
+                                                            float *__restrict__ part) {
+  __shared__ float4 red[2][kThreads];
+  const Geo g = geo(C);
+  const int sub = threadIdx.x / g.lpr, cq = threadIdx.x - sub * g.lpr;
+  const bool active = sub < g.rpi;
+  const long long r0 = blockIdx.x * rows_per_blk;
+  const long long r1 = min(R, r0 + rows_per_blk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  if (active) {
+    for (long long r = r0 + sub; r < r1; r += g.rpi) {
+      float4 v = ld4(x + r * C + 4 * cq);
+      if (addend) {
+        const float4 a = ld4(addend + r * C + 4 * cq);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < g.lpr) {
+    float4 ts = red[0][threadIdx.x], tq = red[1][threadIdx.x];
+    for (int u = 1; u < g.rpi; ++u) {
+      const float4 a = red[0][u * g.lpr + threadIdx.x], b = red[1][u * g.lpr + threadIdx.x];
+      ts.x += a.x; ts.y += a.y; ts.z += a.z; ts.w += a.w;
+      tq.x += b.x; tq.y += b.y; tq.z += b.z; tq.w += b.w;
+    }
+    float *o = part + static_cast<long long>(blockIdx.x) * 2 * C;
+    *reinterpret_cast<float4 *>(o + 4 * threadIdx.x) = ts;
+    *reinterpret_cast<float4 *>(o + C + 4 * threadIdx.x) = tq;
+  }
+}
+
+// Column-wise combination of the per-workgroup partials: 16 lanes share one channel (each sums every
+// 16th partial in double, then a 4-step xor shuffle), so the serial chain is nparts/16 long instead of
+// nparts -- these finalize kernels sit on the critical path of 70 tiny launches per step.
+__device__ __forceinline__ void combine_partials(const float *__restrict__ part, int nparts, int C, int c,
+                                                 int sub16, double &s, double &q) {
+  s = 0.0;
+  q = 0.0;
+  if (c < C) {
+    for (int p = sub16; p < nparts; p += 16) {
+      s += part[static_cast<long long>(p) * 2 * C + c];
+      q += part[static_cast<long long>(p) * 2 * C + C + c];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+}
+
+// mean / invstd from the partials + running-statistics update
+// (momentum form of nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance for running_var)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nparts, long long R,
+                                                          int C, float eps, float momentum,
+                                                          float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ mean,
+                                                          float *__restrict__ invstd) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub16 = threadIdx.x & 15;
+  double s, q;
+  combine_partials(part, nparts, C, c, sub16, s, q);
+  if (c >= C || sub16 != 0) return;
+  const double m = s / static_cast<double>(R);
+  double var = q / static_cast<double>(R) - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = static_cast<float>(m);
+  invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  if (running_mean) {
+    const double unbiased = R > 1 ? var * static_cast<double>(R) / static_cast<double>(R - 1) : var;
+    running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// y = ((x [+ addend]) - mean) * invstd * gamma + beta, optional ReLU
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ addend,
+                                                            const float *__restrict__ mean,
+                                                            const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta, long long total4,
+                                                            int C4, int relu, float *__restrict__ y) {
+  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total4;
+       e += static_cast<long long>(gridDim.x) * kThreads) {
+    const int cq = static_cast<int>(e % C4);
+    float4 v = ld4(x + 4 * e);
+    if (addend) {
+      const float4 a = ld4(addend + 4 * e);
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    const float4 m = ld4(mean + 4 * cq), is = ld4(invstd + 4 * cq), ga = ld4(gamma + 4 * cq), be = ld4(beta + 4 * cq);
+    float4 o = make_float4((v.x - m.x) * is.x * ga.x + be.x, (v.y - m.y) * is.y * ga.y + be.y,
+                           (v.z - m.z) * is.z * ga.z + be.z, (v.w - m.w) * is.w * ga.w + be.w);
+    if (relu) {
+      o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+    }
+    *reinterpret_cast<float4 *>(y + 4 * e) = o;
+  }
+}
+
+// backward column sums: dbeta = sum dy', dgamma = sum dy' * xhat, with dy' = dy * (y > 0) when relu
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+    const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+    const float *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
+    long long R, int C, long long rows_per_blk, float *__restrict__ part) {
+  __shared__ float4 red[2][kThreads];
+  const Geo g = geo(C);
+  const int sub = threadIdx.x / g.lpr, cq = threadIdx.x - sub * g.lpr;
+  const bool active = sub < g.rpi;
+  const long long r0 = blockIdx.x * rows_per_blk;
+  const long long r1 = min(R, r0 + rows_per_blk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+  if (active) {
+    const float4 m = ld4(mean + 4 * cq), is = ld4(invstd + 4 * cq);
+    for (long long r = r0 + sub; r < r1; r += g.rpi) {
+      float4 d = ld4(dy + r * C + 4 * cq);
+      if (y) {
+        const float4 yv = ld4(y + r * C + 4 * cq);
+        d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+        d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+      }
+      float4 v = ld4(x + r * C + 4 * cq);
+      if (addend) {
+        const float4 a = ld4(addend + r * C + 4 * cq);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+      q.x += d.x * (v.x - m.x) * is.x; q.y += d.y * (v.y - m.y) * is.y;
+      q.z += d.z * (v.z - m.z) * is.z; q.w += d.w * (v.w - m.w) * is.w;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < g.lpr) {
+    float4 ts = red[0][threadIdx.x], tq = red[1][threadIdx.x];
+    for (int u = 1; u < g.rpi; ++u) {
+      const float4 a = red[0][u * g.lpr + threadIdx.x], b = red[1][u * g.lpr + threadIdx.x];
+      ts.x += a.x; ts.y += a.y; ts.z += a.z; ts.w += a.w;
+      tq.x += b.x; tq.y += b.y; tq.z += b.z; tq.w += b.w;
+    }
+    float *o = part + static_cast<long long>(blockIdx.x) * 2 * C;
+    *reinterpret_cast<float4 *>(o + 4 * threadIdx.x) = ts;
+    *reinterpret_cast<float4 *>(o + C + 4 * threadIdx.x) = tq;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nparts, int C,
+                                                              float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub16 = threadIdx.x & 15;
+  double s, q;
+  combine_partials(part, nparts, C, c, sub16, s, q);
+  if (c >= C || sub16 != 0) return;
+  dbeta[c] = static_cast<float>(s);
+  dgamma[c] = static_cast<float>(q);
+}
+
+// dx = gamma * invstd * (dy' - dbeta/R - xhat * dgamma/R)   (training)
+// dx = gamma * invstd * dy'                                   (eval: statistics are constants)
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+    const float *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ gamma, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+    long long total4, int C4, float inv_r, int training, float *__restrict__ dx) {
+  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total4;
+       e += static_cast<long long>(gridDim.x) * kThreads) {
+    const int cq = static_cast<int>(e % C4);
+    float4 d = ld4(dy + 4 * e);
+    if (y) {
+      const float4 yv = ld4(y + 4 * e);
+      d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+      d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+    }
+    const float4 is = ld4(invstd + 4 * cq), ga = ld4(gamma + 4 * cq);
+    float4 o;
+    if (training) {
+      float4 v = ld4(x + 4 * e);
+      if (addend) {
+        const float4 a = ld4(addend + 4 * e);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      const float4 m = ld4(mean + 4 * cq), dg = ld4(dgamma + 4 * cq), db = ld4(dbeta + 4 * cq);
+      o = make_float4(ga.x * is.x * (d.x - db.x * inv_r - (v.x - m.x) * is.x * dg.x * inv_r),
+                      ga.y * is.y * (d.y - db.y * inv_r - (v.y - m.y) * is.y * dg.y * inv_r),
+                      ga.z * is.z * (d.z - db.z * inv_r - (v.z - m.z) * is.z * dg.z * inv_r),
+                      ga.w * is.w * (d.w - db.w * inv_r - (v.w - m.w) * is.w * dg.w * inv_r));
+    } else {
+      o = make_float4(ga.x * is.x * d.x, ga.y * is.y * d.y, ga.z * is.z * d.z, ga.w * is.w * d.w);
+    }
+    *reinterpret_cast<float4 *>(dx + 4 * e) = o;
+  }
+}
+
+struct Plan {
+  int parts;
+  long long rows_per_blk;
+};
+inline Plan plan(long long R, int C) {
+  const int rpi = kThreads / (C >> 2);
+  long long rows = (R + kMaxParts - 1) / kMaxParts;
+  const long long min_rows = 8LL * rpi;
+  if (rows < min_rows) rows = min_rows;
+  rows = (rows + rpi - 1) / rpi * rpi;
+  Plan p;
+  p.rows_per_blk = rows;
+  p.parts = static_cast<int>((R + rows - 1) / rows);
+  return p;
+}
+inline int ew_grid(long long total4) {
+  long long g = (total4 + kThreads - 1) / kThreads;
+  if (g > 2048) g = 2048;
+  return static_cast<int>(g < 1 ? 1 : g);
+}
+inline bool c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 1024; }
+
+}  // namespace
+
+extern "C" {
+
+size_t nsdp_bn_workspace_bytes(int C) { return static_cast<size_t>(kMaxParts) * 2 * C * sizeof(float); }
+
+int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
+                  float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
+                  void *stream) {
+  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_stats: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
+  NSDP_REQUIRE(x && mean && invstd && workspace, "bn_stats: null pointer");
+  NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats go together");
+  hipStream_t st = nsdp::as_stream(stream);
+  const Plan p = plan(R, C);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, 4.0 * R * C * (addend ? 2 : 1));
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk,
+                     workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, R, C, eps,
+                     momentum, running_mean, running_var, mean, invstd);
+  return nsdp::launch_status("bn_stats_kernel");
+}
+
+int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
+                  const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream) {
+  if (R <= 0) return 0;
+  NSDP_REQUIRE(c_ok(C), "bn_apply: C=%d must be a multiple of 4, <= 1024", C);
+  NSDP_REQUIRE(x && mean && invstd && gamma && beta && y, "bn_apply: null pointer");
+  hipStream_t st = nsdp::as_stream(stream);
+  const long long total4 = R * (C >> 2);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, 4.0 * R * C * (addend ? 3 : 2));
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(kThreads), 0, st, x, addend, mean, invstd, gamma,
+                     beta, total4, C >> 2, relu, y);
+  return nsdp::launch_status("bn_apply_kernel");
+}
+
+int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const float *addend,
+                     const float *mean, const float *invstd, const float *gamma, long long R, int C,
+                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, void *stream) {
+  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_backward: need R > 0 and C %% 4 == 0, C <= 1024");
+  NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
+               "bn_backward: null pointer");
+  hipStream_t st = nsdp::as_stream(stream);
+  const Plan p = plan(R, C);
+  const long long total4 = R * (C >> 2);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
+                          4.0 * R * C * (5.0 + (y_relu ? 2 : 0) + (addend ? 2 : 0)));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.parts), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
+                     invstd, R, C, p.rows_per_blk, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, C, dgamma,
+                     dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
+                     invstd, gamma, dgamma, dbeta, total4, C >> 2, 1.0f / static_cast<float>(R), training, dx);
+  return nsdp::launch_status("bn_backward");
+}
+
+}  // extern "C"

@@ -1,0 +1,80 @@
+"""BatchNorm1d on channels-last rows with the fused residual-add prologue and ReLU epilogue
+(csrc/batchnorm.hip).  Semantics of nn.BatchNorm1d (momentum update, biased variance for normalisation,
+unbiased for running_var, eval mode on running statistics)."""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
+
+_ll = ctypes.c_longlong
+_ci = ctypes.c_int
+_cf = ctypes.c_float
+
+
+def _ws(C, device):
+    L = lib()
+    L.nsdp_bn_workspace_bytes.restype = ctypes.c_size_t
+    return torch.empty(int(L.nsdp_bn_workspace_bytes(_ci(C))) // 4, dtype=torch.float32, device=device)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.reshape(-1, C)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        a2 = None
+        if addend is not None:
+            a2 = addend.reshape(-1, C)
+            a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        R = x2.shape[0]
+        dev = x2.device
+        with on_device(x2):
+            if training:
+                mean = torch.empty(C, dtype=torch.float32, device=dev)
+                invstd = torch.empty(C, dtype=torch.float32, device=dev)
+                check(lib().nsdp_bn_stats(fptr(x2, "x"), optptr(a2), _ll(R), _ci(C), _cf(eps), _cf(momentum),
+                                          optptr(running_mean), optptr(running_var), fptr(mean), fptr(invstd),
+                                          fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_stats")
+            else:
+                mean = running_mean
+                invstd = torch.rsqrt(running_var + eps)
+            y = torch.empty_like(x2)
+            check(lib().nsdp_bn_apply(fptr(x2), optptr(a2), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
+                                      fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), fptr(y), stream_ptr()),
+                  "nsdp_bn_apply")
+        ctx.save_for_backward(x2, a2, gamma, mean, invstd, y if relu else None)
+        ctx.training, ctx.shape, ctx.has_addend = bool(training), shape, addend is not None
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, a2, gamma, mean, invstd, y = ctx.saved_tensors
+        R, C = x2.shape
+        dy2 = dy.reshape(R, C)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dev = dy2.device
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        with on_device(dy2):
+            check(lib().nsdp_bn_backward(fptr(dy2, "dy"), optptr(y), fptr(x2), optptr(a2), fptr(mean), fptr(invstd),
+                                         fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), fptr(dx), fptr(dgamma),
+                                         fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
+        dx = dx.reshape(ctx.shape)
+        return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None
+
+
+def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
+    """relu?( BN(x + addend) ) with bn's parameters / running statistics / mode."""
+    training = bn.training or not bn.track_running_stats
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps),
+                              bool(relu))

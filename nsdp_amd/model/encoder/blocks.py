@@ -64,9 +64,9 @@ class ElementwiseMLP(nn.Module):
         self.bn3 = nn.BatchNorm1d(dim)
 
     def forward(self, x):
-        h = torch.relu(ops.batch_norm(ops.linear(x, self.conv1), self.bn1))
-        h = torch.relu(ops.batch_norm(ops.linear(h, self.conv2), self.bn2))
-        return ops.batch_norm(x + h, self.bn3)
+        h = ops.batch_norm(ops.linear(x, self.conv1), self.bn1, relu=True)
+        h = ops.batch_norm(ops.linear(h, self.conv2), self.bn2, relu=True)
+        return ops.batch_norm(x, self.bn3, addend=h)                      # bn3(x + h), add fused
 
 
 class TransformerSetAbstraction(nn.Module):
@@ -113,8 +113,8 @@ class TransformerSetAbstraction(nn.Module):
         res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2), ops.linear(points, self.w_vs2), idx,
                                         None, self.fc_gamma2, residual=res1, pos=pos)
 
-        new_points = ops.batch_norm(res12, self.bnorm1) + ops.index_points(points, fps_idx)
-        return new_xyz, ops.batch_norm(new_points, self.bnorm2)
+        new_points = ops.batch_norm(res12, self.bnorm1)
+        return new_xyz, ops.batch_norm(new_points, self.bnorm2, addend=ops.index_points(points, fps_idx))
 
 
 class TransitionDown(nn.Module):

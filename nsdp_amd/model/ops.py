@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip_attention, hip_linear
+from .. import hip_attention, hip_batchnorm, hip_linear
 from .. import pointnet2_utils as pu
 
 
@@ -65,14 +65,11 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
     return linear(linear(x, seq[0], relu=True), seq[2])
 
 
-def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d) -> torch.Tensor:
-    """BatchNorm1d over (B*n) rows per channel; batch statistics + running update when training."""
-    shape = x.shape
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
-    y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                     bn.training, bn.momentum, bn.eps)
-    return y.reshape(shape)
+def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = False) -> torch.Tensor:
+    """relu?( BatchNorm1d(x + addend) ) over the (B*n) rows of a channels-last tensor: batch statistics +
+    running update when training, running statistics in eval.  The residual add in front and the ReLU
+    behind are fused into the HIP kernels (hip_batchnorm)."""
+    return hip_batchnorm.batch_norm(x, bn, addend=addend, relu=relu)
 
 
 # ---------------------------------------------------------------------------------------------

