@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="shapes per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="forward_train",
+                    choices=["forward_train", "arbitrary_train", "dense_inference"],
+                    help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3 shape, "
+                         "fp32) | dense_inference (BASELINE config 5: eval, 100k queries per shape)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
     args = ap.parse_args()
@@ -104,15 +108,30 @@ def main():
     from nsdp_amd.model.utils import compute_l2_error
 
     cfg = model_config()
+    n_query = N_QUERY
+    if args.workload == "arbitrary_train":
+        cfg["model"]["type"] = "arbitrary"
+    elif args.workload == "dense_inference":
+        n_query = 100000
     model, _train_on_batch, _, _ = build_model(cfg, device="cpu")
     state = synth.procedural_state_dict(model.state_dict(), 2048)  # identical weights on every rank
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-    model.to(device).train()
+    model.to(device).train(args.workload != "dense_inference")
     _, optimizer = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
                                       "weight_decay": 0.0}, model.parameters())
     reducer = GradAllReducer(model, world) if (world > 1 or args.force_reducer) else None
     data = {k: torch.from_numpy(v).to(device)
-            for k, v in synth.make_batch(1000 + rank, args.batch, N_SURF, N_QUERY).items()}
+            for k, v in synth.make_batch(1000 + rank, args.batch, N_SURF, n_query).items()}
+
+    def forward():
+        if args.workload == "arbitrary_train":
+            s_in = data["surface_samples_inputs"]
+            return model(data["space_samples_src"], s_in[:, :, 0:3], s_in[:, :, 3:6], s_in[:, :, 6:7])
+        return model(data["space_samples_src"], data["surface_samples_inputs"])
+
+    def infer_step():
+        with torch.no_grad():
+            return forward().sum()
 
     def step():
         # train_on_batch_with_cano (reference model/deformation_networks.py:63-77); the loss scalar is
@@ -121,7 +140,7 @@ def main():
             reducer.zero_grad()
         else:
             optimizer.zero_grad(set_to_none=True)
-        pred = model(data["space_samples_src"], data["surface_samples_inputs"])
+        pred = forward()
         loss = compute_l2_error(pred, data["space_samples_tgt"])
         loss.backward()
         if reducer is not None:
@@ -134,13 +153,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = infer_step if args.workload == "dense_inference" else step
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     profiling.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     elapsed = time.perf_counter() - t0
     prof = profiling.stop()
@@ -151,26 +171,33 @@ def main():
     final_loss = float(loss.item())
 
     if rank == 0:
-        total_q = world * args.batch * N_QUERY * args.steps
+        total_q = world * args.batch * n_query * args.steps
         value = total_q / elapsed
+        names = {"forward_train": ("query-points/sec fwd+bwd (2048 surf pts, 8192 queries)",
+                                   "forward.yaml TDNet train step (fwd + l2 loss + bwd + Adam)"),
+                 "arbitrary_train": ("query-points/sec fwd+bwd, FlowArbitrary (2048 surf pts, 8192 queries)",
+                                     "arbitrary.yaml FlowArbitrary train step (two TDNets, fwd + l2 loss + bwd + Adam)"),
+                 "dense_inference": ("query-points/sec forward (2048 surf pts, 100000 queries)",
+                                     "forward.yaml TDNet eval forward, dense per-vertex decode")}[args.workload]
         line = {
-            "metric": "query-points/sec fwd+bwd (2048 surf pts, 8192 queries)",
+            "metric": names[0],
             "value": round(value, 1), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "forward.yaml TDNet train step (fwd + l2 loss + bwd + Adam), "
-                                   f"{args.batch} shapes/GPU, {N_SURF} surface + {N_QUERY} query points per shape, "
+            "config": {"workload": f"{names[1]}, "
+                                   f"{args.batch} shapes/GPU, {N_SURF} surface + {n_query} query points per shape, "
                                    "fp32, procedural random-init weights",
-                       "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": N_QUERY,
+                       "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1),
-            "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2),
+            "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2) if args.workload == "forward_train" else None,
             "final_loss": round(final_loss, 6),
             "roofline": profiling.roofline(prof),
             "kernels": profiling.summary(prof),
         }
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.workload != "forward_train") \
+            else cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
