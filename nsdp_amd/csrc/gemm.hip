@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   const long long row0 = (static_cast<long long>(blockIdx.x) * 4 + wave) * (MT * 16);
   if (row0 >= p.M) return;  // whole wave out of range (no barriers in this kernel)
   const int K = p.K, N = p.N;
+  const int ntile0 = blockIdx.y * NT;  // column-tile offset (grid.y > 1 only for the small-M split-N launch)
 
   f32x4 acc[MT][NT];
   if (p.residual) {  // residual add fused as the accumulator's initial value (loads overlap the k loop)
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        int col = nt * 16 + li;
+        int col = (ntile0 + nt) * 16 + li;
         col = col < N ? col : (N - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   const float *wb[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int n = nt * 16 + li;
+    int n = (ntile0 + nt) * 16 + li;
     n = n < N ? n : (N - 1);
     wb[nt] = p.W + static_cast<long long>(n) * K;
   }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   // (N % 16 != 0) and the last row block of the matrix take the predicated form.
   const bool full_rows = row0 + MT * 16 <= p.M;
   auto tile = [&](int nt, auto has_omask, auto guarded) {
-    const int col = nt * 16 + li;
+    const int col = (ntile0 + nt) * 16 + li;
     const bool cv = col < N;
     const int colc = cv ? col : (N - 1);
     const float bv = p.bias ? p.bias[colc] : 0.f;
@@ -231,13 +232,13 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
     if (full_rows && p.dbg != 1) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        if (nt < full_tiles) tile(nt, has_omask, std::false_type{});
-        else if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
+        if (ntile0 + nt < full_tiles) tile(nt, has_omask, std::false_type{});
+        else if ((ntile0 + nt) * 16 < N) tile(nt, has_omask, std::true_type{});
       }
     } else {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        if (nt * 16 < N) tile(nt, has_omask, std::true_type{});
+        if ((ntile0 + nt) * 16 < N) tile(nt, has_omask, std::true_type{});
     }
   };
   if (p.out_mask) epilogue(std::true_type{});
@@ -427,14 +428,14 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 }
 
 template <int MT, int NT>
-int launch_nt(const LinearParams &p, hipStream_t st) {
+int launch_nt(const LinearParams &p, hipStream_t st, int grid_y = 1) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   const long long rows_per_wg = 4LL * MT * 16;
   const long long grid = (p.M + rows_per_wg - 1) / rows_per_wg;
   nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
-  const dim3 gr(static_cast<unsigned>(grid));
-  if (g_nt_pipe == 2) {
+  const dim3 gr(static_cast<unsigned>(grid), grid_y);
+  if (g_nt_pipe == 2 && grid_y == 1) {
     if (pre == 0) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 0>), gr, dim3(256), 0, st, p);
     else if (pre == 1) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 1>), gr, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 2>), gr, dim3(256), 0, st, p);
@@ -781,6 +782,9 @@ int nsdp_linear_f32(const float *X, const float *W, const float *bias, const flo
   LinearParams p{X, W, bias, residual, mask, out_mask, Y, g_nt_dbg, M, N, K, relu_in, relu_out};
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
+  // small M (per-point layers at the 500/100-anchor levels): one 16-row tile x 4 column tiles per wave and
+  // the column tiles spread over grid.y, so that a few thousand rows still fill the chip
+  if (M <= 32768 && nt > 4 && g_nt_pipe != 2) return launch_nt<1, 4>(p, st, (nt + 3) / 4);
   if (nt <= 1) return launch_nt<4, 1>(p, st);
   if (nt <= 4) return launch_nt<4, 4>(p, st);
   if (nt <= 8) return launch_nt<4, 8>(p, st);
