@@ -85,6 +85,8 @@ def main():
                     choices=["forward_train", "arbitrary_train", "dense_inference"],
                     help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3 shape, "
                          "fp32) | dense_inference (BASELINE config 5: eval, 100k queries per shape)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole train step (fwd + bwd + Adam) in one hipGraph and replay it")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
     args = ap.parse_args()
@@ -154,6 +156,24 @@ def main():
         torch.cuda.synchronize()
 
     run = infer_step if args.workload == "dense_inference" else step
+    graph = None
+    if args.graph and args.workload != "dense_inference" and world == 1:
+        # whole-step capture: every kernel of the step (HIP library launches on the current stream, Adam's
+        # foreach kernels) goes into one hipGraph; needs a capturable optimizer and static input buffers
+        for g in optimizer.param_groups:
+            g["capturable"] = True
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = step()
+        run = lambda: (graph.replay(), static_loss)[1]
     for _ in range(args.warmup):
         run()
     fence()

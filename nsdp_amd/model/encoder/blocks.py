@@ -35,9 +35,12 @@ class TransformerBlock(nn.Module):
         self.k = k
         self.group_all = group_all
 
-    def forward(self, xyz, feats=None):
+    def forward(self, xyz, feats=None, idx=None):
+        """``idx`` [B,n,k] int32: precomputed neighbour indices (geometry pyramid); computed here if None."""
         B, n, _ = xyz.shape
-        if self.group_all:
+        if idx is not None:
+            pass
+        elif self.group_all:
             idx = torch.arange(n, device=xyz.device, dtype=torch.int32).view(1, 1, n).expand(B, n, n).contiguous()
         else:
             idx = ops.knn_indices(xyz, xyz, self.k)
@@ -93,10 +96,14 @@ class TransformerSetAbstraction(nn.Module):
         self.w_ks2 = nn.Linear(dim, dim, bias=False)
         self.w_vs2 = nn.Linear(dim, dim, bias=False)
 
-    def forward(self, xyz, points):
-        fps_idx = ops.fps_indices(xyz, self.npoint)                       # [B, npoint] int32
-        new_xyz = ops.index_points(xyz.detach(), fps_idx)                 # detached centres (no_grad in ref)
-        idx = ops.knn_indices(new_xyz, xyz, self.nneigh)                  # [B, npoint, k]
+    def forward(self, xyz, points, geo=None):
+        """``geo``: precomputed {fps_idx, new_xyz, sa_idx} of this level (geometry pyramid), else computed here."""
+        if geo is not None:
+            fps_idx, new_xyz, idx = geo["fps_idx"], geo["new_xyz"], geo["sa_idx"]
+        else:
+            fps_idx = ops.fps_indices(xyz, self.npoint)                   # [B, npoint] int32
+            new_xyz = ops.index_points(xyz.detach(), fps_idx)             # detached centres (no_grad in ref)
+            idx = ops.knn_indices(new_xyz, xyz, self.nneigh)              # [B, npoint, k]
         rel = ops.index_points(xyz, idx) - new_xyz.unsqueeze(2)           # xyz_j - c  (sign opposite to PTB)
 
         # the reference projects all N points with w_qs and then gathers the centres; gathering first
@@ -131,5 +138,5 @@ class TransitionDown(nn.Module):
         else:
             raise ValueError("Set Abstraction type " + type + " unknown!")
 
-    def forward(self, xyz, feats):
-        return self.sa(xyz, feats)
+    def forward(self, xyz, feats, geo=None):
+        return self.sa(xyz, feats, geo) if geo is not None else self.sa(xyz, feats)

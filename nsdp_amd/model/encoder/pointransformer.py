@@ -41,16 +41,23 @@ class PointTransformerEncoder(nn.Module):
             [ElementwiseMLP(dim=d_transformer) for _ in range(nfinal_transformers)])
 
     def forward(self, xyz):
+        coords = xyz[:, :, :3].contiguous() if self.has_features else xyz
+        # all FPS / kNN index tensors of the pyramid, launched on a side stream under transformer_begin
+        levels, join = ops.geometry_pyramid(
+            coords, [td.sa.npoint for td in self.transition_downs],
+            [(td.sa.nneigh, None if tb.group_all else tb.k)
+             for td, tb in zip(self.transition_downs, self.transformer_downs)])
         if self.has_features:
             feats = ops.linear(xyz[:, :, 3:], self.enc_sdf)
-            xyz = xyz[:, :, :3].contiguous()
+            xyz = coords
             feats = self.transformer_begin(xyz, feats)
         else:
             feats = self.transformer_begin(xyz)
+        join()
         for i in range(len(self.transition_downs)):
-            xyz, feats = self.transition_downs[i](xyz, feats)
+            xyz, feats = self.transition_downs[i](xyz, feats, levels[i])
             feats = self.elementwise_extras[i](feats)
-            feats = self.transformer_downs[i](xyz, feats)
+            feats = self.transformer_downs[i](xyz, feats, idx=levels[i]["blk_idx"])
             if i == 0 and self.d_reduced != self.d_transformer:
                 feats = ops.linear(feats, self.fc1)
             feats = self.elementwise[i](feats)

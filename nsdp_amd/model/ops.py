@@ -27,6 +27,53 @@ def fps_indices(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     return pu.furthest_point_sample(xyz.detach().contiguous(), npoint)
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
+@torch.no_grad()
+def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
+    """Every index tensor of the encoder's down-sampling pyramid depends on coordinates only:
+    FPS level 1 -> centres -> FPS level 2 -> centres, and the kNN sets of the set abstractions and of the
+    local attention blocks at each level.  They are produced here in one go on a SIDE STREAM, so the ~600
+    dependent FPS iterations and the kNN scans run underneath the first attention block's dense layers
+    instead of in front of every later block (the reference serialises them, model/encoder/blocks.py:283-288).
+
+    xyz [B,N,3]; npoints = [n1, n2, ...]; ks = [(k_sa, k_block), ...] per level.
+    Returns a list of dicts {fps_idx, new_xyz, sa_idx, blk_idx} and the event-free join handle (call
+    ``join()`` on the consumer stream before the first use)."""
+    main = torch.cuda.current_stream(xyz.device)
+    side = _side_stream(xyz.device) if overlap else main
+    if overlap:
+        side.wait_stream(main)
+    levels = []
+    with torch.cuda.stream(side):
+        cur = xyz.detach().contiguous()
+        for n_new, (k_sa, k_blk) in zip(npoints, ks):
+            fps_idx = pu.furthest_point_sample(cur, n_new)
+            new_xyz = pu.gather_rows(cur, fps_idx)
+            sa_idx = pu.knn(new_xyz, cur, k_sa)
+            blk_idx = pu.knn(new_xyz, new_xyz, k_blk) if k_blk is not None else None
+            levels.append({"fps_idx": fps_idx, "new_xyz": new_xyz, "sa_idx": sa_idx, "blk_idx": blk_idx})
+            cur = new_xyz
+
+    def join():
+        if overlap:
+            torch.cuda.current_stream(xyz.device).wait_stream(side)
+            for lv in levels:
+                for t in lv.values():
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream(xyz.device))
+
+    return levels, join
+
+
 class _GatherRows(torch.autograd.Function):
     """index_points (model/utils.py:58-70) for idx [B,S] or [B,S,K]; backward = scatter-add."""
 
