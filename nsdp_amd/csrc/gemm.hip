@@ -621,14 +621,19 @@ int g_wgrad_pipe = 0;  // measured on MI355X: the register-lean form wins at eve
 // t' is k = 64*kg + 4*j + t'.
 // Waves: waves_n = ceil(N/64) of them split the columns; the remaining factor row_split = 4/waves_n
 // splits the chunk's 16-row blocks, each row split writing its own partial slot.
-template <int TK4>
-__global__ __launch_bounds__(256) void linear_wgrad4_kernel(WgradParams p, int waves_n) {
+template <int TK4, int THREADS>
+__global__ __launch_bounds__(THREADS) void linear_wgrad4_kernel(WgradParams p, int waves_n, int kparts) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int N = p.N, K = p.K;
-  const int row_split = 4 / waves_n;
-  const int ng = wave % waves_n, rs = wave / waves_n;
-  const int kg0 = blockIdx.y * TK4;
+  // waves = waves_n (column groups of dY) x kparts (column halves of X) x row_split (16-row blocks): the k
+  // halves live in the SAME workgroup, so the dY rows they both need come from L1/L2 once instead of
+  // being fetched from HBM by two different workgroups
+  const int row_split = (THREADS / 64) / (waves_n * kparts);
+  const int ng = wave % waves_n;
+  const int kh = (wave / waves_n) % kparts;
+  const int rs = wave / (waves_n * kparts);
+  const int kg0 = kh * TK4;
   const long long m_begin = static_cast<long long>(blockIdx.x) * p.rows_per_chunk;
   const long long m_end = min(p.M, m_begin + p.rows_per_chunk);
 
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(256) void linear_wgrad4_kernel(WgradParams p, int w
       }
     }
   }
-  if (p.want_db && blockIdx.y == 0) {
+  if (p.want_db && kh == 0) {
     // lane (li, g) holds the column sums of columns 64*ng + 4*li + {0..3} over its rows (4g+s): fold the 4 g groups
     float v[4] = {dbsum.x, dbsum.y, dbsum.z, dbsum.w};
 #pragma unroll
@@ -801,7 +806,7 @@ struct WgradPlan {
   long long chunks, rows, slots;  // slots = partial buffers written (chunks x row splits)
   int grid_y;
   bool vec4;
-  int tk4, waves_n;
+  int tk4, waves_n, kparts, threads;
 };
 WgradPlan plan_wgrad(long long M, int N, int K) {
   const int ktiles = (K + 15) / 16;
@@ -811,9 +816,11 @@ WgradPlan plan_wgrad(long long M, int N, int K) {
   if (pl.vec4) {
     const int kgroups = (K + 63) / 64;
     pl.tk4 = kgroups >= 2 ? 2 : 1;
-    pl.grid_y = (kgroups + pl.tk4 - 1) / pl.tk4;
+    pl.kparts = (kgroups + pl.tk4 - 1) / pl.tk4;         // 1 or 2 (K <= 256)
+    pl.grid_y = 1;
     pl.waves_n = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
-    slots_per_chunk = 4 / pl.waves_n;
+    pl.threads = pl.waves_n * pl.kparts > 4 ? 512 : 256;
+    slots_per_chunk = (pl.threads / 64) / (pl.waves_n * pl.kparts);
   } else {
     const int wn = N <= 64 ? 1 : (N <= 128 ? 2 : 4);
     const int max_tk = 32 / wn > 16 ? 16 : 32 / wn;
@@ -826,8 +833,10 @@ WgradPlan plan_wgrad(long long M, int N, int K) {
     pl.grid_y = (ktiles + tk - 1) / tk;
     pl.tk4 = 0;
     pl.waves_n = 0;
+    pl.kparts = 1;
+    pl.threads = 256;
   }
-  long long max_chunks = 512 / pl.grid_y;
+  long long max_chunks = (pl.vec4 && pl.threads == 512) ? 256 : 512 / pl.grid_y;
   // the partial buffers cost 2 * slots * N*K*4 bytes of extra traffic (write + reduce-read): keep that
   // below ~1/4 of the operand traffic M*(N+K)*4, i.e. slots <= M*(N+K) / (8*N*K)
   const long long traffic_cap = (M * static_cast<long long>(N + K)) / (8LL * N * K) / slots_per_chunk;
@@ -880,9 +889,13 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
                             4.0 * (static_cast<double>(M) * (K + N)));
     const unsigned gx = static_cast<unsigned>(chunks);
     if (pl.vec4) {
-      const dim3 grid(gx, pl.grid_y);
-      if (pl.tk4 == 2) hipLaunchKernelGGL((linear_wgrad4_kernel<2>), grid, dim3(256), 0, st, p, pl.waves_n);
-      else hipLaunchKernelGGL((linear_wgrad4_kernel<1>), grid, dim3(256), 0, st, p, pl.waves_n);
+      const dim3 grid(gx, 1);
+      if (pl.threads == 512)
+        hipLaunchKernelGGL((linear_wgrad4_kernel<2, 512>), grid, dim3(512), 0, st, p, pl.waves_n, pl.kparts);
+      else if (pl.tk4 == 2)
+        hipLaunchKernelGGL((linear_wgrad4_kernel<2, 256>), grid, dim3(256), 0, st, p, pl.waves_n, pl.kparts);
+      else
+        hipLaunchKernelGGL((linear_wgrad4_kernel<1, 256>), grid, dim3(256), 0, st, p, pl.waves_n, pl.kparts);
     } else if (N <= 64) dispatch_wgrad_k<1>(p, gx, ktiles, st);
     else if (N <= 128) dispatch_wgrad_k<2>(p, gx, ktiles, st);
     else dispatch_wgrad_k<4>(p, gx, ktiles, st);
