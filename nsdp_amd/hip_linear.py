@@ -8,6 +8,7 @@ the split-row dW = dY'^T X with the bias gradient as a by-product).  No torch/ro
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 import torch.nn.functional as F
@@ -45,6 +46,77 @@ def _wgrad(dy2, x2, mask, relu_x, want_db):
     return dw, db
 
 
+# ------------------------------------------------------------------------------------------------
+# weight gradients on a side stream
+# ------------------------------------------------------------------------------------------------
+# dW/db of a layer are needed only by the optimizer, dX is on the critical path of the backward chain.
+# When the layer's parameters are known (`params=` of linear(), i.e. the nn.Module call sites), the wgrad
+# kernels are launched on a second HIP stream and their results are accumulated there into a per-parameter
+# pending buffer; autograd gets no gradient for the weights from this Function.  A callback queued on the
+# autograd engine runs when the backward pass has finished: it makes the main stream wait for the side
+# stream and only then publishes the buffers to `param.grad` (assign, or `+=` into an existing `.grad` such
+# as the data-parallel flat-bucket views).  So nothing on the main stream can observe an unfinished weight
+# gradient, and `.grad` is complete when `backward()` returns -- while the wgrad GEMMs overlap the
+# (often HBM-bound) attention glue and the dX GEMMs of later layers.
+# Without `params` (functional use, torch.autograd.grad on raw tensors) everything runs on the main stream.
+_OVERLAP_WGRAD = os.environ.get("NSDP_WGRAD_STREAM", "1") != "0"
+_side = {}
+_pending = {}          # device index -> {id(param): [param, grad tensor living on the side stream]}
+
+
+def _side_stream(device):
+    key = device.index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def _publish(device):
+    """End-of-backward callback: join the streams, then hand the pending gradients to the parameters."""
+    main = torch.cuda.current_stream(device)
+    main.wait_stream(_side_stream(device))
+    todo = _pending.pop(device.index, {})
+    with torch.no_grad():
+        for param, g in todo.values():
+            g.record_stream(main)
+            if param.grad is None:
+                param.grad = g
+            else:
+                param.grad.add_(g)
+
+
+def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig):
+    dw, db = _wgrad(dy2, x2, mask, relu_x, want_db)
+    if dw.shape[1] != k_orig:          # zero-padded reduction dimension (K = 3)
+        dw = dw[:, :k_orig].contiguous()
+    return dw, db
+
+
+def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param):
+    dev = dy2.device
+    main = torch.cuda.current_stream(dev)
+    side = _side_stream(dev)
+    side.wait_stream(main)
+    slot = _pending.get(dev.index)
+    if slot is None:
+        slot = _pending[dev.index] = {}
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev))
+    with torch.cuda.stream(side):      # everything that touches dw/db before the join stays on `side`
+        dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig)
+        for param, g in ((w_param, dw), (b_param, db)):
+            if param is None:
+                continue
+            g = g.view_as(param)
+            ent = slot.get(id(param))
+            if ent is None:
+                slot[id(param)] = [param, g]
+            else:
+                ent[1].add_(g)         # parameter used twice in one graph (e.g. fc_gamma in the decoder)
+    for t in (dy2, x2, mask):
+        if t is not None:
+            t.record_stream(side)
+
+
 def _pad_cols(t, mult=4):
     r = (-t.shape[-1]) % mult
     return t if r == 0 else F.pad(t, (0, r))
@@ -52,7 +124,8 @@ def _pad_cols(t, mult=4):
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu_in, relu_out):
+    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None):
+        ctx.w_param, ctx.b_param = w_param, b_param
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
@@ -78,6 +151,18 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dx = dw = db = dres = None
+        if ctx.w_param is not None:
+            if _OVERLAP_WGRAD:
+                _wgrad_deferred(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param)   # side stream
+            else:
+                gw, gb = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.b_param is not None, ctx.k_orig)
+                with torch.no_grad():
+                    for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
+                        if prm is not None:
+                            g = g.view_as(prm)
+                            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         if ctx.needs_input_grad[0]:
             wt = wk.t().contiguous()                      # [K, N]: dX = dY' @ W  ==  dY' @ (W^T)^T
             dyk, mk = dy2, y
@@ -86,17 +171,24 @@ class _LinearFn(torch.autograd.Function):
                 mk = _pad_cols(y) if y is not None else None
             dx = _fwd(dyk, wt, None, None, mk, x2 if ctx.relu_in else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _wgrad(dy2, x2, y, ctx.relu_in, ctx.has_bias)
-            if dw.shape[1] != ctx.k_orig:
-                dw = dw[:, :ctx.k_orig].contiguous()
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None):
-    if weight.dim() == 3:  # 1x1 Conv1d weight [out, in, 1]
-        weight = weight.squeeze(-1)
-    return _LinearFn.apply(x, weight, bias, residual, bool(relu_in), bool(relu_out))
+def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False):
+    """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
+    produced on the side stream and published to ``.grad`` at the end of the backward pass (see above)."""
+    w_param = b_param = None
+    if params and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
+        w_param = weight
+        b_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
+        if bias is not None and b_param is None:
+            w_param = None             # mixed case: keep everything on the plain autograd path
+    w2 = weight.squeeze(-1) if weight.dim() == 3 else weight   # 1x1 Conv1d weight [out, in, 1]
+    if w_param is not None:
+        # the Function sees detached operands for the weights: their gradient does not go through autograd
+        return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
+                               bool(relu_out), w_param, b_param)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out))

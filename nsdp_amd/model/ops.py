@@ -104,7 +104,8 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) )."""
-    return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual)
+    return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
+                             params=True)
 
 
 def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
