@@ -56,11 +56,44 @@ def summary(prof):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def roofline(prof):
-    """Roofline object for the kernel with the largest total time."""
+def roofline(prof, prof_isolated=None):
+    """Roofline object for the kernel with the largest total time in the timed region.  ``achieved`` is
+    measured over the timed region (kernels of other streams may run concurrently); ``isolated`` repeats
+    the figure for the same kernel from a pass without stream overlap, when one was recorded."""
     if not prof:
         return None
     name, v = max(prof.items(), key=lambda kv: kv[1]["ms"])
+    out = _roofline_one(name, v)
+    out.update(_pmc_traffic(name))
+    if prof_isolated and name in prof_isolated:
+        iso = _roofline_one(name, prof_isolated[name])
+        out["isolated"] = {k: iso[k] for k in ("achieved", "frac", "launches", "avg_launch_ms")}
+    return out
+
+
+def _pmc_traffic(name):
+    """HBM bytes per launch of `name` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r1_pmc_hbm.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the file is absent."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            pmc = json.load(f)
+        stem = name.replace("_kernels", "").replace("_kernel", "")
+        fetch = [v for k, v in pmc.get("FETCH_SIZE", {}).items() if k.startswith(stem)]
+        write = [v for k, v in pmc.get("WRITE_SIZE", {}).items() if k.startswith(stem)]
+        n = sum(v[0] for v in fetch)
+        if not n:
+            return {"traffic": None}
+        total = (2.0 * sum(v[1] for v in fetch) + sum(v[1] for v in write)) * 1024.0
+        return {"traffic": round(total / n), "traffic_unit": "bytes/launch (PMC, profiles/r1_pmc_hbm.json)"}
+    except Exception:
+        return {"traffic": None}
+
+
+def _roofline_one(name, v):
     per_launch_ms = v["ms"] / v["launches"]
     flops_per_launch = v["flops"] / v["launches"]
     bytes_per_launch = v["bytes"] / v["launches"]
@@ -69,8 +102,10 @@ def roofline(prof):
         achieved = flops_per_launch / (per_launch_ms * 1e9)
         return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "launches": v["launches"], "avg_launch_ms": round(per_launch_ms, 4)}
+                "algorithmic_bytes": round(bytes_per_launch), "launches": v["launches"],
+                "avg_launch_ms": round(per_launch_ms, 4)}
     achieved = bytes_per_launch / (per_launch_ms * 1e6)
     return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-            "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None, "launches": v["launches"],
+            "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
+            "algorithmic_bytes": round(bytes_per_launch), "launches": v["launches"],
             "avg_launch_ms": round(per_launch_ms, 4)}
