@@ -87,6 +87,8 @@ def main():
                          "fp32) | dense_inference (BASELINE config 5: eval, 100k queries per shape)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole train step (fwd + bwd + Adam) in one hipGraph and replay it")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                    "to exercise the multi-rank code path on a single GPU)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
     args = ap.parse_args()
@@ -98,11 +100,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from nsdp_amd import profiling, synth
     from nsdp_amd.model import build_model, optimizer_factory

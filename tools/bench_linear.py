@@ -15,11 +15,11 @@ for (M, K, N) in [(1835008, 200, 200), (1835008, 208, 208), (655360, 120, 120), 
     dy = torch.randn(M, N, device=dev)
     from nsdp_amd._lib import lib
     t1 = timeit(lambda: _fwd(x, w, b, None, None, None, False, True))
-    lib().nsdp_debug_set(3, 2); t1a = timeit(lambda: _fwd(x, w, b, None, None, None, False, True)); lib().nsdp_debug_set(3, 0); t1b = timeit(lambda: _fwd(x, w, b, None, None, None, False, True)); lib().nsdp_debug_set(3, 1)
+    res = torch.randn(M, N, device=dev); t1a = timeit(lambda: _fwd(x, w, b, res, None, None, False, False)); t1b = timeit(lambda: _fwd(x, w, b, None, x[:, :K] if False else None, res, False, False)); del res
     t2 = timeit(lambda: F.relu(F.linear(x, w, b)))
     from nsdp_amd._lib import lib
     lib().nsdp_debug_set(5, 0); t3 = timeit(lambda: _wgrad(dy, x, None, False, True))
     lib().nsdp_debug_set(5, 1); t3b = timeit(lambda: _wgrad(dy, x, None, False, True))
     t4 = timeit(lambda: (dy.t() @ x, dy.sum(0)))
     fl = 2.0 * M * N * K
-    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF lds {fl/t1a/1e9:.1f} lean {fl/t1b/1e9:.1f} | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | wgrad dword {fl/t3/1e9:.1f} TF vec4 {t3b:.3f} ms {fl/t3b/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
+    print(f"M={M} K={K} N={N}: hip fwd {t1:.3f} ms {fl/t1/1e9:.1f} TF | +residual {fl/t1a/1e9:.1f} | +out_mask {fl/t1b/1e9:.1f} | torch fwd {t2:.3f} ms {fl/t2/1e9:.1f} TF | wgrad dword {fl/t3/1e9:.1f} TF vec4 {t3b:.3f} ms {fl/t3b/1e9:.1f} TF | torch wgrad {t4:.3f} ms {fl/t4/1e9:.1f} TF")
