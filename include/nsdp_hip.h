@@ -152,6 +152,24 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        float *da, float *dpos, float *dvf, float *da_g, float *dv_g, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Fused cross-attention decoder forward (no-grad / inference path): CrossTransformerDecoder.forward,
+ * model/decoder/crosstransformer_decoder.py:45-70 + model/decoder/blocks.py:48-95, for dim = 200,
+ * hidden_dim = 128, n_blocks = 5, out_dim = 3.  One wave carries 16 query points through all 18 dense
+ * layers in registers (transposed fp32 MFMA chain).  Inputs, all zero-padded to 208 / 128 channels:
+ *   xyz_q (B,NQ,3), anchors (B,A,3), idx (B,NQ,KN) i32 nearest anchors,
+ *   qk (B,A,208) = w_qs(z) - w_ks(anchor_feats), vtab (B,A,208) = w_vs(anchor_feats),
+ *   a_g (B,208) = fc_gamma(w_qs(z) - w_k_global(z)), v_g (B,208) = w_v_global(z),
+ *   weights[17] = { fc_delta.0 [208,4] (weight | bias), fc_delta.2 W [208,208], b [208], fc_gamma.0 W, b,
+ *                   fc_gamma.2 W, b, init_enc W [128,208], b [128], fc_c W [5,128,208], b [5,128],
+ *                   blocks.fc_0 W [5,128,128], b [5,128], blocks.fc_1 W [5,128,128], b [5,128],
+ *                   fc_out W [16,128], b [16] }.
+ * -------------------------------------------------------------------------------------------- */
+int nsdp_decoder_fused_fwd(const float *xyz_q, const float *anchors, const int32_t *idx, const float *qk,
+                           const float *vtab, const float *a_g, const float *v_g,
+                           const float *const *weights, int n_weights, int B, int NQ, int A, int KN, int D,
+                           int H, float *out, void *stream);
+
+/* ----------------------------------------------------------------------------------------------
  * BatchNorm1d on channels-last rows x[R,C] (R = B*n, C % 4 == 0, C <= 1024), replacing the 35
  * nn.BatchNorm1d calls of the encoder (model/encoder/blocks.py:132, :158, :300-312) together with the
  * residual add in front of them (`addend`, may be NULL: the norm acts on x + addend) and the ReLU behind

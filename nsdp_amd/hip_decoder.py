@@ -1,0 +1,121 @@
+"""Fused cross-attention decoder forward (no-grad path) over ``nsdp_decoder_fused_fwd``.
+
+Reference: CrossTransformerDecoder.forward, model/decoder/crosstransformer_decoder.py:45-70 and
+CrossTransformerBlock.forward, model/decoder/blocks.py:48-95.  The per-shape pieces (anchor key / value
+tables, the global token: a few hundred rows) go through the ordinary HIP linear; everything that scales
+with the number of query points (7-NN, 18 dense layers, the 8-token softmax) is one kNN launch and one fused
+kernel launch.  There is no fallback: shapes the kernel was not built for raise.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, hip_linear, pointnet2_utils
+
+import os
+
+ENABLED = os.environ.get("NSDP_FUSED_DECODER", "1") != "0"   # off: the layer-by-layer kernels (debug / A-B timing)
+DIM, HIDDEN, NBLOCKS, OUT = 200, 128, 5, 3
+DP, HP = 208, 128            # channel counts padded to multiples of 16 (one MFMA tile)
+
+
+def supported(decoder) -> bool:
+    """The kernel is specialised for the one decoder geometry every NSDP configuration uses."""
+    ct = decoder.ct1
+    return (decoder.dim == DIM and decoder.init_enc.out_features == HIDDEN and decoder.n_blocks == NBLOCKS
+            and decoder.fc_out.out_features == OUT and ct.reduce_dim and ct.nneigh >= 1)
+
+
+def _pad2(w, rows, cols):
+    return F.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0])).contiguous()
+
+
+def _pad1(b, n):
+    return F.pad(b, (0, n - b.shape[0])).contiguous()
+
+
+class _Pack:
+    """Zero-padded copies of the decoder weights in the layout of include/nsdp_hip.h, rebuilt whenever a
+    parameter changes (optimizer steps bump ``_version``; load_state_dict copies in place and bumps it too)."""
+
+    def __init__(self):
+        self.key = None
+        self.tensors = None
+        self.ptrs = None
+        self.tables = None
+
+    def get(self, dec):
+        params = list(dec.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self.key:
+            return self
+        ct = dec.ct1
+        with torch.no_grad():
+            d0, d2 = ct.fc_delta[0], ct.fc_delta[2]
+            g0, g2 = ct.fc_gamma[0], ct.fc_gamma[2]
+            t = [
+                _pad2(torch.cat([d0.weight, d0.bias[:, None]], dim=1), DP, 4),
+                _pad2(d2.weight, DP, DP), _pad1(d2.bias, DP),
+                _pad2(g0.weight, DP, DP), _pad1(g0.bias, DP),
+                _pad2(g2.weight, DP, DP), _pad1(g2.bias, DP),
+                _pad2(dec.init_enc.weight, HP, DP), _pad1(dec.init_enc.bias, HP),
+                torch.stack([_pad2(l.weight, HP, DP) for l in dec.fc_c]).contiguous(),
+                torch.stack([_pad1(l.bias, HP) for l in dec.fc_c]).contiguous(),
+                torch.stack([_pad2(b.fc_0.weight, HP, HP) for b in dec.blocks]).contiguous(),
+                torch.stack([_pad1(b.fc_0.bias, HP) for b in dec.blocks]).contiguous(),
+                torch.stack([_pad2(b.fc_1.weight, HP, HP) for b in dec.blocks]).contiguous(),
+                torch.stack([_pad1(b.fc_1.bias, HP) for b in dec.blocks]).contiguous(),
+                _pad2(dec.fc_out.weight, 16, HP), _pad1(dec.fc_out.bias, 16),
+            ]
+            # projections producing the per-shape tables directly at the padded width
+            self.tables = {
+                "w_qs": _pad2(ct.w_qs.weight, DP, ct.w_qs.in_features),
+                "w_ks": _pad2(ct.w_ks.weight, DP, ct.w_ks.in_features),
+                "w_vs": _pad2(ct.w_vs.weight, DP, ct.w_vs.in_features),
+                "w_kg": _pad2(ct.w_k_global.weight, DP, ct.w_k_global.in_features),
+                "w_vg": _pad2(ct.w_v_global.weight, DP, ct.w_v_global.in_features),
+            }
+        self.tensors = t
+        self.ptrs = (ctypes.c_void_p * len(t))(*[x.data_ptr() for x in t])
+        self.key = key
+        return self
+
+
+def decoder_forward(dec, xyz_q: torch.Tensor, encoding: dict) -> torch.Tensor:
+    """xyz_q [B,NQ,3] + encoding {z [B,C], anchors [B,A,3], anchor_feats [B,A,C]} -> [B,NQ,3]."""
+    if not supported(dec):
+        raise _lib.NsdpHipError("fused decoder: built for dim=200, hidden_dim=128, n_blocks=5, out_dim=3")
+    z, anchors, feats = encoding["z"], encoding["anchors"], encoding["anchor_feats"]
+    if z.dim() != 2:
+        raise _lib.NsdpHipError("fused decoder: per-query latent codes are not used by any NSDP configuration")
+    pack = dec.__dict__.get("_fused_pack")
+    if pack is None:
+        pack = dec.__dict__["_fused_pack"] = _Pack()
+    pack = pack.get(dec)
+    ct = dec.ct1
+    B, NQ, _ = xyz_q.shape
+    A = anchors.shape[1]
+    xyz_q = xyz_q.contiguous().float()
+    anchors = anchors.contiguous().float()
+    with torch.no_grad(), _lib.on_device(xyz_q):
+        idx = pointnet2_utils.knn(xyz_q, anchors, ct.nneigh)                    # [B,NQ,k] int32
+        tb = pack.tables
+        q = hip_linear.linear(z, tb["w_qs"])                                    # [B,DP] (pad channels = 0)
+        k_g = hip_linear.linear(z, tb["w_kg"])
+        v_g = hip_linear.linear(z, tb["w_vg"]).contiguous()
+        kf = hip_linear.linear(feats, tb["w_ks"])                               # [B,A,DP]
+        vtab = hip_linear.linear(feats, tb["w_vs"]).contiguous()
+        qk = (q.unsqueeze(1) - kf).contiguous()
+        t = pack.tensors
+        h = hip_linear.linear(q - k_g, t[3], t[4], relu_out=True)              # global-token logits
+        a_g = hip_linear.linear(h, t[5], t[6]).contiguous()
+        out = torch.empty(B, NQ, OUT, dtype=torch.float32, device=xyz_q.device)
+        _lib.check(_lib.lib().nsdp_decoder_fused_fwd(
+            _lib.fptr(xyz_q, "xyz_q"), _lib.fptr(anchors, "anchors"), _lib.iptr(idx, "idx"),
+            _lib.fptr(qk, "qk"), _lib.fptr(vtab, "vtab"), _lib.fptr(a_g, "a_g"), _lib.fptr(v_g, "v_g"),
+            pack.ptrs, len(t), B, NQ, A, ct.nneigh, DIM, HIDDEN, _lib.fptr(out, "out"), _lib.stream_ptr()),
+            "nsdp_decoder_fused_fwd")
+    return out

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ... import hip_decoder
 from .blocks import CrossTransformerBlock, ResnetBlockFC
 
 
@@ -23,6 +24,9 @@ class CrossTransformerDecoder(nn.Module):
         self.fc_out = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, xyz_q, encoding):
+        if hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self):
+            # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
+            return hip_decoder.decoder_forward(self, xyz_q, encoding)
         lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
         net = ops.linear(lat, self.init_enc)
         for i in range(self.n_blocks):

@@ -29,13 +29,20 @@ def test_eval_forward_matches_golden(mtype):
     fx, cfg, seed, data = fixture_setup("tiny_" + mtype, mtype)
     model, _, _ = build_product(cfg, seed, DEV)
     model.eval()
+    from nsdp_amd import hip_decoder
     tape = {}
     hs = _hooks(model, tape)
     with torch.no_grad():
-        out = run_forward(model, cfg, to_dev(data, DEV))
+        out_fused = run_forward(model, cfg, to_dev(data, DEV))       # decoder = nsdp_decoder_fused_fwd
+        hip_decoder.ENABLED = False                                    # layer-by-layer decoder: exposes the taps
+        try:
+            out = run_forward(model, cfg, to_dev(data, DEV))
+        finally:
+            hip_decoder.ENABLED = True
     for h in hs:
         h.remove()
     assert l2_err(out.cpu().numpy(), fx["eval_out"]) <= TOL_L2
+    assert l2_err(out_fused.cpu().numpy(), fx["eval_out"]) <= TOL_L2
     checked = 0
     for key, ref in fx.items():
         if key.startswith("eval_tap/"):
