@@ -114,6 +114,20 @@ int nsdp_linear_f32(const float *X, const float *W, const float *bias, const flo
                     const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
                     int relu_in, int relu_out, void *stream);
 
+/* Fragment-major weight packs for nsdp_linear_wp_f32 (one contiguous KiB per wave-wide MFMA operand load
+ * instead of 16 rows x 64 B): Wp = pack of W[N,K] (forward operand), WpT = pack of W^T (the operand of
+ * dX = dY * W); either may be NULL.  Each holds nsdp_packed_weight_floats(N,K) floats, zero padded to
+ * multiples of 16 in both dimensions:
+ *   Wp [((tn*ceil(K/16) + kb)*64 + 16g + li)*4 + c] = W[16tn + li][16kb + 4g + c]
+ *   WpT[((tk*ceil(N/16) + nb)*64 + 16g + li)*4 + c] = W[16nb + 4g + c][16tk + li]                       */
+long long nsdp_packed_weight_floats(int N, int K);
+int nsdp_pack_weight_f32(const float *W, int N, int K, float *Wp, float *WpT, void *stream);
+
+/* nsdp_linear_f32 with W given as its fragment-major pack (logical shape still [N,K]); same semantics. */
+int nsdp_linear_wp_f32(const float *X, const float *Wp, const float *bias, const float *residual,
+                       const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                       int relu_in, int relu_out, void *stream);
+
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.
  * Deterministic (two-stage
@@ -159,7 +173,9 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
  *   xyz_q (B,NQ,3), anchors (B,A,3), idx (B,NQ,KN) i32 nearest anchors,
  *   qk (B,A,208) = w_qs(z) - w_ks(anchor_feats), vtab (B,A,208) = w_vs(anchor_feats),
  *   a_g (B,208) = fc_gamma(w_qs(z) - w_k_global(z)), v_g (B,208) = w_v_global(z),
- *   weights[17] = { fc_delta.0 [208,4] (weight | bias), fc_delta.2 W [208,208], b [208], fc_gamma.0 W, b,
+ *   weights[17], every W in FRAGMENT-MAJOR order [out tile of 16][k block of 16][lane = 16 g + li][4], holding
+ *   W_rowmajor[16 tile + li][16 kblock + 4 g + 0..3] (one wave-wide MFMA operand load = one contiguous KiB):
+ *                 { fc_delta.0 [208,4] (weight | bias, row-major), fc_delta.2 W [208,208], b [208], fc_gamma.0 W, b,
  *                   fc_gamma.2 W, b, init_enc W [128,208], b [128], fc_c W [5,128,208], b [5,128],
  *                   blocks.fc_0 W [5,128,128], b [5,128], blocks.fc_1 W [5,128,128], b [5,128],
  *                   fc_out W [16,128], b [16] }.

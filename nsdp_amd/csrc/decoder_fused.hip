@@ -140,7 +140,6 @@ template <int NTOUT, int NTIN, bool RELU_IN, bool RELU_OUT, bool ACC>
 __device__ __forceinline__ void dense(const float *__restrict__ W, const float *__restrict__ bias,
                                       const f32x4 *v_in, f32x4 *v_out, int li, int g) {
   using S = Steps<NTOUT, NTIN>;
-  constexpr int LDW = NTIN * 16;
   f32x4 x[NTIN];
 #pragma unroll
   for (int kb = 0; kb < NTIN; ++kb) {
@@ -150,13 +149,15 @@ __device__ __forceinline__ void dense(const float *__restrict__ W, const float *
       x[kb][2] = fmaxf(x[kb][2], 0.f); x[kb][3] = fmaxf(x[kb][3], 0.f);
     }
   }
-  const unsigned wl = (static_cast<unsigned>(li) * LDW + 4u * g) * 4u;    // lane's row / k offset inside a tile
+  // W is fragment-major: [out tile][k block][lane = 16 g + li][4] -- each wave-wide load is one contiguous KiB
+  // (row-major rows would make every 16-lane group touch 16 different cache lines for 16 B each)
+  const unsigned wl = (16u * g + li) * 16u;
   const unsigned bl = 16u * g;
   f32x4 ra[kRing], rb[kRing];
   auto issue = [&](auto I) {
     constexpr int s = decltype(I)::value;
-    wload<S::kb_a(s) * 64>(ra[s % kRing], W + S::tile_a(s) * 16 * LDW, wl);
-    if constexpr (S::has_b(s)) wload<S::kb_b(s) * 64>(rb[s % kRing], W + S::tile_b(s) * 16 * LDW, wl);
+    wload<0>(ra[s % kRing], W + (S::tile_a(s) * NTIN + S::kb_a(s)) * 256, wl);
+    if constexpr (S::has_b(s)) wload<0>(rb[s % kRing], W + (S::tile_b(s) * NTIN + S::kb_b(s)) * 256, wl);
   };
   constexpr int kPro = kPrefetch < S::kSteps ? kPrefetch : S::kSteps;
   static_for<0, kPro>(issue);

@@ -42,7 +42,9 @@ struct LinearParams {
 // s_waitcnt vmcnt(0), which serialises the whole operand stream.  Rows >= M and columns >= N compute
 // garbage that is never stored; the ragged last k-block (K % 16 != 0) is handled by zeroing the weight
 // fragment with a select while the activation fragment re-reads in-row (finite) data.
-template <int MT, int NT, int PRE, bool PIPE>
+// WP: W is the fragment-major pack written by nsdp_pack_weight_f32 ([n tile][k block][lane][4], zero padded):
+// every wave-wide weight load is one contiguous KiB instead of 16 rows x 64 B, and needs no clamps or k-tail fix-up.
+template <int MT, int NT, int PRE, bool PIPE, bool WP = false>
 __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -83,15 +85,20 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
     xa[mt] = p.X + r * K;
     ma[mt] = PRE == 1 ? p.mask + r * K : nullptr;
   }
+  const int KB = (K + 15) >> 4;
   const float *wb[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int n = (ntile0 + nt) * 16 + li;
-    n = n < N ? n : (N - 1);
-    wb[nt] = p.W + static_cast<long long>(n) * K;
+    if (WP) {
+      int t = ntile0 + nt;
+      t = t * 16 < N ? t : ((N + 15) / 16 - 1);
+      wb[nt] = p.W + (static_cast<long long>(t) * KB * 64 + lane) * 4;
+    } else {
+      int n = (ntile0 + nt) * 16 + li;
+      n = n < N ? n : (N - 1);
+      wb[nt] = p.W + static_cast<long long>(n) * K;
+    }
   }
-
-  const int KB = (K + 15) >> 4;
 
   // Software pipeline, two register buffers.  Phase = { issue the raw loads of block kb+1 ; MFMAs of
   // block kb }.  hipcc's scheduler otherwise sinks the prefetch loads down to their first use (minimum
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
       if (PRE == 1) f.m[mt] = *reinterpret_cast<const float4 *>(ma[mt] + ko);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) f.b[nt] = *reinterpret_cast<const float4 *>(wb[nt] + ko);
+    for (int nt = 0; nt < NT; ++nt) f.b[nt] = *reinterpret_cast<const float4 *>(wb[nt] + (WP ? kb * 256 : ko));
   };
   auto fixup = [&](int kb, Frag &f) {
     const bool kv = kb * 16 + 4 * g < K;
@@ -130,11 +137,13 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
       }
       f.a[mt] = v;
     }
+    if (!WP) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float4 v = f.b[nt];
-      v.x = kv ? v.x : 0.f; v.y = kv ? v.y : 0.f; v.z = kv ? v.z : 0.f; v.w = kv ? v.w : 0.f;
-      f.b[nt] = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        float4 v = f.b[nt];
+        v.x = kv ? v.x : 0.f; v.y = kv ? v.y : 0.f; v.z = kv ? v.z : 0.f; v.w = kv ? v.w : 0.f;
+        f.b[nt] = v;
+      }
     }
   };
   auto mma = [&](const Frag &f) {
@@ -428,14 +437,18 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 }
 
 template <int MT, int NT>
-int launch_nt(const LinearParams &p, hipStream_t st, int grid_y = 1) {
+int launch_nt(const LinearParams &p, hipStream_t st, int grid_y = 1, bool wp = false) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   const long long rows_per_wg = 4LL * MT * 16;
   const long long grid = (p.M + rows_per_wg - 1) / rows_per_wg;
   nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   const dim3 gr(static_cast<unsigned>(grid), grid_y);
-  if (g_nt_pipe == 2 && grid_y == 1) {
+  if (wp) {
+    if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0, true, true>), gr, dim3(256), 0, st, p);
+    else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1, true, true>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2, true, true>), gr, dim3(256), 0, st, p);
+  } else if (g_nt_pipe == 2 && grid_y == 1) {
     if (pre == 0) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 0>), gr, dim3(256), 0, st, p);
     else if (pre == 1) hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 1>), gr, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((linear_nt_lds_kernel<MT, NT, 2>), gr, dim3(256), 0, st, p);
@@ -763,6 +776,39 @@ __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long
   }
 }
 
+// Fragment-major weight packs for linear_nt_kernel<.., WP = true>:
+//   Wp  [ceil(N/16)][ceil(K/16)][64][4]: Wp [((tn*KB + kb)*64 + 16g + li)*4 + c] = W[16tn + li][16kb + 4g + c]
+//   WpT [ceil(K/16)][ceil(N/16)][64][4]: WpT[((tk*NB + nb)*64 + 16g + li)*4 + c] = W[16nb + 4g + c][16tk + li]
+// (the operand of dX = dY * W, i.e. the pack of W^T), zero outside [N,K].  One thread per float4 of each output.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ W, int N, int K,
+                                                          float *__restrict__ Wp, float *__restrict__ WpT) {
+  const int NB = (N + 15) >> 4, KB = (K + 15) >> 4;
+  const long long q = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (q >= static_cast<long long>(NB) * KB * 64) return;
+  const int lane = static_cast<int>(q & 63), li = lane & 15, g = lane >> 4;
+  const long long blk = q >> 6;
+  if (Wp) {
+    const int tn = static_cast<int>(blk / KB), kb = static_cast<int>(blk % KB);
+    const int n = tn * 16 + li, k0 = kb * 16 + 4 * g;
+    float4 v;
+    v.x = n < N && k0 + 0 < K ? W[static_cast<long long>(n) * K + k0 + 0] : 0.f;
+    v.y = n < N && k0 + 1 < K ? W[static_cast<long long>(n) * K + k0 + 1] : 0.f;
+    v.z = n < N && k0 + 2 < K ? W[static_cast<long long>(n) * K + k0 + 2] : 0.f;
+    v.w = n < N && k0 + 3 < K ? W[static_cast<long long>(n) * K + k0 + 3] : 0.f;
+    reinterpret_cast<float4 *>(Wp)[q] = v;
+  }
+  if (WpT) {
+    const int tk = static_cast<int>(blk / NB), nb = static_cast<int>(blk % NB);
+    const int k = tk * 16 + li, n0 = nb * 16 + 4 * g;
+    float4 v;
+    v.x = k < K && n0 + 0 < N ? W[static_cast<long long>(n0 + 0) * K + k] : 0.f;
+    v.y = k < K && n0 + 1 < N ? W[static_cast<long long>(n0 + 1) * K + k] : 0.f;
+    v.z = k < K && n0 + 2 < N ? W[static_cast<long long>(n0 + 2) * K + k] : 0.f;
+    v.w = k < K && n0 + 3 < N ? W[static_cast<long long>(n0 + 3) * K + k] : 0.f;
+    reinterpret_cast<float4 *>(WpT)[q] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -774,9 +820,9 @@ void nsdp_debug_set(int key, int value) {
   if (key == 5) g_wgrad_vec4 = value;
 }
 
-int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
-                    const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
-                    int relu_in, int relu_out, void *stream) {
+static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,
+                           const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                           int relu_in, int relu_out, void *stream, bool wp) {
   if (M <= 0 || N <= 0) return 0;
   NSDP_REQUIRE(X && W && Y, "linear: null pointer");
   NSDP_REQUIRE(K > 0 && K % 4 == 0, "linear: K=%d must be a positive multiple of 4", K);
@@ -789,12 +835,38 @@ int nsdp_linear_f32(const float *X, const float *W, const float *bias, const flo
   const int nt = (N + 15) / 16;
   // small M (per-point layers at the 500/100-anchor levels): one 16-row tile x 4 column tiles per wave and
   // the column tiles spread over grid.y, so that a few thousand rows still fill the chip
-  if (M <= 32768 && nt > 4 && g_nt_pipe != 2) return launch_nt<1, 4>(p, st, (nt + 3) / 4);
-  if (nt <= 1) return launch_nt<4, 1>(p, st);
-  if (nt <= 4) return launch_nt<4, 4>(p, st);
-  if (nt <= 8) return launch_nt<4, 8>(p, st);
-  if (nt <= 13) return launch_nt<2, 13>(p, st);
-  return launch_nt<2, 16>(p, st);
+  if (M <= 32768 && nt > 4 && (wp || g_nt_pipe != 2)) return launch_nt<1, 4>(p, st, (nt + 3) / 4, wp);
+  if (nt <= 1) return launch_nt<4, 1>(p, st, 1, wp);
+  if (nt <= 4) return launch_nt<4, 4>(p, st, 1, wp);
+  if (nt <= 8) return launch_nt<4, 8>(p, st, 1, wp);
+  if (nt <= 13) return launch_nt<2, 13>(p, st, 1, wp);
+  return launch_nt<2, 16>(p, st, 1, wp);
+}
+
+int nsdp_linear_f32(const float *X, const float *W, const float *bias, const float *residual,
+                    const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                    int relu_in, int relu_out, void *stream) {
+  return linear_dispatch(X, W, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out, stream, false);
+}
+
+int nsdp_linear_wp_f32(const float *X, const float *Wp, const float *bias, const float *residual,
+                       const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                       int relu_in, int relu_out, void *stream) {
+  return linear_dispatch(X, Wp, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out, stream, true);
+}
+
+long long nsdp_packed_weight_floats(int N, int K) {
+  return static_cast<long long>((N + 15) / 16) * ((K + 15) / 16) * 256;
+}
+
+int nsdp_pack_weight_f32(const float *W, int N, int K, float *Wp, float *WpT, void *stream) {
+  if (N <= 0 || K <= 0) return 0;
+  NSDP_REQUIRE(W && (Wp || WpT), "pack_weight: null pointer");
+  const long long quads = nsdp_packed_weight_floats(N, K) / 4;
+  hipStream_t st = nsdp::as_stream(stream);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(static_cast<unsigned>((quads + 255) / 256)), dim3(256), 0, st, W, N, K,
+                     Wp, WpT);
+  return nsdp::launch_status("pack_weight_kernel");
 }
 
 }  // extern "C"

@@ -33,6 +33,13 @@ def _pad2(w, rows, cols):
     return F.pad(w, (0, cols - w.shape[1], 0, rows - w.shape[0])).contiguous()
 
 
+def _frag(w):
+    """Row-major zero-padded [16*To, 16*Ti] -> fragment-major [To][Ti][lane = 16 g + li][4]: the 64 float4 one
+    wave-wide MFMA A-operand load reads (row 16 to + li, columns 16 ti + 4 g .. + 3) become one contiguous KiB."""
+    to, ti = w.shape[0] // 16, w.shape[1] // 16
+    return w.view(to, 16, ti, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
 def _pad1(b, n):
     return F.pad(b, (0, n - b.shape[0])).contiguous()
 
@@ -46,6 +53,7 @@ class _Pack:
         self.tensors = None
         self.ptrs = None
         self.tables = None
+        self.gamma_rows = None
 
     def get(self, dec):
         params = list(dec.parameters())
@@ -58,18 +66,19 @@ class _Pack:
             g0, g2 = ct.fc_gamma[0], ct.fc_gamma[2]
             t = [
                 _pad2(torch.cat([d0.weight, d0.bias[:, None]], dim=1), DP, 4),
-                _pad2(d2.weight, DP, DP), _pad1(d2.bias, DP),
-                _pad2(g0.weight, DP, DP), _pad1(g0.bias, DP),
-                _pad2(g2.weight, DP, DP), _pad1(g2.bias, DP),
-                _pad2(dec.init_enc.weight, HP, DP), _pad1(dec.init_enc.bias, HP),
-                torch.stack([_pad2(l.weight, HP, DP) for l in dec.fc_c]).contiguous(),
+                _frag(_pad2(d2.weight, DP, DP)), _pad1(d2.bias, DP),
+                _frag(_pad2(g0.weight, DP, DP)), _pad1(g0.bias, DP),
+                _frag(_pad2(g2.weight, DP, DP)), _pad1(g2.bias, DP),
+                _frag(_pad2(dec.init_enc.weight, HP, DP)), _pad1(dec.init_enc.bias, HP),
+                torch.stack([_frag(_pad2(l.weight, HP, DP)) for l in dec.fc_c]).contiguous(),
                 torch.stack([_pad1(l.bias, HP) for l in dec.fc_c]).contiguous(),
-                torch.stack([_pad2(b.fc_0.weight, HP, HP) for b in dec.blocks]).contiguous(),
+                torch.stack([_frag(_pad2(b.fc_0.weight, HP, HP)) for b in dec.blocks]).contiguous(),
                 torch.stack([_pad1(b.fc_0.bias, HP) for b in dec.blocks]).contiguous(),
-                torch.stack([_pad2(b.fc_1.weight, HP, HP) for b in dec.blocks]).contiguous(),
+                torch.stack([_frag(_pad2(b.fc_1.weight, HP, HP)) for b in dec.blocks]).contiguous(),
                 torch.stack([_pad1(b.fc_1.bias, HP) for b in dec.blocks]).contiguous(),
-                _pad2(dec.fc_out.weight, 16, HP), _pad1(dec.fc_out.bias, 16),
+                _frag(_pad2(dec.fc_out.weight, 16, HP)), _pad1(dec.fc_out.bias, 16),
             ]
+            self.gamma_rows = (_pad2(g0.weight, DP, DP), _pad2(g2.weight, DP, DP))   # row-major, for the global token
             # projections producing the per-shape tables directly at the padded width
             self.tables = {
                 "w_qs": _pad2(ct.w_qs.weight, DP, ct.w_qs.in_features),
@@ -110,8 +119,8 @@ def decoder_forward(dec, xyz_q: torch.Tensor, encoding: dict) -> torch.Tensor:
         vtab = hip_linear.linear(feats, tb["w_vs"]).contiguous()
         qk = (q.unsqueeze(1) - kf).contiguous()
         t = pack.tensors
-        h = hip_linear.linear(q - k_g, t[3], t[4], relu_out=True)              # global-token logits
-        a_g = hip_linear.linear(h, t[5], t[6]).contiguous()
+        h = hip_linear.linear(q - k_g, pack.gamma_rows[0], t[4], relu_out=True)  # global-token logits
+        a_g = hip_linear.linear(h, pack.gamma_rows[1], t[6]).contiguous()
         out = torch.empty(B, NQ, OUT, dtype=torch.float32, device=xyz_q.device)
         _lib.check(_lib.lib().nsdp_decoder_fused_fwd(
             _lib.fptr(xyz_q, "xyz_q"), _lib.fptr(anchors, "anchors"), _lib.iptr(idx, "idx"),

@@ -30,6 +30,31 @@ def _fwd(x2, w, b, residual, mask, out_mask, relu_in, relu_out):
     return y
 
 
+def pack_weight(w, fwd=True, transposed=False):
+    """Fragment-major packs of W [N,K] (nsdp_pack_weight_f32): (Wp or None, WpT or None)."""
+    N, K = w.shape
+    L = lib()
+    L.nsdp_packed_weight_floats.restype = ctypes.c_longlong
+    n = int(L.nsdp_packed_weight_floats(_ci(N), _ci(K)))
+    wp = torch.empty(n, dtype=torch.float32, device=w.device) if fwd else None
+    wpt = torch.empty(n, dtype=torch.float32, device=w.device) if transposed else None
+    with on_device(w):
+        check(L.nsdp_pack_weight_f32(fptr(w, "weight"), _ci(N), _ci(K), optptr(wp), optptr(wpt), stream_ptr()),
+              "nsdp_pack_weight_f32")
+    return wp, wpt
+
+
+def _fwd_wp(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
+    """_fwd with the weight given as its fragment-major pack (logical [N, K = x2.shape[1]])."""
+    M, K = x2.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_wp_f32(fptr(x2, "x"), fptr(wp, "packed weight"), optptr(b), optptr(residual),
+                                       optptr(mask), optptr(out_mask), fptr(y), _ll(M), _ci(N), _ci(K),
+                                       _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()), "nsdp_linear_wp_f32")
+    return y
+
+
 def _wgrad(dy2, x2, mask, relu_x, want_db):
     M, N = dy2.shape
     K = x2.shape[1]
@@ -122,32 +147,50 @@ def _pad_cols(t, mult=4):
     return t if r == 0 else F.pad(t, (0, r))
 
 
+def _packs(w, owner, want_t):
+    """(Wp, WpT) fragment-major packs of w [N,K].  `owner` (the layer's nn.Parameter, or None) carries a
+    cache keyed by (storage pointer, version counter): optimizer steps and load_state_dict bump the version,
+    .to(device) changes the pointer.  Without an owner the pack is rebuilt per call (a reused address of a
+    freed temporary must never hit a stale pack)."""
+    if owner is not None:
+        key = (w.data_ptr(), w._version)
+        ent = owner.__dict__.get("_nsdp_pack")
+        if ent is not None and ent[0] == key and (ent[2] is not None or not want_t):
+            return ent[1], ent[2]
+    wc = w if w.is_contiguous() else w.contiguous()
+    wp, wpt = pack_weight(wc, True, want_t)
+    if owner is not None:
+        owner.__dict__["_nsdp_pack"] = (key, wp, wpt)
+    return wp, wpt
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None):
         ctx.w_param, ctx.b_param = w_param, b_param
         K = x.shape[-1]
+        N = w.shape[0]
         x2 = x.reshape(-1, K)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        wk = w
-        if K % 4:  # K = 3 (relative coordinates): zero-pad the reduction dimension
-            x2, wk = _pad_cols(x2), _pad_cols(w)
-        wk = wk if wk.is_contiguous() else wk.contiguous()
+        if K % 4:  # K = 3 (relative coordinates): zero-pad the reduction dimension (the weight pack pads itself)
+            x2 = _pad_cols(x2)
         res2 = None
         if residual is not None:
-            res2 = residual.reshape(-1, w.shape[0])
+            res2 = residual.reshape(-1, N)
             res2 = res2 if res2.is_contiguous() else res2.contiguous()
-        y = _fwd(x2, wk, b, res2, None, None, relu_in, relu_out)
+        want_t = bool(ctx.needs_input_grad[0])                         # dX = dY' @ W needs the pack of W^T
+        wp, wpt = _packs(w, w_param, want_t)
+        y = _fwd_wp(x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
-        ctx.x_shape, ctx.k_orig = x.shape, K
-        ctx.save_for_backward(x2, wk, y if relu_out else None)
-        return y.reshape(*x.shape[:-1], w.shape[0])
+        ctx.x_shape, ctx.k_orig, ctx.n_out = x.shape, K, N
+        ctx.save_for_backward(x2, wpt, y if relu_out else None)
+        return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, wk, y = ctx.saved_tensors
-        N = wk.shape[0]
+        x2, wpt, y = ctx.saved_tensors
+        N = ctx.n_out
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dx = dw = db = dres = None
@@ -164,12 +207,12 @@ class _LinearFn(torch.autograd.Function):
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         if ctx.needs_input_grad[0]:
-            wt = wk.t().contiguous()                      # [K, N]: dX = dY' @ W  ==  dY' @ (W^T)^T
             dyk, mk = dy2, y
             if N % 4:                                      # N = 3 (fc_out): pad the reduction dimension
-                dyk, wt = _pad_cols(dy2), _pad_cols(wt)
+                dyk = _pad_cols(dy2)
                 mk = _pad_cols(y) if y is not None else None
-            dx = _fwd(dyk, wt, None, None, mk, x2 if ctx.relu_in else None, False, False)
+            # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
+            dx = _fwd_wp(dyk, wpt, x2.shape[1], None, None, mk, x2 if ctx.relu_in else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
