@@ -46,6 +46,19 @@ __device__ __forceinline__ float sq_dist3(float ax, float ay, float az, float bx
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// compute units of the current device (cached per device)
+inline int num_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 inline int ceil_div(long long a, long long b) { return static_cast<int>((a + b - 1) / b); }
 
 }  // namespace nsdp

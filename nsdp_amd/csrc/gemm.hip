@@ -811,6 +811,10 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 
 }  // namespace
 
+namespace nsdp {
+void debug_set_x3(int value);   // gemm_bf16x3.hip
+}
+
 extern "C" {
 
 void nsdp_debug_set(int key, int value) {
@@ -818,6 +822,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 3) g_nt_pipe = value;
   if (key == 4) g_nt_dbg = value;
   if (key == 5) g_wgrad_vec4 = value;
+  if (key == 6) nsdp::debug_set_x3(value);
 }
 
 static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,

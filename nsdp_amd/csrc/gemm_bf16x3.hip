@@ -1,0 +1,462 @@
+// fp32 dense layers on the CDNA4 bf16 matrix pipe by error-compensated splitting ("bf16x3"):
+//
+//     x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (round to nearest, residuals exact)
+//     x * w  ~=  h*wh + h*wm + m*wh + m*wm + h*wl + l*wh                          (6 of the 9 products)
+//
+// The dropped products (m*wl, l*wm, l*wl) are <= 2^-23 |x||w|, the split itself loses <= 2^-24 |x| -- the result
+// is accurate to fp32 rounding level (tests: error vs. an fp64 reference is the same as the exact-fp32 MFMA
+// kernel's), products are exact in the matrix pipe and accumulate in fp32.  v_mfma_f32_16x16x32_bf16 has 16x
+// the rate of v_mfma_f32_16x16x4_f32, so 6 products cost 6/16 of the exact path: a 2.67x higher compute
+// roofline (2.5 PF / 6 = 417 TFLOP/s of fp32-equivalent work), which moves the tall-skinny layers of the
+// TDNet path (M ~ 10^6, N, K <= 256) from the MFMA bound to the HBM bound.
+//
+// nsdp_linear_bf16x3_f32: Y[M,N] = post( pre(X)[M,K] W[N,K]^T + b ) (+ residual), same contract as nsdp_linear_f32.
+//   * one wave owns 64 rows (MT = 4 row tiles) and all N columns: accumulators 4 x NT x 4 <= 256 AGPRs.
+//   * W comes pre-split (nsdp_pack_weight_bf16x3: [k block of 32][n tile][plane h,m,l][lane][8 bf16] = 1 KiB
+//     per wave-wide operand), is DMA'd global -> LDS once per workgroup and k block (global_load_lds, two
+//     buffers, one barrier per k block) and read back with conflict-free ds_read_b128: per-wave register
+//     loads of W would need 62 B/clk/CU of L1 bandwidth at this MFMA rate.
+//   * X is read once from HBM, 32 B per lane and k block (k-permuted fragment convention: lane group g
+//     supplies k = 32 kb + 8 g .. + 7 to A and B alike, so row-major rows need no transposition), one
+//     k block ahead, and split on the VALU (v_cvt_pk_bf16_f32 / v_pk_add_f32: 4.5 ops per value) during
+//     the first MFMA steps of the previous k block.
+#include <type_traits>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+int g_x3_dbg = 0;
+
+struct X3Params {
+  const float *X;
+  const void *Wp;  // bf16x3 pack
+  const float *bias, *residual, *mask, *out_mask;
+  float *Y;
+  long long M;
+  int N, K;
+  int relu_in, relu_out;
+  int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, 1 no activation loads in the loop,
+            // 3 no stores -- wrong results, timing only
+};
+
+// two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// hand-issued activation loads (the compiler would sink them to their first use, see decoder_fused.hip)
+__device__ __forceinline__ void xload(f32x4 &dst, const float *lane_ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(lane_ptr));
+}
+
+
+// weight fragments come back from LDS through hand-placed ds_read_b128 (the compiler sinks ordinary LDS loads
+// below the MFMA block of a step, exposing their latency every step); lgkmcnt is awaited by hand, the fragment
+// registers being in/out operands of the wait so that their users depend on it
+template <int OFF>
+__device__ __forceinline__ void lds_read(u32x4 &dst, unsigned lane_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lane_addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+
+template <int MT, int NT, int PRE>
+__global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
+  static_assert(MT == 4, "the step schedule below is written for four row tiles per wave");
+  __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][NT * 3 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int K = p.K, N = p.N;
+  const int KB = (K + 31) >> 5;                // >= 2 (host contract)
+  const int ntiles = (N + 15) >> 4;            // n tiles present in the pack (<= NT)
+  constexpr long long kRowsWg = 4LL * MT * 16;
+  const long long wg_tiles = (p.M + kRowsWg - 1) / kRowsWg;
+  const long long stride = gridDim.x;
+  long long tile = blockIdx.x;                 // persistent workgroup: tile, tile + grid, ...
+
+  // per-lane activation rows of a tile, clamped into the tensor (rows >= M are computed and never stored)
+  const float *xa[MT], *xn[MT];
+  const float *ma[MT], *mn[MT];
+  auto set_rows = [&](long long t, const float **x, const float **m) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      long long r = (t * 4 + wave) * (MT * 16) + mt * 16 + li;
+      r = r < p.M ? r : (p.M - 1);
+      x[mt] = p.X + r * K;
+      m[mt] = PRE == 1 ? p.mask + r * K : nullptr;
+    }
+  };
+  set_rows(tile, xa, ma);
+  set_rows(tile + stride, xn, mn);
+
+  const char *wlane = static_cast<const char *>(p.Wp) + lane * 16;
+  auto stage = [&](int kb, int buf) {   // DMA one k block of weight pieces (1 KiB each), spread over the 4 waves
+    const int pieces = ntiles * 3;
+    for (int q = wave; q < pieces; q += 4)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wlane + ((static_cast<long long>(kb) * pieces + q) << 10)),
+                                       (lds_ptr_t)(&wbuf[buf][q * 64]), 16, 0, 0);
+  };
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wbuf[0][lane])));
+  constexpr unsigned kBufBytes = NT * 3 * 1024;
+
+  // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 8 g + 4 half ..)
+  f32x4 raw[MT][2], rawm[PRE == 1 ? MT : 1][2];
+  auto xissue = [&](const float *const *x, const float *const *m, int kb) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int ko = kb * 32 + 8 * g + 4 * hf;
+        ko = ko < K ? ko : (K - 4);     // past the row end: re-read in-row data (the packed weights are zero there)
+        xload(raw[mt][hf], x[mt] + ko);
+        if (PRE == 1) xload(rawm[mt][hf], m[mt] + ko);
+      }
+  };
+  auto xwait = [&]() {   // all outstanding vector memory operations; the raw registers become data-dependent on it
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[mt][0]), "+v"(raw[mt][1]));
+      if (PRE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawm[mt][0]), "+v"(rawm[mt][1]));
+    }
+  };
+  struct Planes {
+    u32x4 h[MT], m[MT], l[MT];
+  };
+  auto convert_pair = [&](Planes &pl, int mt, int pr) {   // pr = 0..3: values 2 pr, 2 pr + 1 of the lane's 8
+    f32x4 v = raw[mt][pr >> 1];
+    if (PRE == 1) {
+      const f32x4 mk = rawm[mt][pr >> 1];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.f ? v[c] : 0.f;
+    }
+    if (PRE == 2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+    }
+    unsigned h, m, l;
+    split_pair(v[2 * (pr & 1)], v[2 * (pr & 1) + 1], h, m, l);
+    pl.h[mt][pr] = h; pl.m[mt][pr] = m; pl.l[mt][pr] = l;
+  };
+
+  Planes cur, nxt;
+  // prologue (once per workgroup): block 0 of the first tile, split; block 1 in flight
+  stage(0, 0);
+  xissue(xa, ma, 0);
+  xwait();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) convert_pair(cur, mt, pr);
+  xissue(xa, ma, 1);
+  xwait();
+  __syncthreads();
+
+  // the split of the next k block's activations is spread over the first kConvSteps n-tile steps of a block
+  constexpr int kConvSteps = NT > 4 ? 4 : NT - 1;
+  constexpr int kPairs = MT * 4;
+  constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
+  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 23) / 24;
+
+  unsigned gs = 0;   // running k block count: weight buffer parity
+  for (;;) {
+    const long long row0 = (tile * 4 + wave) * (MT * 16);
+    const bool next_tile = tile + stride < wg_tiles;
+    // (opaque per-tile copies of the lane coordinates: everything the prologue / epilogue derives from them is
+    // tile-invariant, and LICM would otherwise keep ~60 such values live across the whole k loop)
+    int li_t = li, g_t = g;
+    asm volatile("" : "+v"(li_t), "+v"(g_t));
+    f32x4 acc[MT][NT];
+    // TRANSPOSED product D = W X^T: lane (li, g) of accumulator (mt, nt) holds row row0 + 16 mt + li, columns
+    // 16 nt + 4 g .. + 3 -- four consecutive floats of Y, so residual / bias / out_mask / Y move as float4
+    if (p.residual) {  // residual add fused as the accumulator's initial value
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        long long row = row0 + mt * 16 + li_t;
+        row = row < p.M ? row : (p.M - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int col = nt * 16 + 4 * g_t;
+          col = col + 4 <= N ? col : (N - 4);
+          const float4 v = *reinterpret_cast<const float4 *>(p.residual + row * N + col);
+          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int kb = 0; kb < KB; ++kb, ++gs) {
+      const unsigned buf = gs & 1u;
+      const bool more = kb + 1 < KB || next_tile;          // a k block follows (this tile's, or the next tile's first)
+      if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
+      const unsigned wl_addr = lds0 + buf * kBufBytes;
+      u32x4 wh, wm, wl;
+      lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
+      lds_wait(wh, wm, wl);
+      static_for<0, NT>([&](auto I) {
+        constexpr int nt = decltype(I)::value;
+        u32x4 nh, nm, nl;
+        if constexpr (nt + 1 < NT) {
+          lds_read<(nt + 1) * 3072>(nh, wl_addr); lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
+          lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
+        }
+        if constexpr (nt == kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
+          if (!(p.dbg & 2)) {
+            if (kb + 2 < KB) xissue(xa, ma, kb + 2);
+            else if (next_tile) xissue(xn, mn, kb + 2 - KB);
+          }
+        }
+        // ---- one scheduling region: 24 MFMAs + this step's share of the activation split (VALU) ----
+        // (unconditional -- after the last block it splits stale data that nobody uses: a branch would put the
+        // VALU work into its own basic block, where it cannot be interleaved with the MFMAs)
+        if constexpr (nt < kConvSteps) {
+#pragma unroll
+          for (int i = 0; i < kPerStep; ++i) {
+            constexpr int base = nt * kPerStep;
+            if (base + i < kPairs) convert_pair(nxt, (base + i) >> 2, (base + i) & 3);
+          }
+        }
+        // smallest products first; the MT accumulators of a product are independent
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.l[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wl, cur.h[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wm, cur.m[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.m[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wm, cur.h[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.h[mt], acc[mt][nt]);
+        if constexpr (nt < kConvSteps) {
+          // a wave issues in order: the split only overlaps the matrix pipe if its VALU ops sit BETWEEN MFMAs
+#pragma unroll
+          for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);
+          }
+        }
+        // MFMAs are pure values to the compiler; pin them (and the split's results) to this step
+        asm volatile("" : "+a"(acc[0][nt]), "+a"(acc[1][nt]), "+a"(acc[2][nt]), "+a"(acc[3][nt]));
+        if constexpr (nt < kConvSteps) {
+#pragma unroll
+          for (int i = 0; i < kPerStep; ++i) {
+            constexpr int base = nt * kPerStep;
+            if (base + i < kPairs) {
+              const int mt = (base + i) >> 2, pr = (base + i) & 3;
+              asm volatile("" : "+v"(nxt.h[mt][pr]), "+v"(nxt.m[mt][pr]), "+v"(nxt.l[mt][pr]));
+            }
+          }
+        }
+        if constexpr (nt + 1 < NT) {
+          lds_wait(nh, nm, nl);
+          wh = nh; wm = nm; wl = nl;
+        }
+      });
+      xwait();            // next block's weights (DMA) and the activations after next have landed
+      __syncthreads();    // every wave is done reading wbuf[buf]
+      cur = nxt;
+    }
+
+    // epilogue: lane (li, g) of (mt, nt) holds Y[row0 + 16 mt + li][16 nt + 4 g .. + 3]
+    if (row0 < p.M && !(p.dbg & 8)) {
+      const bool full_rows = row0 + MT * 16 <= p.M;
+      int li_e = li, g_e = g;
+      asm volatile("" : "+v"(li_e), "+v"(g_e));
+      auto otile = [&](int nt, auto has_omask, auto guarded) {
+        const int col = nt * 16 + 4 * g_e;
+        const bool cv = col + 4 <= N;
+        const int colc = cv ? col : (N - 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + colc);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const long long row = row0 + mt * 16 + li_e;
+          const bool rv = !decltype(guarded)::value || row < p.M;
+          const long long rowc = rv ? row : (p.M - 1);
+          float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (decltype(has_omask)::value) {
+            const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
+            v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f;
+          }
+          if (decltype(guarded)::value) {
+            if (cv && rv) *reinterpret_cast<float4 *>(p.Y + rowc * N + colc) = v;
+          } else {
+            *reinterpret_cast<float4 *>(p.Y + row * N + col) = v;
+          }
+        }
+      };
+      auto epilogue = [&](auto has_omask) {
+        const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
+        if (full_rows) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (nt < full_tiles) otile(nt, has_omask, std::false_type{});
+            else if (nt * 16 < N) otile(nt, has_omask, std::true_type{});
+          }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (nt * 16 < N) otile(nt, has_omask, std::true_type{});
+        }
+      };
+      if (p.out_mask) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+    }
+
+    if (!next_tile) break;
+    tile += stride;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { xa[mt] = xn[mt]; ma[mt] = mn[mt]; }
+    set_rows(tile + stride, xn, mn);
+  }
+}
+
+// bf16x3 packs.  Wp  [ceil(K/32)][ceil(N/16)][3 planes][64 lanes][8 bf16]:
+//   element j of lane 16 g + li of (kb, tn) = plane_p( W[16 tn + li][32 kb + 8 g + j] )
+// WpT [ceil(N/32)][ceil(K/16)][3][64][8]: the pack of W^T (operand of dX = dY W):
+//   element j of lane 16 g + li of (nb, tk) = plane_p( W[32 nb + 8 g + j][16 tk + li] )
+// zero outside [N,K].  One thread per (block, tile, lane) of each output.
+__global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restrict__ W, int N, int K,
+                                                          u32x4 *__restrict__ Wp, u32x4 *__restrict__ WpT) {
+  const long long q = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const int lane = static_cast<int>(q & 63), li = lane & 15, g = lane >> 4;
+  const long long blk = q >> 6;
+  if (Wp) {
+    const int NT = (N + 15) >> 4, KB = (K + 31) >> 5;
+    if (blk < static_cast<long long>(NT) * KB) {
+      const int kb = static_cast<int>(blk / NT), tn = static_cast<int>(blk % NT);
+      const int n = tn * 16 + li, k0 = kb * 32 + 8 * g;
+      u32x4 h, m, l;
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const int k = k0 + 2 * pr;
+        const float x0 = n < N && k < K ? W[static_cast<long long>(n) * K + k] : 0.f;
+        const float x1 = n < N && k + 1 < K ? W[static_cast<long long>(n) * K + k + 1] : 0.f;
+        unsigned a, b, c;
+        split_pair(x0, x1, a, b, c);
+        h[pr] = a; m[pr] = b; l[pr] = c;
+      }
+      u32x4 *dst = Wp + (blk * 3) * 64 + lane;
+      dst[0] = h; dst[64] = m; dst[128] = l;
+    }
+  }
+  if (WpT) {
+    const int KT = (K + 15) >> 4, NB = (N + 31) >> 5;
+    if (blk < static_cast<long long>(KT) * NB) {
+      const int nb = static_cast<int>(blk / KT), tk = static_cast<int>(blk % KT);
+      const int k = tk * 16 + li, n0 = nb * 32 + 8 * g;
+      u32x4 h, m, l;
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const int n = n0 + 2 * pr;
+        const float x0 = k < K && n < N ? W[static_cast<long long>(n) * K + k] : 0.f;
+        const float x1 = k < K && n + 1 < N ? W[static_cast<long long>(n + 1) * K + k] : 0.f;
+        unsigned a, b, c;
+        split_pair(x0, x1, a, b, c);
+        h[pr] = a; m[pr] = b; l[pr] = c;
+      }
+      u32x4 *dst = WpT + (blk * 3) * 64 + lane;
+      dst[0] = h; dst[64] = m; dst[128] = l;
+    }
+  }
+}
+
+template <int NT>
+int launch_x3(const X3Params &p, hipStream_t st) {
+  constexpr int MT = 4;
+  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
+  const long long rows_per_wg = 4LL * MT * 16;
+  const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
+  // persistent workgroups, one per CU (512 registers per lane): the next tile's first k blocks are prefetched
+  // under the current tile's last MFMAs and epilogue
+  const unsigned grid = static_cast<unsigned>(wg_tiles < nsdp::num_cus() ? wg_tiles : nsdp::num_cus());
+  nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
+                          4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
+  if (pre == 0) hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 0>), dim3(grid), dim3(256), 0, st, p);
+  else if (pre == 1) hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 1>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 2>), dim3(grid), dim3(256), 0, st, p);
+  return nsdp::launch_status("linear_bf16x3_kernel");
+}
+
+}  // namespace
+
+namespace nsdp {
+void debug_set_x3(int value) { g_x3_dbg = value; }
+}  // namespace nsdp
+
+extern "C" {
+
+long long nsdp_packed_weight_bf16x3_bytes(int N, int K, int transposed) {
+  const long long blocks = transposed ? static_cast<long long>((N + 31) / 32) * ((K + 15) / 16)
+                                      : static_cast<long long>((K + 31) / 32) * ((N + 15) / 16);
+  return blocks * 3 * 1024;
+}
+
+int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, void *stream) {
+  if (N <= 0 || K <= 0) return 0;
+  NSDP_REQUIRE(W && (Wp || WpT), "pack_weight_bf16x3: null pointer");
+  const long long b0 = Wp ? nsdp_packed_weight_bf16x3_bytes(N, K, 0) / 3072 : 0;
+  const long long b1 = WpT ? nsdp_packed_weight_bf16x3_bytes(N, K, 1) / 3072 : 0;
+  const long long threads = (b0 > b1 ? b0 : b1) * 64;
+  hipStream_t st = nsdp::as_stream(stream);
+  hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)), dim3(256), 0, st, W, N, K,
+                     static_cast<u32x4 *>(Wp), static_cast<u32x4 *>(WpT));
+  return nsdp::launch_status("pack_bf16x3_kernel");
+}
+
+int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,
+                           const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                           int relu_in, int relu_out, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X && Wp && Y, "linear_bf16x3: null pointer");
+  NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
+  NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3: N=%d must be a multiple of 4 and <= 256", N);
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
+                 reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) |
+                 reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(out_mask)) & 15) == 0,
+               "linear_bf16x3: all operands must be 16-byte aligned");
+  X3Params p{X, Wp, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out, g_x3_dbg};
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 4) return launch_x3<4>(p, st);
+  if (nt <= 8) return launch_x3<8>(p, st);
+  if (nt <= 13) return launch_x3<13>(p, st);
+  return launch_x3<16>(p, st);
+}
+
+}  // extern "C"

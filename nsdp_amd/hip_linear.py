@@ -55,6 +55,34 @@ def _fwd_wp(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
     return y
 
 
+def pack_weight_x3(w, fwd=True, transposed=False):
+    """bf16x3 split packs of W [N,K] (nsdp_pack_weight_bf16x3): (Wp or None, WpT or None), uint8 buffers."""
+    N, K = w.shape
+    L = lib()
+    L.nsdp_packed_weight_bf16x3_bytes.restype = ctypes.c_longlong
+    wp = wpt = None
+    if fwd:
+        wp = torch.empty(int(L.nsdp_packed_weight_bf16x3_bytes(_ci(N), _ci(K), _ci(0))), dtype=torch.uint8, device=w.device)
+    if transposed:
+        wpt = torch.empty(int(L.nsdp_packed_weight_bf16x3_bytes(_ci(N), _ci(K), _ci(1))), dtype=torch.uint8, device=w.device)
+    with on_device(w):
+        check(L.nsdp_pack_weight_bf16x3(fptr(w, "weight"), _ci(N), _ci(K), optptr(wp), optptr(wpt), stream_ptr()),
+              "nsdp_pack_weight_bf16x3")
+    return wp, wpt
+
+
+def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
+    """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack."""
+    M, K = x2.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_bf16x3_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
+                                           optptr(mask), optptr(out_mask), fptr(y), _ll(M), _ci(N), _ci(K),
+                                           _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),
+              "nsdp_linear_bf16x3_f32")
+    return y
+
+
 def _wgrad(dy2, x2, mask, relu_x, want_db):
     M, N = dy2.shape
     K = x2.shape[1]
@@ -147,21 +175,41 @@ def _pad_cols(t, mult=4):
     return t if r == 0 else F.pad(t, (0, r))
 
 
-def _packs(w, owner, want_t):
-    """(Wp, WpT) fragment-major packs of w [N,K].  `owner` (the layer's nn.Parameter, or None) carries a
-    cache keyed by (storage pointer, version counter): optimizer steps and load_state_dict bump the version,
-    .to(device) changes the pointer.  Without an owner the pack is rebuilt per call (a reused address of a
-    freed temporary must never hit a stale pack)."""
+# Large layers run on the bf16 matrix pipe with the error-compensated 3-way split (nsdp_linear_bf16x3_f32, fp32
+# rounding-level accuracy, see csrc/gemm_bf16x3.hip); NSDP_BF16X3=0 keeps every layer on the exact-fp32 MFMA path.
+_USE_X3 = os.environ.get("NSDP_BF16X3", "1") != "0"
+_X3_MIN_ROWS = 32768
+
+
+def _x3_ok(M, N, K):
+    """Shape contract of the bf16x3 kernel: two k blocks at least, float4 rows, enough rows to fill the chip."""
+    return _USE_X3 and M >= _X3_MIN_ROWS and K > 32 and K % 4 == 0 and N % 4 == 0 and N <= 256
+
+
+def _packs(w, owner, kind, want_t):
+    """(pack of W, pack of W^T or None) of w [N,K]; kind 'wp' = fp32 fragment-major, 'x3' = bf16x3 planes.
+    `owner` (the layer's nn.Parameter, or None) carries a cache keyed by (storage pointer, version counter):
+    optimizer steps and load_state_dict bump the version, .to(device) changes the pointer.  Without an owner
+    the pack is rebuilt per call (a reused address of a freed temporary must never hit a stale pack)."""
+    cache = None
     if owner is not None:
         key = (w.data_ptr(), w._version)
-        ent = owner.__dict__.get("_nsdp_pack")
-        if ent is not None and ent[0] == key and (ent[2] is not None or not want_t):
-            return ent[1], ent[2]
+        cache = owner.__dict__.get("_nsdp_pack")
+        if cache is None or cache["key"] != key:
+            cache = owner.__dict__["_nsdp_pack"] = {"key": key}
+        ent = cache.get(kind)
+        if ent is not None and (ent[1] is not None or not want_t):
+            return ent
     wc = w if w.is_contiguous() else w.contiguous()
-    wp, wpt = pack_weight(wc, True, want_t)
-    if owner is not None:
-        owner.__dict__["_nsdp_pack"] = (key, wp, wpt)
-    return wp, wpt
+    ent = pack_weight_x3(wc, True, want_t) if kind == "x3" else pack_weight(wc, True, want_t)
+    if cache is not None:
+        cache[kind] = ent
+    return ent
+
+
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out):
+    fn = _fwd_x3 if kind == "x3" else _fwd_wp
+    return fn(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -178,12 +226,16 @@ class _LinearFn(torch.autograd.Function):
         if residual is not None:
             res2 = residual.reshape(-1, N)
             res2 = res2 if res2.is_contiguous() else res2.contiguous()
-        want_t = bool(ctx.needs_input_grad[0])                         # dX = dY' @ W needs the pack of W^T
-        wp, wpt = _packs(w, w_param, want_t)
-        y = _fwd_wp(x2, wp, N, b, res2, None, None, relu_in, relu_out)
+        M, Kp = x2.shape
+        want_t = bool(ctx.needs_input_grad[0])                         # dX = dY' @ W needs a pack of W^T
+        kind = "x3" if _x3_ok(M, N, Kp) else "wp"
+        kind_t = "x3" if _x3_ok(M, Kp, N) else "wp"                    # dX: Kp outputs, N is the reduction dim
+        wp = _packs(w, w_param, kind, want_t and kind_t == kind)[0]
+        wpt = _packs(w, w_param, kind_t, True)[1] if want_t else None
+        y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
-        ctx.x_shape, ctx.k_orig, ctx.n_out = x.shape, K, N
+        ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
         ctx.save_for_backward(x2, wpt, y if relu_out else None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -212,7 +264,7 @@ class _LinearFn(torch.autograd.Function):
                 dyk = _pad_cols(dy2)
                 mk = _pad_cols(y) if y is not None else None
             # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
-            dx = _fwd_wp(dyk, wpt, x2.shape[1], None, None, mk, x2 if ctx.relu_in else None, False, False)
+            dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, None, mk, x2 if ctx.relu_in else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
