@@ -149,6 +149,15 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
                           float *db, long long M, int N, int K, int accumulate, float *workspace,
                           size_t workspace_bytes, void *stream);
 
+/* nsdp_linear_wgrad_f32 on the bf16 matrix pipe (error-compensated 3-way split of both operands, fp32 rounding-level
+ * accuracy, csrc/wgrad_bf16x3.hip).  Same contract; shapes must satisfy nsdp_linear_wgrad_bf16x3_supported
+ * (M >= 1024, 16 < N,K <= 208, tensors below 4 GB), workspace >= nsdp_linear_wgrad_bf16x3_workspace_bytes. */
+int nsdp_linear_wgrad_bf16x3_supported(long long M, int N, int K);
+size_t nsdp_linear_wgrad_bf16x3_workspace_bytes(long long M, int N, int K);
+int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                                 float *db, long long M, int N, int K, int accumulate, float *workspace,
+                                 size_t workspace_bytes, void *stream);
+
 /* ----------------------------------------------------------------------------------------------
  * Point-Transformer vector attention glue (everything between the dense layers of one block), replacing
  * the materialised ATen gather / sub / add / softmax / einsum sequence of model/encoder/blocks.py:104-124,

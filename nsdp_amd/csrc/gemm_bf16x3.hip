@@ -168,6 +168,9 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
   };
 
   Planes cur, nxt;
+  if (p.dbg & 16) {   // experiment: stagger the persistent workgroups so that their epilogue store bursts do not convoy
+    for (int i = 0; i < static_cast<int>(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // prologue (once per workgroup): block 0 of the first tile, split; block 1 in flight
   stage(0, 0);
   xissue(xa, ma, 0);

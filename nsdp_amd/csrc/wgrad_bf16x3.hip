@@ -1,0 +1,487 @@
+// Weight gradient of a dense layer on the bf16 matrix pipe with the error-compensated 3-way split of
+// gemm_bf16x3.hip (fp32 rounding-level accuracy, 6 bf16 MFMA products per fp32 product):
+//
+//     dW[N,K] = pre(dY)[M,N]^T pre(X)[M,K],   db[N] = colsum(pre(dY))
+//
+// Rows are the MFMA reduction dimension and BOTH operands are activations, so both must be split at run time.
+// One persistent workgroup (4 waves, one per SIMD) walks a contiguous range of 32-row blocks:
+//
+//   produce  all 256 lanes cooperatively load the [32 rows x (N + K) columns] slab of the next block (a lane
+//            owns 8 consecutive rows of ONE column per slot: consecutive lanes = consecutive columns, 256 B
+//            per load instruction), apply the ReLU mask / ReLU, split into three bf16 planes on the VALU and
+//            write them to LDS directly in MFMA fragment order (one ds_write_b128 per plane and slot) --
+//            every value is loaded and split exactly once per workgroup;
+//   consume  wave (a, b) owns the [n tiles of half a] x [k tiles of half b] quarter of dW (<= 7 x 7 tiles =
+//            196 accumulator registers), reads its A (dY) and B (X) fragments back with conflict-free
+//            ds_read_b128 and issues 6 MFMAs per tile pair and block.
+//
+// Two LDS plane buffers (2 x (NT + KT) x 3 KiB <= 156 KiB) and one barrier per block; the next block's
+// global loads are issued one block ahead and its split is interleaved with the first MFMA steps.  Partial
+// results go to a workspace as fragment-ordered float4 (one partial dW per workgroup) and are summed by a
+// second kernel in fixed order (deterministic, no atomics).
+#include <type_traits>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+struct WgX3Params {
+  const float *dY, *X, *mask;
+  int relu_x;
+  float *ws;            // [S][NT*KT*256 + NT*16] partials (fragment order, then db)
+  long long M;
+  int N, K;
+  long long blocks_per_wg;   // 32-row blocks per workgroup
+  int want_db;
+};
+
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x0, x1}, bf16x2));
+  const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{r0, r1}, bf16x2));
+  const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{s0, s1}, bf16x2));
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ const float *sgpr_ptr(const float *q) {   // pin a wave-uniform pointer into SGPRs
+  const unsigned long long u = reinterpret_cast<unsigned long long>(q);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u));
+  const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+  return reinterpret_cast<const float *>((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// hand-placed memory operations (the compiler sinks ordinary loads to their first use; see decoder_fused.hip)
+__device__ __forceinline__ void gload(float &dst, const float *uniform_base, unsigned byte_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform_base));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read(u32x4 &dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void lds_wait3(u32x4 &a, u32x4 &b, u32x4 &c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+
+// NTA / KTB: 16-column tiles of dY / X.  Wave (a, b) = (wave >> 1, wave & 1) owns n tiles [a TA, a TA + TA) and
+// k tiles [b TB, b TB + TB).
+template <int NTA, int KTB, bool MASK>
+__global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
+  constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
+  constexpr int kTiles = NTA + KTB;
+  constexpr int kColsA = NTA * 16, kColsB = KTB * 16;
+  constexpr int RA = (4 * kColsA + 255) / 256, RB = (4 * kColsB + 255) / 256;   // producer slots per lane
+  // two plane buffers + one spare tile (fragment reads of the tile past a wave's range land there)
+  __shared__ __attribute__((aligned(16))) u32x4 planes[2 * kTiles * 3 * 64 + 3 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 1, wb = wave & 1;
+  const int N = p.N, K = p.K;
+  // uniform (SGPR) bases of the asm loads
+  const float *const dYp = sgpr_ptr(p.dY), *const Xp = sgpr_ptr(p.X), *const Mp = sgpr_ptr(p.mask);
+  const long long Mrows = p.M;
+  const long long mb0 = static_cast<long long>(blockIdx.x) * p.blocks_per_wg;
+  const long long mb_all = (p.M + 31) >> 5;
+  long long mb1 = mb0 + p.blocks_per_wg;
+  mb1 = mb1 < mb_all ? mb1 : mb_all;
+  const int nblk = static_cast<int>(mb1 - mb0);    // > 0 by construction of the grid
+
+  // ---- producer slot geometry: slot s = tid + 256 r  ->  row group g' = s / cols, column = s % cols ----
+  // A slot of the padding tail of the last round (s >= 4 cols) aliases the same lane's slot of the round before:
+  // it loads, splits and writes exactly the same values to the same place.  Three registers per slot:
+  unsigned offA[RA], offB[RB];       // byte offset of (row 32 mb + 8 g', column) in dY / X, mb = next block to load
+  unsigned ldsA[RA], ldsB[RB];       // byte offset of the slot's fragment entry inside a plane buffer
+  int g8A[RA], g8B[RB];              // 8 g' if the column is inside the matrix, else a huge value: row j of the
+                                     // slot is valid  <=>  g8 + j < rows of the block
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    int s = tid + 256 * r;
+    s = s < 4 * kColsA ? s : s - 256;
+    const int gp = s / kColsA, col = s % kColsA;
+    const int colc = col < N ? col : (N - 1);
+    g8A[r] = col < N ? 8 * gp : (1 << 20);
+    offA[r] = static_cast<unsigned>(((mb0 * 32 + 8 * gp) * N + colc) * 4);
+    ldsA[r] = static_cast<unsigned>((((col >> 4) * 3) * 64 + 16 * gp + (col & 15)) * 16);
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    int s = tid + 256 * r;
+    s = s < 4 * kColsB ? s : s - 256;
+    const int gp = s / kColsB, col = s % kColsB;
+    const int colc = col < K ? col : (K - 1);
+    g8B[r] = col < K ? 8 * gp : (1 << 20);
+    offB[r] = static_cast<unsigned>(((mb0 * 32 + 8 * gp) * K + colc) * 4);
+    ldsB[r] = static_cast<unsigned>(((NTA * 3 + (col >> 4) * 3) * 64 + 16 * gp + (col & 15)) * 16);
+  }
+  const unsigned strideA = static_cast<unsigned>(N) * 4u, strideB = static_cast<unsigned>(K) * 4u;
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&planes[0])));
+  constexpr unsigned kBufBytes = kTiles * 3 * 1024;
+
+  float rawA[RA][8], rawM[MASK ? RA : 1][8], rawB[RB][8];
+  float dbsum[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) dbsum[r] = 0.f;
+
+  // rows past M (only the very last block of the matrix can have them) are re-read from row M-1 and zeroed by
+  // `rows_left` in the split; all other blocks take the unclamped path (one add per load)
+  auto issue_a = [&](int r, long long mb) {
+    if (mb * 32 + 32 <= Mrows) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned off = offA[r] + static_cast<unsigned>(j) * strideA;
+        gload(rawA[r][j], dYp, off);
+        if (MASK) gload(rawM[r][j], Mp, off);
+      }
+    } else {
+      const int last_row = static_cast<int>(Mrows - 1 - mb * 32);      // >= 0
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g8 = g8A[r] & 31;                              // (padding columns: any in-range row will do)
+        int rr = g8 + j;
+        rr = rr <= last_row ? rr : last_row;
+        const unsigned off = offA[r] + static_cast<unsigned>(rr - g8) * strideA;
+        gload(rawA[r][j], dYp, off);
+        if (MASK) gload(rawM[r][j], Mp, off);
+      }
+    }
+  };
+  auto issue_b = [&](int r, long long mb) {
+    if (mb * 32 + 32 <= Mrows) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gload(rawB[r][j], Xp, offB[r] + static_cast<unsigned>(j) * strideB);
+    } else {
+      const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int g8 = g8B[r] & 31;
+        int rr = g8 + j;
+        rr = rr <= last_row ? rr : last_row;
+        gload(rawB[r][j], Xp, offB[r] + static_cast<unsigned>(rr - g8) * strideB);
+      }
+    }
+  };
+  auto issue = [&](long long mb) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) issue_a(r, mb);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) issue_b(r, mb);
+  };
+  auto advance = [&]() {   // offsets always point at the block whose loads are issued next
+#pragma unroll
+    for (int r = 0; r < RA; ++r) offA[r] += 32u * strideA;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) offB[r] += 32u * strideB;
+  };
+  auto gwait = [&]() {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA[r][0]), "+v"(rawA[r][1]), "+v"(rawA[r][2]), "+v"(rawA[r][3]),
+                   "+v"(rawA[r][4]), "+v"(rawA[r][5]), "+v"(rawA[r][6]), "+v"(rawA[r][7]));
+      if (MASK)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawM[r][0]), "+v"(rawM[r][1]), "+v"(rawM[r][2]), "+v"(rawM[r][3]),
+                     "+v"(rawM[r][4]), "+v"(rawM[r][5]), "+v"(rawM[r][6]), "+v"(rawM[r][7]));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawB[r][0]), "+v"(rawB[r][1]), "+v"(rawB[r][2]), "+v"(rawB[r][3]),
+                   "+v"(rawB[r][4]), "+v"(rawB[r][5]), "+v"(rawB[r][6]), "+v"(rawB[r][7]));
+  };
+  // split one slot and write its three fragment entries; rows_left = valid rows of the block (32, or fewer in
+  // the last block of the matrix)
+  auto produce_a = [&](int r, unsigned buf_off, int rows_left, bool real) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = rawA[r][j];
+      if (MASK) x = rawM[r][j] > 0.f ? x : 0.f;
+      v[j] = g8A[r] + j < rows_left ? x : 0.f;
+    }
+    const float colsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    dbsum[r] += real ? colsum : 0.f;     // (the split after the last block works on stale registers)
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned a, b, c;
+      split_pair(v[2 * q], v[2 * q + 1], a, b, c);
+      h[q] = a; m[q] = b; l[q] = c;
+    }
+    char *dst = reinterpret_cast<char *>(&planes[0]) + buf_off + ldsA[r];
+    *reinterpret_cast<u32x4 *>(dst) = h;
+    *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+    *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+  };
+  auto produce_b = [&](int r, unsigned buf_off, int rows_left) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = rawB[r][j];
+      if (p.relu_x) x = fmaxf(x, 0.f);
+      v[j] = g8B[r] + j < rows_left ? x : 0.f;
+    }
+    u32x4 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      unsigned a, b, c;
+      split_pair(v[2 * q], v[2 * q + 1], a, b, c);
+      h[q] = a; m[q] = b; l[q] = c;
+    }
+    char *dst = reinterpret_cast<char *>(&planes[0]) + buf_off + ldsB[r];
+    *reinterpret_cast<u32x4 *>(dst) = h;
+    *reinterpret_cast<u32x4 *>(dst + 1024) = m;
+    *reinterpret_cast<u32x4 *>(dst + 2048) = l;
+  };
+  auto rows_in = [&](long long mb) {
+    const long long left = p.M - mb * 32;
+    return static_cast<int>(left < 32 ? left : 32);
+  };
+
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: block 0 into buffer 0, block 1 in flight
+  issue(mb0);
+  gwait();
+  {
+    const int rl = rows_in(mb0);
+#pragma unroll
+    for (int r = 0; r < RA; ++r) produce_a(r, 0u, rl, true);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) produce_b(r, 0u, rl);
+  }
+  advance();
+  if (nblk > 1) issue(mb0 + 1);
+  advance();
+  gwait();
+  __syncthreads();
+
+  // consumer fragment addresses: tile t, plane pl of a buffer at ((t * 3 + pl) * 64 + lane) * 16
+  const unsigned fragA = lds_base + static_cast<unsigned>((wa * TA * 3 * 64 + lane) * 16);
+  const unsigned fragB = lds_base + static_cast<unsigned>(((NTA + wb * TB) * 3 * 64 + lane) * 16);
+  constexpr int kSlots = RA + RB;
+  constexpr int kAH = 4;                                // n tiles whose A fragments are held at a time
+  constexpr int kPasses = (TA + kAH - 1) / kAH;
+  static_assert(kSlots <= kPasses * TB, "one producer slot per consumer step");
+
+  for (int ib = 0; ib < nblk; ++ib) {
+    const unsigned buf = static_cast<unsigned>(ib & 1) * kBufBytes, nbuf = kBufBytes - buf;
+    const int rl_next = rows_in(mb0 + ib + 1 < mb_all ? mb0 + ib + 1 : mb_all - 1);
+    // A fragments are held for at most kAH n tiles at a time (TA > kAH: two passes over the k tiles; the extra
+    // LDS reads of B are cheap, 84 live fragment registers are not).  Global step index st = pass * TB + b.
+    static_for<0, kPasses>([&](auto P) {
+      constexpr int pass = decltype(P)::value;
+      constexpr int a0 = pass * kAH;
+      constexpr int na = (TA - a0) < kAH ? (TA - a0) : kAH;
+      u32x4 ah[na], am[na], al[na];
+      static_for<0, na>([&](auto I) {
+        constexpr int a = decltype(I)::value;
+        lds_read<(a0 + a) * 3072>(ah[a], fragA + buf); lds_read<(a0 + a) * 3072 + 1024>(am[a], fragA + buf);
+        lds_read<(a0 + a) * 3072 + 2048>(al[a], fragA + buf);
+      });
+      u32x4 bh, bm, bl;
+      lds_read<0>(bh, fragB + buf); lds_read<1024>(bm, fragB + buf); lds_read<2048>(bl, fragB + buf);
+      static_for<0, na>([&](auto I) {
+        constexpr int a = decltype(I)::value;
+        lds_wait3(ah[a], am[a], al[a]);
+      });
+      lds_wait3(bh, bm, bl);
+      static_for<0, TB>([&](auto I) {
+        constexpr int b = decltype(I)::value;
+        constexpr int st = pass * TB + b;
+        u32x4 nh, nm, nl;
+        if constexpr (b + 1 < TB) {
+          lds_read<(b + 1) * 3072>(nh, fragB + buf); lds_read<(b + 1) * 3072 + 1024>(nm, fragB + buf);
+          lds_read<(b + 1) * 3072 + 2048>(nl, fragB + buf);
+        }
+        // the next block's split, one producer slot per step (VALU + 3 LDS writes interleaved with this step's
+        // MFMAs; unconditional: after the last block it re-splits stale registers into the unused buffer).  A
+        // slot's raw registers are free as soon as it is split: the loads of the block after next follow
+        // immediately and have a whole block of MFMAs to land.
+        if constexpr (st < RA) {
+          produce_a(st, nbuf, rl_next, ib + 1 < nblk);
+          if (ib + 2 < nblk) issue_a(st, mb0 + ib + 2);
+        } else if constexpr (st < kSlots) {
+          produce_b(st - RA, nbuf, rl_next);
+          if (ib + 2 < nblk) issue_b(st - RA, mb0 + ib + 2);
+        }
+        if constexpr (st == kSlots - 1) advance();
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(al[a], bh, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bl, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bm, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bh, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bm, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bh, acc[a0 + a][b]);
+        if constexpr (st < kSlots) {
+#pragma unroll
+          for (int i = 0; i < 6 * na; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < na; ++a) asm volatile("" : "+a"(acc[a0 + a][b]));   // pin the MFMAs to this step
+        if constexpr (b + 1 < TB) {
+          lds_wait3(nh, nm, nl);
+          bh = nh; bm = nm; bl = nl;
+        }
+      });
+    });
+    gwait();            // the block after next has landed in the raw registers
+    __syncthreads();    // next buffer complete, this buffer free
+  }
+
+  // ---- partial results: fragment-ordered float4 per (n tile, k tile), then the bias-gradient partial ----
+  float *wsp = p.ws + static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(NTA) * KTB * 256 + NTA * 16);
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int ta = wa * TA + a, tb = wb * TB + b;
+      if (ta < NTA && tb < KTB) {
+        const f32x4 v = acc[a][b];
+        *reinterpret_cast<float4 *>(wsp + (static_cast<size_t>(ta) * KTB + tb) * 256 + lane * 4) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  if (p.want_db) {
+    // every slot s = (row group, column) has exactly one owner: park the per-slot sums in LDS and add the four
+    // row groups of a column in fixed order (deterministic)
+    float *dbl = reinterpret_cast<float *>(&planes[0]);       // all plane reads are behind the last barrier
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int s = tid + 256 * r;
+      if (s < 4 * kColsA) dbl[s] = dbsum[r];
+    }
+    __syncthreads();
+    for (int c = tid; c < kColsA; c += 256)
+      wsp[static_cast<size_t>(NTA) * KTB * 256 + c] = (dbl[c] + dbl[kColsA + c]) + (dbl[2 * kColsA + c] + dbl[3 * kColsA + c]);
+  }
+}
+
+// dW[n][k] = sum over the S partials of element (n, k): accumulator (tile n/16, tile k/16), lane 16 (n%16)/4 + k%16,
+// register (n%16)%4  (C/D layout of the MFMA: row = 4 (lane >> 4) + reg, column = lane & 15)
+__global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_kernel(const float *__restrict__ ws, int S, int NTA, int KTB,
+                                                                  int N, int K, float *__restrict__ dW,
+                                                                  float *__restrict__ db, int accumulate) {
+  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  const long long nw = static_cast<long long>(N) * K;
+  const size_t stride = static_cast<size_t>(NTA) * KTB * 256 + NTA * 16;
+  size_t idx;
+  if (e < nw) {
+    const int n = static_cast<int>(e / K), k = static_cast<int>(e % K);
+    const int nl = n & 15, kl = k & 15;
+    idx = (static_cast<size_t>(n >> 4) * KTB + (k >> 4)) * 256 + (16 * (nl >> 2) + kl) * 4 + (nl & 3);
+  } else if (e < nw + N && db) {
+    idx = static_cast<size_t>(NTA) * KTB * 256 + (e - nw);
+  } else {
+    return;
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    s0 += ws[idx + (s + 0) * stride]; s1 += ws[idx + (s + 1) * stride];
+    s2 += ws[idx + (s + 2) * stride]; s3 += ws[idx + (s + 3) * stride];
+  }
+  for (; s < S; ++s) s0 += ws[idx + s * stride];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (e < nw) dW[e] = accumulate ? dW[e] + t : t;
+  else db[e - nw] = accumulate ? db[e - nw] + t : t;
+}
+
+struct X3Plan {
+  int nta, ktb, grid;
+  long long blocks_per_wg;
+  size_t ws_floats;
+};
+
+X3Plan plan_x3(long long M, int N, int K) {
+  X3Plan pl;
+  pl.nta = (N + 15) / 16;
+  pl.ktb = (K + 15) / 16;
+  // instantiated tile classes: 8 (<= 128 columns) and 13 (<= 208)
+  pl.nta = pl.nta <= 8 ? 8 : 13;
+  pl.ktb = pl.ktb <= 8 ? 8 : 13;
+  const long long mb_all = (M + 31) / 32;
+  long long grid = nsdp::num_cus();
+  if (grid > mb_all / 4) grid = mb_all / 4 > 0 ? mb_all / 4 : 1;     // at least 4 blocks per workgroup
+  pl.blocks_per_wg = (mb_all + grid - 1) / grid;
+  pl.grid = static_cast<int>((mb_all + pl.blocks_per_wg - 1) / pl.blocks_per_wg);
+  pl.ws_floats = static_cast<size_t>(pl.grid) * (static_cast<size_t>(pl.nta) * pl.ktb * 256 + pl.nta * 16);
+  return pl;
+}
+
+template <int NTA, int KTB>
+void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
+  if (p.mask) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true>), dim3(grid), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false>), dim3(grid), dim3(256), 0, st, p);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsdp_linear_wgrad_bf16x3_supported(long long M, int N, int K) {
+  return M >= 1024 && N > 16 && K > 16 && N <= 208 && K <= 208 &&
+         static_cast<double>(M) * (N > K ? N : K) * 4.0 < 4.0e9;      // 32-bit byte offsets inside a tensor
+}
+
+size_t nsdp_linear_wgrad_bf16x3_workspace_bytes(long long M, int N, int K) {
+  if (M <= 0) return 0;
+  return plan_x3(M, N, K).ws_floats * sizeof(float);
+}
+
+int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                                 float *db, long long M, int N, int K, int accumulate, float *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_supported(M, N, K),
+               "linear_wgrad_bf16x3: shape M=%lld N=%d K=%d outside the kernel's range", M, N, K);
+  NSDP_REQUIRE(dY && X && dW && workspace, "linear_wgrad_bf16x3: null pointer");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K),
+               "linear_wgrad_bf16x3: workspace too small");
+  const X3Plan pl = plan_x3(M, N, K);
+  WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr};
+  hipStream_t st = nsdp::as_stream(stream);
+  {
+    nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
+    if (pl.nta == 8 && pl.ktb == 8) launch_wg<8, 8>(p, pl.grid, st);
+    else if (pl.nta == 8) launch_wg<8, 13>(p, pl.grid, st);
+    else if (pl.ktb == 8) launch_wg<13, 8>(p, pl.grid, st);
+    else launch_wg<13, 13>(p, pl.grid, st);
+    const int rc = nsdp::launch_status("wgrad_bf16x3_kernel");
+    if (rc) return rc;
+  }
+  const long long ne = static_cast<long long>(N) * K + N;
+  hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 255) / 256)), dim3(256), 0, st,
+                     workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
+  return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
+}
+
+}  // extern "C"

@@ -87,6 +87,8 @@ def _wgrad(dy2, x2, mask, relu_x, want_db):
     M, N = dy2.shape
     K = x2.shape[1]
     L = lib()
+    if _USE_X3 and M >= _X3_MIN_ROWS_WGRAD and L.nsdp_linear_wgrad_bf16x3_supported(_ll(M), _ci(N), _ci(K)):
+        return _wgrad_x3(dy2, x2, mask, relu_x, want_db)
     L.nsdp_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_linear_wgrad_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
@@ -96,6 +98,23 @@ def _wgrad(dy2, x2, mask, relu_x, want_db):
         check(L.nsdp_linear_wgrad_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
                                       optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws),
                                       ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_wgrad_f32")
+    return dw, db
+
+
+def _wgrad_x3(dy2, x2, mask, relu_x, want_db):
+    """_wgrad on the bf16 matrix pipe (3-way split of both operands, nsdp_linear_wgrad_bf16x3_f32)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    L = lib()
+    L.nsdp_linear_wgrad_bf16x3_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(_ll(M), _ci(N), _ci(K)))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    with on_device(dy2):
+        check(L.nsdp_linear_wgrad_bf16x3_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
+                                             optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws),
+                                             ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_wgrad_bf16x3_f32")
     return dw, db
 
 
@@ -179,6 +198,7 @@ def _pad_cols(t, mult=4):
 # rounding-level accuracy, see csrc/gemm_bf16x3.hip); NSDP_BF16X3=0 keeps every layer on the exact-fp32 MFMA path.
 _USE_X3 = os.environ.get("NSDP_BF16X3", "1") != "0"
 _X3_MIN_ROWS = 32768
+_X3_MIN_ROWS_WGRAD = 2048      # the split-row wgrad kernel already wins at a few thousand rows
 
 
 def _x3_ok(M, N, K):
