@@ -1,0 +1,145 @@
+"""bf16x3 split-precision dense kernels (nsdp_linear_bf16x3_f32, nsdp_linear_wgrad_bf16x3_f32) and the fragment-major
+weight packs, through the C ABI, against an fp64 reference of the same op.  The bar is the exact-fp32 MFMA kernel's
+own error: the 3-way split must not be measurably less accurate (tolerances are stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _rand(g, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _ref64(x, w, b, res, mask, out_mask, relu_in, relu_out):
+    xi = x.double()
+    if mask is not None:
+        xi = xi * (mask > 0)
+    if relu_in:
+        xi = F.relu(xi)
+    y = xi @ w.double().t()
+    if b is not None:
+        y = y + b.double()
+    if res is not None:
+        y = y + res.double()
+    if relu_out:
+        y = F.relu(y)
+    if out_mask is not None:
+        y = y * (out_mask > 0)
+    return y
+
+
+X3_CASES = [  # (M, K, N, bias, residual, mask, out_mask, relu_in, relu_out)
+    (256, 64, 64, True, False, False, False, False, False),          # one workgroup tile, two k blocks
+    (1000, 200, 200, True, False, False, False, False, True),        # ragged rows, ragged k block (200 = 6.25 x 32)
+    (4099, 120, 120, False, True, False, False, False, False),       # residual as accumulator init, N % 16 != 0
+    (70001, 128, 256, True, False, True, False, False, False),       # mask prologue, N = 256 (16 tiles), many tiles per workgroup
+    (33000, 256, 128, True, False, False, True, False, False),       # out_mask epilogue
+    (9000, 200, 128, True, True, False, False, True, True),          # relu on both sides + residual
+    (300, 36, 200, True, False, False, False, False, False),         # K just above one k block
+]
+
+
+@pytest.mark.parametrize("M,K,N,bias,res,mask,omask,relu_in,relu_out", X3_CASES)
+def test_linear_bf16x3_matches_fp64(M, K, N, bias, res, mask, omask, relu_in, relu_out):
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(M + 13 * K + 101 * N)
+    x, w = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5)
+    b = _rand(g, N) if bias else None
+    r = _rand(g, M, N) if res else None
+    m = _rand(g, M, K) if mask else None
+    o = _rand(g, M, N) if omask else None
+    ref = _ref64(x, w, b, r, m, o, relu_in, relu_out)
+    y3 = hip_linear._fwd_x3(x, hip_linear.pack_weight_x3(w)[0], N, b, r, m, o, relu_in, relu_out)
+    y32 = hip_linear._fwd_wp(x, hip_linear.pack_weight(w)[0], N, b, r, m, o, relu_in, relu_out)
+    scale = float(ref.abs().max())
+    e3, e32 = float((y3.double() - ref).abs().max()) / scale, float((y32.double() - ref).abs().max()) / scale
+    # fp32 rounding level: 2^-24 = 6e-8 per operation, sqrt(K)-ish growth over the reduction
+    assert e3 <= 1.5e-6, (e3, e32)
+    assert e3 <= 2.0 * e32 + 2e-7, (e3, e32)      # not measurably worse than the exact-fp32 MFMA chain
+
+
+def test_linear_bf16x3_transposed_pack_is_dx():
+    """dX = dY @ W through the pack of W^T (backward operand), ragged N as the reduction dimension."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(5)
+    M, N, K = 5000, 200, 120
+    dy, w = _rand(g, M, N), _rand(g, N, K)
+    wpt = hip_linear.pack_weight_x3(w, False, True)[1]
+    dx = hip_linear._fwd_x3(dy, wpt, K, None, None, None, None, False, False)
+    ref = dy.double() @ w.double()
+    assert float((dx.double() - ref).abs().max()) / float(ref.abs().max()) <= 1.5e-6
+
+
+def test_fragment_major_pack_kernel_is_exact_against_rowmajor_kernel():
+    """nsdp_linear_wp_f32 (packed W) must be bit-identical to nsdp_linear_f32 (row-major W): same MFMA chain."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for (M, K, N) in [(777, 200, 200), (64, 4, 120), (5000, 128, 3), (33, 256, 256)]:
+        x, w, b = _rand(g, M, K), _rand(g, N, K), _rand(g, N)
+        wp, wpt = hip_linear.pack_weight(w, True, True)
+        assert torch.equal(hip_linear._fwd_wp(x, wp, N, b, None, None, None, False, True),
+                           hip_linear._fwd(x, w, b, None, None, None, False, True))
+        if N % 4 == 0:
+            dy = _rand(g, M, N)
+            assert torch.equal(hip_linear._fwd_wp(dy, wpt, K, None, None, None, None, False, False),
+                               hip_linear._fwd(dy, w.t().contiguous(), None, None, None, None, False, False))
+
+
+WG_CASES = [  # (M, N, K, mask, relu_x)
+    (2048, 200, 200, False, False),
+    (4099, 120, 128, True, True),        # ragged last 32-row block, both prologues
+    (70000, 128, 200, True, False),      # mixed tile classes (8 x 13)
+    (50000, 200, 120, False, True),      # (13 x 8)
+    (33333, 64, 64, False, False),
+]
+
+
+@pytest.mark.parametrize("M,N,K,mask,relu_x", WG_CASES)
+def test_wgrad_bf16x3_matches_fp64(M, N, K, mask, relu_x):
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    dy, x = _rand(g, M, N), _rand(g, M, K)
+    m = _rand(g, M, N) if mask else None
+    dw, db = hip_linear._wgrad_x3(dy, x, m, relu_x, True)
+    dyp = dy.double() * (m > 0) if mask else dy.double()
+    xp = F.relu(x.double()) if relu_x else x.double()
+    ref_w, ref_b = dyp.t() @ xp, dyp.sum(0)
+    # rows are the reduction dimension: fp32 accumulation over M terms (partials per workgroup, then a fixed-order sum)
+    assert float((dw.double() - ref_w).abs().max()) / float(ref_w.abs().max()) <= 3e-6
+    assert float((db.double() - ref_b).abs().max()) / float(ref_b.abs().max()) <= 3e-6
+    dw2, db2 = hip_linear._wgrad_x3(dy, x, m, relu_x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # deterministic
+
+
+def test_bf16x3_rejects_shapes_outside_its_contract():
+    from nsdp_amd import _lib, hip_linear
+    x = torch.randn(128, 32, device=DEV)
+    w = torch.randn(64, 32, device=DEV)
+    with pytest.raises(_lib.NsdpHipError):         # K must span two k blocks
+        hip_linear._fwd_x3(x, hip_linear.pack_weight_x3(w)[0], 64, None, None, None, None, False, False)
+    with pytest.raises(_lib.NsdpHipError):         # N = 256 > 208 columns
+        hip_linear._wgrad_x3(torch.randn(4096, 256, device=DEV), torch.randn(4096, 64, device=DEV), None, False, True)
+
+
+def test_autograd_routes_large_layers_through_bf16x3_and_matches_fp32_path():
+    """End to end through hip_linear.linear: a layer large enough for the split path, against the exact path."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(3)
+    M, K, N = 40000, 200, 200
+    x0, w0, b0 = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    go = _rand(g, M, N)
+    outs = []
+    for use in (True, False):
+        hip_linear._USE_X3 = use
+        try:
+            x, w, b = (t.clone().requires_grad_(True) for t in (x0, w0, b0))
+            y = hip_linear.linear(x, w, b)      # (no ReLU: a sign flip of y ~ 0 between the paths would change dX)
+            outs.append((y.detach(),) + torch.autograd.grad(y, (x, w, b), go))
+        finally:
+            hip_linear._USE_X3 = True
+    for a, e in zip(*outs):
+        s = float(e.abs().max())
+        assert float((a - e).abs().max()) <= 4e-6 * s
