@@ -46,8 +46,8 @@ struct X3Params {
   long long M;
   int N, K;
   int relu_in, relu_out;
-  int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, 1 no activation loads in the loop,
-            // 3 no stores -- wrong results, timing only
+  int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores -- wrong results,
+            // timing only
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -90,8 +90,12 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
 
 template <int MT, int NT, int PRE>
 __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
-  static_assert(MT == 4, "the step schedule below is written for four row tiles per wave");
+  // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
+  // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
+  // in LDS next to the weights and keeps the register path.
+  constexpr bool kXLds = PRE != 1;
   __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][NT * 3 * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? 4 : 1][kXLds ? MT * 2 * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
@@ -129,31 +133,42 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
   constexpr unsigned kBufBytes = NT * 3 * 1024;
 
   // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 8 g + 4 half ..)
-  f32x4 raw[MT][2], rawm[PRE == 1 ? MT : 1][2];
-  auto xissue = [&](const float *const *x, const float *const *m, int kb) {
+  f32x4 raw[kXLds ? 1 : MT][2], rawm[kXLds ? 1 : MT][2];
+  auto xissue = [&](const float *const *x, const float *const *m, int kb, unsigned xb) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         int ko = kb * 32 + 8 * g + 4 * hf;
         ko = ko < K ? ko : (K - 4);     // past the row end: re-read in-row data (the packed weights are zero there)
-        xload(raw[mt][hf], x[mt] + ko);
-        if (PRE == 1) xload(rawm[mt][hf], m[mt] + ko);
+        if constexpr (kXLds) {
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(x[mt] + ko), (lds_ptr_t)(&xbuf[xb][wave][(mt * 2 + hf) * 64]), 16, 0, 0);
+        } else {
+          xload(raw[mt][hf], x[mt] + ko);
+          xload(rawm[mt][hf], m[mt] + ko);
+        }
       }
   };
-  auto xwait = [&]() {   // all outstanding vector memory operations; the raw registers become data-dependent on it
+  auto xwait = [&]() {   // all outstanding vector memory operations (DMA included)
+    if constexpr (kXLds) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {   // the raw registers become data-dependent on the wait
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[mt][0]), "+v"(raw[mt][1]));
-      if (PRE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawm[mt][0]), "+v"(rawm[mt][1]));
+      for (int mt = 0; mt < MT; ++mt) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[mt][0]), "+v"(raw[mt][1]));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawm[mt][0]), "+v"(rawm[mt][1]));
+      }
     }
   };
   struct Planes {
     u32x4 h[MT], m[MT], l[MT];
   };
-  auto convert_pair = [&](Planes &pl, int mt, int pr) {   // pr = 0..3: values 2 pr, 2 pr + 1 of the lane's 8
-    f32x4 v = raw[mt][pr >> 1];
-    if (PRE == 1) {
+  auto convert_pair = [&](Planes &pl, int mt, int pr, unsigned xb) {   // pr = 0..3: values 2 pr, 2 pr + 1 of the lane's 8
+    f32x4 v;
+    if constexpr (kXLds) {
+      v = __builtin_bit_cast(f32x4, xbuf[xb][wave][(mt * 2 + (pr >> 1)) * 64 + lane]);
+    } else {
+      v = raw[mt][pr >> 1];
       const f32x4 mk = rawm[mt][pr >> 1];
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.f ? v[c] : 0.f;
@@ -168,26 +183,32 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
   };
 
   Planes cur, nxt;
-  if (p.dbg & 16) {   // experiment: stagger the persistent workgroups so that their epilogue store bursts do not convoy
-    for (int i = 0; i < static_cast<int>(blockIdx.x & 7); ++i) __builtin_amdgcn_s_sleep(127);
+  // stagger the persistent workgroups by eighths of a tile time (~640 cycles per k block): all of them run the same
+  // program on the same amount of work, and without it their epilogue store bursts hit HBM at the same moments
+  // (measured: -7 % time on the 1.8 M-row layers).  Only worth it when a workgroup has several tiles to go.
+  if (wg_tiles >= 4 * stride) {
+    for (int i = 0; i < static_cast<int>(blockIdx.x & 7) * KB; ++i) __builtin_amdgcn_s_sleep(10);
   }
   // prologue (once per workgroup): block 0 of the first tile, split; block 1 in flight
   stage(0, 0);
-  xissue(xa, ma, 0);
+  xissue(xa, ma, 0, 0u);
+  if constexpr (kXLds) xissue(xa, ma, 1, 1u);
   xwait();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr) convert_pair(cur, mt, pr);
-  xissue(xa, ma, 1);
-  xwait();
+    for (int pr = 0; pr < 4; ++pr) convert_pair(cur, mt, pr, 0u);
+  if constexpr (!kXLds) {
+    xissue(xa, ma, 1, 0u);
+    xwait();
+  }
   __syncthreads();
 
   // the split of the next k block's activations is spread over the first kConvSteps n-tile steps of a block
   constexpr int kConvSteps = NT > 4 ? 4 : NT - 1;
   constexpr int kPairs = MT * 4;
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
-  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 23) / 24;
+  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 6 * MT - 1) / (6 * MT);
 
   unsigned gs = 0;   // running k block count: weight buffer parity
   for (;;) {
@@ -224,6 +245,10 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
       const unsigned buf = gs & 1u;
       const bool more = kb + 1 < KB || next_tile;          // a k block follows (this tile's, or the next tile's first)
       if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
+      if constexpr (kXLds) {   // activations two k blocks ahead into the X buffer whose block was split last iteration
+        if (kb + 2 < KB) xissue(xa, ma, kb + 2, buf);
+        else if (next_tile) xissue(xn, mn, kb + 2 - KB, buf);
+      }
       const unsigned wl_addr = lds0 + buf * kBufBytes;
       u32x4 wh, wm, wl;
       lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
@@ -235,11 +260,9 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
           lds_read<(nt + 1) * 3072>(nh, wl_addr); lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
           lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
         }
-        if constexpr (nt == kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
-          if (!(p.dbg & 2)) {
-            if (kb + 2 < KB) xissue(xa, ma, kb + 2);
-            else if (next_tile) xissue(xn, mn, kb + 2 - KB);
-          }
+        if constexpr (!kXLds && nt == kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
+          if (kb + 2 < KB) xissue(xa, ma, kb + 2, 0u);
+          else if (next_tile) xissue(xn, mn, kb + 2 - KB, 0u);
         }
         // ---- one scheduling region: 24 MFMAs + this step's share of the activation split (VALU) ----
         // (unconditional -- after the last block it splits stale data that nobody uses: a branch would put the
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
 #pragma unroll
           for (int i = 0; i < kPerStep; ++i) {
             constexpr int base = nt * kPerStep;
-            if (base + i < kPairs) convert_pair(nxt, (base + i) >> 2, (base + i) & 3);
+            if (base + i < kPairs) convert_pair(nxt, (base + i) >> 2, (base + i) & 3, buf ^ 1u);
           }
         }
         // smallest products first; the MT accumulators of a product are independent
@@ -267,13 +290,14 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
         if constexpr (nt < kConvSteps) {
           // a wave issues in order: the split only overlaps the matrix pipe if its VALU ops sit BETWEEN MFMAs
 #pragma unroll
-          for (int i = 0; i < 24; ++i) {
+          for (int i = 0; i < 6 * MT; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);
           }
         }
         // MFMAs are pure values to the compiler; pin them (and the split's results) to this step
-        asm volatile("" : "+a"(acc[0][nt]), "+a"(acc[1][nt]), "+a"(acc[2][nt]), "+a"(acc[3][nt]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+a"(acc[mt][nt]));
         if constexpr (nt < kConvSteps) {
 #pragma unroll
           for (int i = 0; i < kPerStep; ++i) {
@@ -399,20 +423,28 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   }
 }
 
-template <int NT>
-int launch_x3(const X3Params &p, hipStream_t st) {
-  constexpr int MT = 4;
-  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
+template <int MT, int NT, int PRE>
+void launch_x3_pre(const X3Params &p, hipStream_t st) {
   const long long rows_per_wg = 4LL * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
   // persistent workgroups, one per CU (512 registers per lane): the next tile's first k blocks are prefetched
   // under the current tile's last MFMAs and epilogue
   const unsigned grid = static_cast<unsigned>(wg_tiles < nsdp::num_cus() ? wg_tiles : nsdp::num_cus());
+  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE>), dim3(grid), dim3(256), 0, st, p);
+}
+
+// MT = 4 row tiles per wave where 4 x NT x 4 accumulators leave room for the operand registers, else 3
+// (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
+template <int NT>
+int launch_x3(const X3Params &p, hipStream_t st) {
+  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
-  if (pre == 0) hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 0>), dim3(grid), dim3(256), 0, st, p);
-  else if (pre == 1) hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 1>), dim3(grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 2>), dim3(grid), dim3(256), 0, st, p);
+  constexpr int MT0 = NT >= 16 ? 3 : 4;             // plain / ReLU prologue
+  constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;   // mask prologue (activation + mask registers in flight)
+  if (pre == 0) launch_x3_pre<MT0, NT, 0>(p, st);
+  else if (pre == 1) launch_x3_pre<MT1, NT, 1>(p, st);
+  else launch_x3_pre<MT0, NT, 2>(p, st);
   return nsdp::launch_status("linear_bf16x3_kernel");
 }
 
