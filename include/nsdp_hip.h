@@ -151,7 +151,7 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
 
 /* nsdp_linear_wgrad_f32 on the bf16 matrix pipe (error-compensated 3-way split of both operands, fp32 rounding-level
  * accuracy, csrc/wgrad_bf16x3.hip).  Same contract; shapes must satisfy nsdp_linear_wgrad_bf16x3_supported
- * (M >= 1024, 16 < N,K <= 208, tensors below 4 GB), workspace >= nsdp_linear_wgrad_bf16x3_workspace_bytes. */
+ * (M >= 1024, 16 < N,K <= 256, tensors below 4 GB), workspace >= nsdp_linear_wgrad_bf16x3_workspace_bytes. */
 int nsdp_linear_wgrad_bf16x3_supported(long long M, int N, int K);
 size_t nsdp_linear_wgrad_bf16x3_workspace_bytes(long long M, int N, int K);
 int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,

@@ -438,7 +438,7 @@ void launch_x3_pre(const X3Params &p, hipStream_t st) {
 template <int NT>
 int launch_x3(const X3Params &p, hipStream_t st) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
-  nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
+  nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   constexpr int MT0 = NT >= 16 ? 3 : 4;             // plain / ReLU prologue
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;   // mask prologue (activation + mask registers in flight)

@@ -17,6 +17,8 @@ enum Kind {
   kAttnBwd,      // fused attention elementwise backward kernels
   kBatchNorm,    // batch-norm kernels
   kDecoderFwd,   // fused decoder forward
+  kLinearX3,     // linear_bf16x3_kernel (bf16 MFMA, 3-way split, 6 products per fp32 product)
+  kWgradX3,      // wgrad_bf16x3_kernel + its reduce
   kNumKinds
 };
 

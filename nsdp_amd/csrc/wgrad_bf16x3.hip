@@ -42,6 +42,7 @@ struct WgX3Params {
   int N, K;
   long long blocks_per_wg;   // 32-row blocks per workgroup
   int want_db;
+  int kparts;                // grid.y: column ranges of X of KTB*16 columns each (K > 208: LDS holds N + K/2 columns)
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
@@ -97,6 +98,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 1, wb = wave & 1;
   const int N = p.N, K = p.K;
+  const int k_off = static_cast<int>(blockIdx.y) * kColsB;          // this workgroup's column range of X / dW
+  const int Kpart = K - k_off < kColsB ? K - k_off : kColsB;
   // uniform (SGPR) bases of the asm loads
   const float *const dYp = sgpr_ptr(p.dY), *const Xp = sgpr_ptr(p.X), *const Mp = sgpr_ptr(p.mask);
   const long long Mrows = p.M;
@@ -128,8 +131,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     int s = tid + 256 * r;
     s = s < 4 * kColsB ? s : s - 256;
     const int gp = s / kColsB, col = s % kColsB;
-    const int colc = col < K ? col : (K - 1);
-    g8B[r] = col < K ? 8 * gp : (1 << 20);
+    const int colc = k_off + (col < Kpart ? col : (Kpart - 1));
+    g8B[r] = col < Kpart ? 8 * gp : (1 << 20);
     offB[r] = static_cast<unsigned>(((mb0 * 32 + 8 * gp) * K + colc) * 4);
     ldsB[r] = static_cast<unsigned>(((NTA * 3 + (col >> 4) * 3) * 64 + 16 * gp + (col & 15)) * 16);
   }
@@ -359,7 +362,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   }
 
   // ---- partial results: fragment-ordered float4 per (n tile, k tile), then the bias-gradient partial ----
-  float *wsp = p.ws + static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(NTA) * KTB * 256 + NTA * 16);
+  float *wsp = p.ws + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) *
+                         (static_cast<size_t>(NTA) * KTB * 256 + NTA * 16);
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
             make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-  if (p.want_db) {
+  if (p.want_db && blockIdx.y == 0) {
     // every slot s = (row group, column) has exactly one owner: park the per-slot sums in LDS and add the four
     // row groups of a column in fixed order (deterministic)
     float *dbl = reinterpret_cast<float *>(&planes[0]);       // all plane reads are behind the last barrier
@@ -387,61 +391,82 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
 }
 
 // dW[n][k] = sum over the S partials of element (n, k): accumulator (tile n/16, tile k/16), lane 16 (n%16)/4 + k%16,
-// register (n%16)%4  (C/D layout of the MFMA: row = 4 (lane >> 4) + reg, column = lane & 15)
+// register (n%16)%4  (C/D layout of the MFMA: row = 4 (lane >> 4) + reg, column = lane & 15).
+// 32 elements x 8 partial ranges per workgroup: a thread sums one eighth of the partials of one element (S/8
+// independent loads in flight instead of a chain of S), the eight sub-sums are combined through LDS in fixed order.
 __global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_kernel(const float *__restrict__ ws, int S, int NTA, int KTB,
                                                                   int N, int K, float *__restrict__ dW,
                                                                   float *__restrict__ db, int accumulate) {
-  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const long long e = static_cast<long long>(blockIdx.x) * 32 + el;
   const long long nw = static_cast<long long>(N) * K;
   const size_t stride = static_cast<size_t>(NTA) * KTB * 256 + NTA * 16;
-  size_t idx;
+  size_t idx = 0;
+  bool valid = true;
   if (e < nw) {
-    const int n = static_cast<int>(e / K), k = static_cast<int>(e % K);
+    const int n = static_cast<int>(e / K), kg = static_cast<int>(e % K);
+    const int part = kg / (KTB * 16), k = kg - part * KTB * 16;       // column range (grid.y of the main kernel)
     const int nl = n & 15, kl = k & 15;
-    idx = (static_cast<size_t>(n >> 4) * KTB + (k >> 4)) * 256 + (16 * (nl >> 2) + kl) * 4 + (nl & 3);
+    idx = static_cast<size_t>(part) * S * stride +
+          (static_cast<size_t>(n >> 4) * KTB + (k >> 4)) * 256 + (16 * (nl >> 2) + kl) * 4 + (nl & 3);
   } else if (e < nw + N && db) {
     idx = static_cast<size_t>(NTA) * KTB * 256 + (e - nw);
   } else {
-    return;
+    valid = false;
   }
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 4 <= S; s += 4) {
-    s0 += ws[idx + (s + 0) * stride]; s1 += ws[idx + (s + 1) * stride];
-    s2 += ws[idx + (s + 2) * stride]; s3 += ws[idx + (s + 3) * stride];
+  if (valid) {
+    const int per = (S + 7) / 8;
+    int s = q * per;
+    const int s_end = s + per < S ? s + per : S;
+    for (; s + 4 <= s_end; s += 4) {
+      s0 += ws[idx + (s + 0) * stride]; s1 += ws[idx + (s + 1) * stride];
+      s2 += ws[idx + (s + 2) * stride]; s3 += ws[idx + (s + 3) * stride];
+    }
+    for (; s < s_end; ++s) s0 += ws[idx + s * stride];
   }
-  for (; s < S; ++s) s0 += ws[idx + s * stride];
-  const float t = (s0 + s1) + (s2 + s3);
-  if (e < nw) dW[e] = accumulate ? dW[e] + t : t;
-  else db[e - nw] = accumulate ? db[e - nw] + t : t;
+  part[q][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && valid) {
+    const float t = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) +
+                    ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+    if (e < nw) dW[e] = accumulate ? dW[e] + t : t;
+    else db[e - nw] = accumulate ? db[e - nw] + t : t;
+  }
 }
 
 struct X3Plan {
-  int nta, ktb, grid;
+  int nta, ktb, kparts, grid;
   long long blocks_per_wg;
   size_t ws_floats;
 };
 
 X3Plan plan_x3(long long M, int N, int K) {
   X3Plan pl;
-  pl.nta = (N + 15) / 16;
-  pl.ktb = (K + 15) / 16;
-  // instantiated tile classes: 8 (<= 128 columns) and 13 (<= 208)
-  pl.nta = pl.nta <= 8 ? 8 : 13;
-  pl.ktb = pl.ktb <= 8 ? 8 : 13;
+  // instantiated tile classes: 8 (<= 128 columns), 13 (<= 208), 16 (<= 256, dY only).  Two plane buffers of
+  // (nta + ktb) x 3 KiB must fit in 160 KiB: wider problems split the columns of X over grid.y
+  pl.nta = N <= 128 ? 8 : N <= 208 ? 13 : 16;
+  pl.ktb = K <= 128 ? 8 : 13;
+  pl.kparts = 1;
+  if (K > 208 || pl.nta + pl.ktb > 26) {
+    pl.ktb = 8;
+    pl.kparts = (K + 127) / 128;
+  }
   const long long mb_all = (M + 31) / 32;
-  long long grid = nsdp::num_cus();
+  long long grid = nsdp::num_cus() / pl.kparts;
   if (grid > mb_all / 4) grid = mb_all / 4 > 0 ? mb_all / 4 : 1;     // at least 4 blocks per workgroup
   pl.blocks_per_wg = (mb_all + grid - 1) / grid;
   pl.grid = static_cast<int>((mb_all + pl.blocks_per_wg - 1) / pl.blocks_per_wg);
-  pl.ws_floats = static_cast<size_t>(pl.grid) * (static_cast<size_t>(pl.nta) * pl.ktb * 256 + pl.nta * 16);
+  pl.ws_floats = static_cast<size_t>(pl.grid) * pl.kparts * (static_cast<size_t>(pl.nta) * pl.ktb * 256 + pl.nta * 16);
   return pl;
 }
 
 template <int NTA, int KTB>
 void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
-  if (p.mask) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true>), dim3(grid), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false>), dim3(grid), dim3(256), 0, st, p);
+  const dim3 g(grid, p.kparts);
+  if (p.mask) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true>), g, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false>), g, dim3(256), 0, st, p);
 }
 
 }  // namespace
@@ -449,7 +474,7 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
 extern "C" {
 
 int nsdp_linear_wgrad_bf16x3_supported(long long M, int N, int K) {
-  return M >= 1024 && N > 16 && K > 16 && N <= 208 && K <= 208 &&
+  return M >= 1024 && N > 16 && K > 16 && N <= 256 && K <= 256 &&
          static_cast<double>(M) * (N > K ? N : K) * 4.0 < 4.0e9;      // 32-bit byte offsets inside a tensor
 }
 
@@ -467,19 +492,20 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
   NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K),
                "linear_wgrad_bf16x3: workspace too small");
   const X3Plan pl = plan_x3(M, N, K);
-  WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr};
+  WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr, pl.kparts};
   hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kWgradX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
   {
-    nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
     if (pl.nta == 8 && pl.ktb == 8) launch_wg<8, 8>(p, pl.grid, st);
     else if (pl.nta == 8) launch_wg<8, 13>(p, pl.grid, st);
+    else if (pl.nta == 16) launch_wg<16, 8>(p, pl.grid, st);
     else if (pl.ktb == 8) launch_wg<13, 8>(p, pl.grid, st);
     else launch_wg<13, 13>(p, pl.grid, st);
     const int rc = nsdp::launch_status("wgrad_bf16x3_kernel");
     if (rc) return rc;
   }
   const long long ne = static_cast<long long>(N) * K + N;
-  hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
                      workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
   return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
 }

@@ -9,6 +9,14 @@ from . import _lib
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters)
 PEAK_HBM_GBPS = 8000.0
 PEAK_F32_MFMA_TFLOPS = 157.3
+# bf16x3 kernels: every fp32 multiply-add is 6 bf16 MFMA products (3-way split of both operands, csrc/gemm_bf16x3.hip);
+# the compute roofline for their ALGORITHMIC flops is the dense bf16 MFMA peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def _mfma_peak(name):
+    return PEAK_BF16X3_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
 
 _active = False
 
@@ -98,10 +106,11 @@ def _roofline_one(name, v):
     flops_per_launch = v["flops"] / v["launches"]
     bytes_per_launch = v["bytes"] / v["launches"]
     intensity = flops_per_launch / max(bytes_per_launch, 1.0)
-    if intensity > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9):
+    peak = _mfma_peak(name)
+    if intensity > peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
         achieved = flops_per_launch / (per_launch_ms * 1e9)
-        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "algorithmic_bytes": round(bytes_per_launch), "launches": v["launches"],
                 "avg_launch_ms": round(per_launch_ms, 4)}
     achieved = bytes_per_launch / (per_launch_ms * 1e6)

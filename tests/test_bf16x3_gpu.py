@@ -94,6 +94,9 @@ WG_CASES = [  # (M, N, K, mask, relu_x)
     (70000, 128, 200, True, False),      # mixed tile classes (8 x 13)
     (50000, 200, 120, False, True),      # (13 x 8)
     (33333, 64, 64, False, False),
+    (5000, 256, 256, True, False),       # N = 256 (16 tiles), columns of X split over grid.y
+    (3200, 200, 256, False, False),      # K = 256 with a 13-tile dY
+    (2500, 256, 200, False, True),       # 16 + 13 tiles would not fit in LDS: K split 128 + 72
 ]
 
 
@@ -120,8 +123,8 @@ def test_bf16x3_rejects_shapes_outside_its_contract():
     w = torch.randn(64, 32, device=DEV)
     with pytest.raises(_lib.NsdpHipError):         # K must span two k blocks
         hip_linear._fwd_x3(x, hip_linear.pack_weight_x3(w)[0], 64, None, None, None, None, False, False)
-    with pytest.raises(_lib.NsdpHipError):         # N = 256 > 208 columns
-        hip_linear._wgrad_x3(torch.randn(4096, 256, device=DEV), torch.randn(4096, 64, device=DEV), None, False, True)
+    with pytest.raises(_lib.NsdpHipError):         # K = 16: a single tile is below the kernel's range
+        hip_linear._wgrad_x3(torch.randn(4096, 256, device=DEV), torch.randn(4096, 16, device=DEV), None, False, True)
 
 
 def test_autograd_routes_large_layers_through_bf16x3_and_matches_fp32_path():

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round profile on the GPU box: bench lines + rocprofv3 kernel stats + HBM PMC passes -> gpurun_out/, then
+# `python tools/summarize_profile.py <tag>` (here) condenses them into profiles/.
+#   tools/profile_round.sh r1
+tag=${1:-r1}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+cd $R
+python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_bench_default.err
+python bench.py --batch 8 --no-cpu-baseline > gpurun_out/${tag}_bench_b8.json 2>/dev/null
+python bench.py --workload arbitrary_train --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary.json 2>/dev/null
+python bench.py --workload dense_inference --no-cpu-baseline > gpurun_out/${tag}_bench_dense_inference.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o ${tag} -- \
+  python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- \
+  python $R/bench.py --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- \
+  python $R/bench.py --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+NSDP_WGRAD_STREAM=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+  --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -o s -- \
+  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1
+ls $R/gpurun_out/prof_${tag} $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_sq
+tail -c 600 $R/gpurun_out/${tag}_bench_default.json
