@@ -88,21 +88,23 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
 
-template <int MT, int NT, int PRE>
-__global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
+// WV waves per workgroup: 4 (one per SIMD, MT up to 4 row tiles: 512 registers per lane) or 8 (two per SIMD, MT <= 2:
+// 256 registers per lane -- the second wave of a SIMD issues MFMAs while the first splits, stores or waits)
+template <int MT, int NT, int PRE, int WV>
+__global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
   // in LDS next to the weights and keeps the register path.
   constexpr bool kXLds = PRE != 1;
   __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][NT * 3 * 64];
-  __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? 4 : 1][kXLds ? MT * 2 * 64 : 1];
+  __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? WV : 1][kXLds ? MT * 2 * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
   const int K = p.K, N = p.N;
   const int KB = (K + 31) >> 5;                // >= 2 (host contract)
   const int ntiles = (N + 15) >> 4;            // n tiles present in the pack (<= NT)
-  constexpr long long kRowsWg = 4LL * MT * 16;
+  constexpr long long kRowsWg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + kRowsWg - 1) / kRowsWg;
   const long long stride = gridDim.x;
   long long tile = blockIdx.x;                 // persistent workgroup: tile, tile + grid, ...
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
   auto set_rows = [&](long long t, const float **x, const float **m) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      long long r = (t * 4 + wave) * (MT * 16) + mt * 16 + li;
+      long long r = (t * WV + wave) * (MT * 16) + mt * 16 + li;
       r = r < p.M ? r : (p.M - 1);
       x[mt] = p.X + r * K;
       m[mt] = PRE == 1 ? p.mask + r * K : nullptr;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
   const char *wlane = static_cast<const char *>(p.Wp) + lane * 16;
   auto stage = [&](int kb, int buf) {   // DMA one k block of weight pieces (1 KiB each), spread over the 4 waves
     const int pieces = ntiles * 3;
-    for (int q = wave; q < pieces; q += 4)
+    for (int q = wave; q < pieces; q += WV)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wlane + ((static_cast<long long>(kb) * pieces + q) << 10)),
                                        (lds_ptr_t)(&wbuf[buf][q * 64]), 16, 0, 0);
   };
@@ -206,13 +208,14 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
 
   // the split of the next k block's activations is spread over the first kConvSteps n-tile steps of a block
   constexpr int kConvSteps = NT > 4 ? 4 : NT - 1;
+  constexpr int kConvFirst = kXLds ? NT - kConvSteps : 0;     // first n-tile step that carries split work
   constexpr int kPairs = MT * 4;
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
   constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 6 * MT - 1) / (6 * MT);
 
   unsigned gs = 0;   // running k block count: weight buffer parity
   for (;;) {
-    const long long row0 = (tile * 4 + wave) * (MT * 16);
+    const long long row0 = (tile * WV + wave) * (MT * 16);
     const bool next_tile = tile + stride < wg_tiles;
     // (opaque per-tile copies of the lane coordinates: everything the prologue / epilogue derives from them is
     // tile-invariant, and LICM would otherwise keep ~60 such values live across the whole k loop)
@@ -245,10 +248,16 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
       const unsigned buf = gs & 1u;
       const bool more = kb + 1 < KB || next_tile;          // a k block follows (this tile's, or the next tile's first)
       if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
+      bool x_issued = false;
       if constexpr (kXLds) {   // activations two k blocks ahead into the X buffer whose block was split last iteration
-        if (kb + 2 < KB) xissue(xa, ma, kb + 2, buf);
-        else if (next_tile) xissue(xn, mn, kb + 2 - KB, buf);
+        if (kb + 2 < KB) { xissue(xa, ma, kb + 2, buf); x_issued = true; }
+        else if (next_tile) { xissue(xn, mn, kb + 2 - KB, buf); x_issued = true; }
       }
+      // vmcnt retires in order: "all but the MT*2 youngest" = everything except the activation pieces just issued
+      auto xwait_older = [&]() {
+        if (x_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
       const unsigned wl_addr = lds0 + buf * kBufBytes;
       u32x4 wh, wm, wl;
       lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
@@ -260,17 +269,20 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
           lds_read<(nt + 1) * 3072>(nh, wl_addr); lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
           lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
         }
-        if constexpr (!kXLds && nt == kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
+        if constexpr (!kXLds && nt == kConvFirst + kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
           if (kb + 2 < KB) xissue(xa, ma, kb + 2, 0u);
           else if (next_tile) xissue(xn, mn, kb + 2 - KB, 0u);
         }
         // ---- one scheduling region: 24 MFMAs + this step's share of the activation split (VALU) ----
         // (unconditional -- after the last block it splits stale data that nobody uses: a branch would put the
         // VALU work into its own basic block, where it cannot be interleaved with the MFMAs)
-        if constexpr (nt < kConvSteps) {
+        // LDS path: the split runs in the LAST steps of the block, behind a counted wait -- the DMA of that data was
+        // issued at the top of the previous block and has had 1 2/3 blocks to land
+        if constexpr (kXLds && nt == kConvFirst) xwait_older();
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
 #pragma unroll
           for (int i = 0; i < kPerStep; ++i) {
-            constexpr int base = nt * kPerStep;
+            constexpr int base = (nt - kConvFirst) * kPerStep;
             if (base + i < kPairs) convert_pair(nxt, (base + i) >> 2, (base + i) & 3, buf ^ 1u);
           }
         }
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wm, cur.h[mt], acc[mt][nt]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.h[mt], acc[mt][nt]);
-        if constexpr (nt < kConvSteps) {
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
           // a wave issues in order: the split only overlaps the matrix pipe if its VALU ops sit BETWEEN MFMAs
 #pragma unroll
           for (int i = 0; i < 6 * MT; ++i) {
@@ -298,10 +310,10 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
         // MFMAs are pure values to the compiler; pin them (and the split's results) to this step
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+a"(acc[mt][nt]));
-        if constexpr (nt < kConvSteps) {
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
 #pragma unroll
           for (int i = 0; i < kPerStep; ++i) {
-            constexpr int base = nt * kPerStep;
+            constexpr int base = (nt - kConvFirst) * kPerStep;
             if (base + i < kPairs) {
               const int mt = (base + i) >> 2, pr = (base + i) & 3;
               asm volatile("" : "+v"(nxt.h[mt][pr]), "+v"(nxt.m[mt][pr]), "+v"(nxt.l[mt][pr]));
@@ -313,7 +325,8 @@ __global__ __launch_bounds__(256) void linear_bf16x3_kernel(X3Params p) {
           wh = nh; wm = nm; wl = nl;
         }
       });
-      xwait();            // next block's weights (DMA) and the activations after next have landed
+      if constexpr (kXLds) xwait_older();   // next block's weights have landed (the activations after next may still fly)
+      else xwait();                         // next block's weights (DMA) and the raw registers of the block after next
       __syncthreads();    // every wave is done reading wbuf[buf]
       cur = nxt;
     }
@@ -423,28 +436,36 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   }
 }
 
-template <int MT, int NT, int PRE>
+template <int MT, int NT, int PRE, int WV>
 void launch_x3_pre(const X3Params &p, hipStream_t st) {
-  const long long rows_per_wg = 4LL * MT * 16;
+  const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
-  // persistent workgroups, one per CU (512 registers per lane): the next tile's first k blocks are prefetched
-  // under the current tile's last MFMAs and epilogue
+  // persistent workgroups, one per CU: the next tile's first k blocks are prefetched under the current tile's
+  // last MFMAs and epilogue
   const unsigned grid = static_cast<unsigned>(wg_tiles < nsdp::num_cus() ? wg_tiles : nsdp::num_cus());
-  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE>), dim3(grid), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
-// MT = 4 row tiles per wave where 4 x NT x 4 accumulators leave room for the operand registers, else 3
 // (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
 template <int NT>
 int launch_x3(const X3Params &p, hipStream_t st) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
-  constexpr int MT0 = NT >= 16 ? 3 : 4;             // plain / ReLU prologue
-  constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;   // mask prologue (activation + mask registers in flight)
-  if (pre == 0) launch_x3_pre<MT0, NT, 0>(p, st);
-  else if (pre == 1) launch_x3_pre<MT1, NT, 1>(p, st);
-  else launch_x3_pre<MT0, NT, 2>(p, st);
+  // measured per class: up to 13 n tiles two waves per SIMD with 2 row tiles each win (1.36 -> 1.20 ms on the
+  // 1.8 M x 200 x 200 layers), at 16 n tiles one wave per SIMD with 3; the masked prologue keeps its raw activation
+  // and mask registers in flight and uses the one-wave, spill-free variants throughout
+  constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
+  const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
+  if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
+  else if (two_waves) {
+    if (pre == 0) launch_x3_pre<2, NT, 0, 8>(p, st);
+    else launch_x3_pre<2, NT, 2, 8>(p, st);
+  } else {
+    constexpr int MT0 = NT >= 16 ? 3 : 4;
+    if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
+    else launch_x3_pre<MT0, NT, 2, 4>(p, st);
+  }
   return nsdp::launch_status("linear_bf16x3_kernel");
 }
 

@@ -8,7 +8,7 @@ x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.
 wp = pack_weight(w)[0]; w3 = pack_weight_x3(w)[0]
 import time
 from nsdp_amd._lib import lib
-for dbg in ([0, 16, 8, 24, 15] if variant == "x3dbg" else [int(variant[4:])] if variant.startswith("x3d=") else [0]):
+for dbg in ([0, 32] if variant == "x3dbg" else [int(variant[4:])] if variant.startswith("x3d=") else [0]):
   lib().nsdp_debug_set(6, dbg)
   torch.cuda.synchronize(); t0 = time.time()
   for _ in range(5):
