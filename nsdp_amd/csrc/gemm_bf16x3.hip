@@ -38,6 +38,16 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 int g_x3_dbg = 0;
 
+#ifdef NSDP_X3_TIMING
+// phase timers (s_memtime ticks summed over waves): 0 steps, 1 bottom wait, 2 barrier, 3 epilogue, 4 tile prologue, 5 total
+__device__ unsigned long long g_x3_timers[8];
+#define X3_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define X3_ADD(i, a, b) t_acc[i] += (b) - (a)
+#else
+#define X3_T(var)
+#define X3_ADD(i, a, b)
+#endif
+
 struct X3Params {
   const float *X;
   const void *Wp;  // bf16x3 pack
@@ -213,8 +223,13 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
   constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 6 * MT - 1) / (6 * MT);
 
+#ifdef NSDP_X3_TIMING
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   unsigned gs = 0;   // running k block count: weight buffer parity
   for (;;) {
+    X3_T(t_tile0);
     const long long row0 = (tile * WV + wave) * (MT * 16);
     const bool next_tile = tile + stride < wg_tiles;
     // (opaque per-tile copies of the lane coordinates: everything the prologue / epilogue derives from them is
@@ -244,7 +259,10 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    X3_T(t_tile1);
+    X3_ADD(4, t_tile0, t_tile1);
     for (int kb = 0; kb < KB; ++kb, ++gs) {
+      X3_T(t_k0);
       const unsigned buf = gs & 1u;
       const bool more = kb + 1 < KB || next_tile;          // a k block follows (this tile's, or the next tile's first)
       if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
@@ -325,23 +343,39 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
           wh = nh; wm = nm; wl = nl;
         }
       });
+      X3_T(t_k1);
       if constexpr (kXLds) xwait_older();   // next block's weights have landed (the activations after next may still fly)
       else xwait();                         // next block's weights (DMA) and the raw registers of the block after next
+      X3_T(t_k2);
       __syncthreads();    // every wave is done reading wbuf[buf]
+      X3_T(t_k3);
+      X3_ADD(0, t_k0, t_k1); X3_ADD(1, t_k1, t_k2); X3_ADD(2, t_k2, t_k3);
       cur = nxt;
     }
 
+    X3_T(t_e0);
     // epilogue: lane (li, g) of (mt, nt) holds Y[row0 + 16 mt + li][16 nt + 4 g .. + 3]
     if (row0 < p.M && !(p.dbg & 8)) {
       const bool full_rows = row0 + MT * 16 <= p.M;
       int li_e = li, g_e = g;
       asm volatile("" : "+v"(li_e), "+v"(g_e));
+      // all bias fragments up front: one L2 round trip instead of one per n tile (each tile below is its own basic
+      // block, so the loads would otherwise be waited for one by one -- that was ~half of the epilogue time)
+      float4 bias4[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bias4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + 4 * g_e;
+          bias4[nt] = *reinterpret_cast<const float4 *>(p.bias + (col + 4 <= N ? col : (N - 4)));
+        }
+      }
       auto otile = [&](int nt, auto has_omask, auto guarded) {
         const int col = nt * 16 + 4 * g_e;
         const bool cv = col + 4 <= N;
         const int colc = cv ? col : (N - 4);
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bv = *reinterpret_cast<const float4 *>(p.bias + colc);
+        const float4 bv = bias4[nt];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const long long row = row0 + mt * 16 + li_e;
@@ -353,10 +387,15 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
             const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
             v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f;
           }
+          const f32x4 vv = {v.x, v.y, v.z, v.w};
           if (decltype(guarded)::value) {
-            if (cv && rv) *reinterpret_cast<float4 *>(p.Y + rowc * N + colc) = v;
+            if (cv && rv) {
+              if (p.dbg & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(p.Y + rowc * N + colc));
+              else *reinterpret_cast<f32x4 *>(p.Y + rowc * N + colc) = vv;
+            }
           } else {
-            *reinterpret_cast<float4 *>(p.Y + row * N + col) = v;
+            if (p.dbg & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(p.Y + row * N + col));
+            else *reinterpret_cast<f32x4 *>(p.Y + row * N + col) = vv;
           }
         }
       };
@@ -378,12 +417,19 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
       else epilogue(std::false_type{});
     }
 
+    X3_T(t_e1);
+    X3_ADD(3, t_e0, t_e1);
     if (!next_tile) break;
     tile += stride;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { xa[mt] = xn[mt]; ma[mt] = mn[mt]; }
     set_rows(tile + stride, xn, mn);
   }
+#ifdef NSDP_X3_TIMING
+  t_acc[5] = __builtin_readcyclecounter() - t_begin;
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_x3_timers[i], t_acc[i]);
+#endif
 }
 
 // bf16x3 packs.  Wp  [ceil(K/32)][ceil(N/16)][3 planes][64 lanes][8 bf16]:
@@ -472,6 +518,13 @@ int launch_x3(const X3Params &p, hipStream_t st) {
 }  // namespace
 
 namespace nsdp {
+#ifdef NSDP_X3_TIMING
+extern "C" void nsdp_debug_x3_timers(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x3_timers), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_x3_timers), z, sizeof(z)); }
+}
+#endif
 void debug_set_x3(int value) { g_x3_dbg = value; }
 }  // namespace nsdp
 
