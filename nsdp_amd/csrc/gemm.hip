@@ -213,11 +213,22 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   // every complete 16-column tile are unconditional straight-line code; only the ragged last tile
   // (N % 16 != 0) and the last row block of the matrix take the predicated form.
   const bool full_rows = row0 + MT * 16 <= p.M;
+  // all bias values up front: one L2 round trip instead of one per n tile (each tile below is its own basic block)
+  float bias_t[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bias_t[nt] = 0.f;
+  if (p.bias) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = (ntile0 + nt) * 16 + li;
+      bias_t[nt] = p.bias[c < N ? c : (N - 1)];
+    }
+  }
   auto tile = [&](int nt, auto has_omask, auto guarded) {
     const int col = (ntile0 + nt) * 16 + li;
     const bool cv = col < N;
     const int colc = cv ? col : (N - 1);
-    const float bv = p.bias ? p.bias[colc] : 0.f;
+    const float bv = bias_t[nt];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
