@@ -1,0 +1,80 @@
+"""GPU: dense-inference metrics (HIP kNN Chamfer) against the oracle / the reference's vectors, and a short real
+training run through the harness (checkpoints written, loss finite and decreasing on a fixed batch)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import model_cfg
+from nsdp_amd import eval_metric, synth, train
+from oracle import eval_metric_ref
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_metrics_match_reference_vectors():
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_metric.npz"))
+    for c in range(3):
+        a, b = fx[f"c{c}_a"], fx[f"c{c}_b"]
+        ta, tb = torch.from_numpy(a).float().to(DEV), torch.from_numpy(b).float().to(DEV)
+        k = min(len(a), len(b))
+        # fp32 coordinates and distances against the reference's float64 KD-tree: relative 2e-6
+        assert abs(float(eval_metric.chamfer_distance(ta, tb)) - fx[f"c{c}_chamfer"]) <= 2e-6 * fx[f"c{c}_chamfer"]
+        assert abs(float(eval_metric.compute_dist_square(ta[:k], tb[:k])) - fx[f"c{c}_l2"]) <= 2e-6 * fx[f"c{c}_l2"]
+        na, nb = torch.from_numpy(fx[f"c{c}_na"]).float().to(DEV), torch.from_numpy(fx[f"c{c}_nb"]).float().to(DEV)
+        assert abs(float(eval_metric.normal_consistency(na, nb)) - fx[f"c{c}_fnc"]) <= 2e-6
+
+
+def test_chamfer_at_evaluation_size_and_nn_indices():
+    """30 000 x 30 000 points (the reference's point-cloud size): nearest-neighbour distances equal the KD-tree's."""
+    a = synth.uniform(5, "a", (30000, 3), -0.5, 0.5)
+    b = synth.uniform(5, "b", (30000, 3), -0.5, 0.5)
+    d = eval_metric.nn_distance(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)).cpu().numpy()
+    from scipy.spatial import KDTree
+    ref, _ = KDTree(b.astype(np.float64)).query(a.astype(np.float64))
+    np.testing.assert_allclose(d, ref, rtol=2e-6, atol=1e-7)
+    cd = float(eval_metric.chamfer_distance(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV)))
+    assert abs(cd - eval_metric_ref.chamfer_distance(a.astype(np.float64), b.astype(np.float64))) <= 2e-6 * cd
+
+
+def test_compute_evaluation_metrics_on_a_mesh():
+    g = np.random.RandomState(0)
+    verts = g.rand(500, 3).astype(np.float32)
+    faces = g.randint(0, 500, size=(900, 3)).astype(np.int64)
+    faces = faces[(faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])]
+    pred = verts + 0.01 * g.randn(500, 3).astype(np.float32)
+    out = {"verts_tgt_pred": torch.from_numpy(pred).to(DEV)[None], "verts_tgt": torch.from_numpy(verts)[None],
+           "faces": torch.from_numpy(faces)[None]}
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    m = eval_metric.compute_evaluation_metrics(out, pointcloud_size=20000, generator=gen)
+    assert abs(m["l2"] - eval_metric_ref.compute_dist_square(pred.astype(np.float64), verts.astype(np.float64))) < 1e-8
+    fn = eval_metric_ref.normal_consistency(eval_metric_ref.face_normals(pred.astype(np.float64), faces),
+                                            eval_metric_ref.face_normals(verts.astype(np.float64), faces))
+    assert abs(m["fnc"] - fn) < 1e-5
+    assert 0.0 < m["cd"] < 0.05          # sampled surfaces 1 cm apart (statistical: own sampling RNG)
+
+
+def test_short_training_run_through_the_harness(tmp_path):
+    from nsdp_amd.model import build_model, optimizer_factory
+    cfg = model_cfg("forward", [2048, 500, 100])
+    cfg["training"] = {"epochs": 3, "save_frequency": 1, "optimizer": "Adam", "lr": 5e-4, "lr_step": 200,
+                       "lr_decay": 0.1, "weight_decay": 0.0}
+    cfg["validation"] = {"frequency": 1}
+    train.seed_everything(27)
+    model, train_fn, val_fn, _ = build_model(cfg, device=DEV)
+    sched, opt = optimizer_factory(cfg["training"], model.parameters())
+    loader = train.SyntheticLoader(3, 2, 2, n_surf=2048, n_query=1024)
+    args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+    hist = train.fit(model, (train_fn, val_fn), sched, opt, loader, loader, cfg, str(tmp_path), args, DEV,
+                     log=lambda *_: None)
+    losses = [h[2] for h in hist if h[0] == "train"]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    files = os.listdir(str(tmp_path))
+    assert {"model_00000", "model_00001", "model_00002", "opt_00002"} <= set(files)
+    assert any(f.startswith("modelbest_") for f in files)
+    # the saved state dict has the reference's keys (loadable by either code base)
+    sd = torch.load(os.path.join(str(tmp_path), "model_00002"), map_location="cpu")
+    assert "decoder.ct1.fc_gamma.0.weight" in sd and "encoder.enc_sdf.weight" in sd

@@ -1,0 +1,96 @@
+"""Training-harness semantics (reference train.py / utils/checkpoints.py) with a stub model on CPU: file naming,
+save / validation cadence, best-model tracking, resume -- and the eval-metric oracle against the vectors produced
+by the reference's own utils/eval_metric.py."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from nsdp_amd import checkpoints, train
+from oracle import eval_metric_ref
+
+
+class _Stub(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(3))
+
+
+def _fns(log):
+    def train_on_batch(model, optimizer, sample, config):
+        optimizer.zero_grad()
+        loss = ((model.w - sample["t"]) ** 2).sum()
+        loss.backward()
+        optimizer.step()
+        log.append(("t", optimizer.param_groups[0]["lr"]))
+        return loss.item()
+
+    def validate_on_batch(model, sample, config):
+        return ((model.w - sample["t"]) ** 2).sum().item()
+    return train_on_batch, validate_on_batch
+
+
+def _cfg(epochs):
+    return {"training": {"epochs": epochs, "save_frequency": 2, "optimizer": "SGD", "lr": 0.1, "lr_step": 3,
+                         "lr_decay": 0.5, "momentum": 0.0},
+            "validation": {"frequency": 2}}
+
+
+def test_fit_cadence_naming_and_resume(tmp_path):
+    from nsdp_amd.model import optimizer_factory
+    d = str(tmp_path)
+    cfg = _cfg(5)
+    model = _Stub()
+    sched, opt = optimizer_factory(cfg["training"], model.parameters())
+    loader = [{"t": torch.ones(3)}, {"t": torch.ones(3)}]
+    args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+    log = []
+    hist = train.fit(model, _fns(log), sched, opt, loader, loader, cfg, d, args, "cpu", log=lambda *_: None)
+    files = sorted(os.listdir(d))
+    # checkpoints at epochs 0, 2, 4 (i % 2 == 0); validation at 2 and 4 only (i > 0), each one improving -> best files
+    assert [f for f in files if f.startswith("model_")] == ["model_00000", "model_00002", "model_00004"]
+    assert [f for f in files if f.startswith("opt_")] == ["opt_00000", "opt_00002", "opt_00004"]
+    best = [f for f in files if f.startswith("modelbest_")]
+    assert [b[:15] for b in best] == ["modelbest_00002", "modelbest_00004"]
+    assert [h[1] for h in hist if h[0] == "val"] == [2, 4]
+    # epoch-wise step schedule: lr = 0.1 * 0.5 ** (epoch // 3), two batches per epoch
+    lrs = [lr for _, lr in log]
+    assert lrs == [0.1] * 6 + [0.05] * 4
+    # resume: latest pair wins over the best file's epoch, optimizer state restored
+    model2 = _Stub()
+    sched2, opt2 = optimizer_factory(cfg["training"], model2.parameters())
+    args2 = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+    cfg7 = _cfg(7)
+    hist2 = train.fit(model2, _fns([]), sched2, opt2, loader, loader, cfg7, d, args2, "cpu", log=lambda *_: None)
+    assert [h[1] for h in hist2 if h[0] == "train"] == [5, 6]
+    assert args2.best_val_loss <= float(best[-1][16:])
+    assert "model_00006" in os.listdir(d)
+
+
+def test_best_checkpoint_name_round_trip(tmp_path):
+    d = str(tmp_path)
+    m = _Stub()
+    checkpoints.save_best_checkpoints(12, m, d, 0.00123456)
+    assert os.listdir(d) == ["modelbest_00012_0.001235"]
+    args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+    checkpoints.load_best_checkpoints(_Stub(), d, args, "cpu")
+    assert args.continue_from_epoch == 13 and abs(args.best_val_loss - 0.001235) < 1e-9
+
+
+def test_seed_everything_matches_reference_recipe():
+    train.seed_everything(27)
+    a = torch.rand(3)
+    np.random.seed(27)
+    torch.manual_seed(np.random.randint(np.iinfo(np.int32).max))
+    assert torch.equal(a, torch.rand(3))
+
+
+def test_eval_metric_oracle_matches_reference_vectors():
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_metric.npz"))
+    for c in range(3):
+        a, b = fx[f"c{c}_a"], fx[f"c{c}_b"]
+        k = min(len(a), len(b))
+        assert eval_metric_ref.chamfer_distance(a, b) == fx[f"c{c}_chamfer"]
+        assert eval_metric_ref.compute_dist_square(a[:k], b[:k]) == fx[f"c{c}_l2"]
+        assert eval_metric_ref.normal_consistency(fx[f"c{c}_na"], fx[f"c{c}_nb"]) == fx[f"c{c}_fnc"]
