@@ -1,0 +1,89 @@
+"""Per-batch tensor contract of the reference's data loader, on the device.
+
+The reference prepares every sample with numpy on the host (dataset/dataset_deform4d_flow.py:174-264 +
+dataset/utils.py:38-83): random sub-sampling of the surface / space samples, the bounding-box handle mask, the masked
+flow, optional noise and the ``[N,7]`` packing ``[src xyz | mask * tgt xyz | mask]``.  Here the raw samples of a
+whole batch live on the GPU and one call produces the ``data_dict`` the model consumes -- index gathers go through
+the HIP row-gather kernel, the rest is a handful of elementwise ops; nothing returns to the host.
+The partial-shape branch (``partial_shape_ratio < 1``) is not enabled by any shipped configuration and is refused.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import pointnet2_utils
+
+
+def load_npz_surface_flow(path):
+    """dataset/utils.py:8-12 (the files hold fp16 / fp32 ``points`` and ``normals``)."""
+    d = np.load(path)
+    return d["points"].astype(np.float32), d["normals"].astype(np.float32)
+
+
+def load_npz_space_flow(path):
+    """dataset/utils.py:14-17."""
+    return np.load(path)["points"].astype(np.float32)
+
+
+def fix_coord_system(points: torch.Tensor) -> torch.Tensor:
+    """dataset/utils.py:29-32: (x, y, z) -> (x, -z, y)."""
+    return torch.stack([points[..., 0], -points[..., 2], points[..., 1]], dim=-1).contiguous()
+
+
+def random_subset(batch: int, n_full: int, n_keep: int, device, generator=None) -> torch.Tensor:
+    """Per-sample random permutation prefix (dataset/utils.py:41): int32 (batch, min(n_keep, n_full))."""
+    keys = torch.rand(batch, n_full, device=device, generator=generator)
+    return keys.argsort(dim=1)[:, :min(n_keep, n_full)].to(torch.int32).contiguous()
+
+
+def _take(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    return pointnet2_utils.gather_rows(points.contiguous().float(), idx)
+
+
+def cano_sample_handle_mask(partial_range: float, cano: torch.Tensor, bbox_min: torch.Tensor, bbox_max: torch.Tensor):
+    """dataset/utils.py:56-62 for a batch: cano (B,n,3), bbox_* (B,3) -> bool (B,n)."""
+    head = cano[..., 1] < bbox_min[:, None, 1] + partial_range
+    tail = cano[..., 1] > bbox_max[:, None, 1] - partial_range
+    foot = cano[..., 2] < bbox_min[:, None, 2] + partial_range
+    return head | tail | foot
+
+
+def prepare_batch(cfg_data: dict, cano: dict, src: dict, tgt: dict, surf_idx=None, space_idx=None, noise=None,
+                  generator=None) -> dict:
+    """``cano`` / ``src`` / ``tgt``: dicts of device tensors ``surface_samples`` (B,Nf,3), ``surface_normals`` (B,Nf,3),
+    ``space_samples`` (B,Mf,3).  Returns the reference's data_dict entries (dataset_deform4d_flow.py:226-246),
+    batched, on the device.  ``surf_idx`` / ``space_idx`` (int32) and ``noise`` may be supplied for reproducibility."""
+    if cfg_data.get("partial_shape_ratio", 1.0) < 1.0:
+        raise NotImplementedError("partial_shape_ratio < 1 (hole carving) is outside the MI355X hot path")
+    if not cfg_data["arbitrary"] and cfg_data["inverse"]:
+        src, tgt = tgt, src                                                      # backward network: arbitrary -> canonical
+    cano_full = cano["surface_samples"].float()
+    B, nf, _ = cano_full.shape
+    dev = cano_full.device
+    bbox_min, bbox_max = cano_full.min(dim=1).values, cano_full.max(dim=1).values      # before sub-sampling (:209)
+    if surf_idx is None:
+        surf_idx = random_subset(B, nf, cfg_data["num_surf_samples"], dev, generator)
+    out = {}
+    for key in ("surface_samples", "surface_normals"):
+        for name, d in (("cano", cano), ("src", src), ("tgt", tgt)):
+            out[f"{key}_{name}"] = _take(d[key], surf_idx)
+    mask = cano_sample_handle_mask(cfg_data["partial_range"], out["surface_samples_cano"], bbox_min, bbox_max)
+    maskf = mask[..., None].float()
+    if cfg_data["noise_level"] > 0.0:
+        if noise is None:
+            noise = torch.randn(out["surface_samples_src"].shape, device=dev, generator=generator)
+        out["surface_samples_src"] = out["surface_samples_src"] + cfg_data["noise_level"] * noise
+    out["cano_handle_sample_idx"] = mask[..., None]
+    out["surface_samples_inputs"] = torch.cat([out["surface_samples_src"], out["surface_samples_tgt"] * maskf, maskf],
+                                              dim=-1).contiguous()
+    mf = cano["space_samples"].shape[1]
+    if mf > cfg_data["num_space_samples"]:
+        if space_idx is None:
+            space_idx = random_subset(B, mf, cfg_data["num_space_samples"], dev, generator)
+        for name, d in (("cano", cano), ("src", src), ("tgt", tgt)):
+            out[f"space_samples_{name}"] = _take(d["space_samples"], space_idx)
+    else:
+        for name, d in (("cano", cano), ("src", src), ("tgt", tgt)):
+            out[f"space_samples_{name}"] = d["space_samples"].float().contiguous()
+    return out

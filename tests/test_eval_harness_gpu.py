@@ -78,3 +78,34 @@ def test_short_training_run_through_the_harness(tmp_path):
     # the saved state dict has the reference's keys (loadable by either code base)
     sd = torch.load(os.path.join(str(tmp_path), "model_00002"), map_location="cpu")
     assert "decoder.ct1.fc_gamma.0.weight" in sd and "encoder.enc_sdf.weight" in sd
+
+
+@pytest.mark.parametrize("inverse,noise_level", [(False, 0.0), (True, 0.02)])
+def test_prepare_batch_matches_oracle(inverse, noise_level):
+    from nsdp_amd import dataset
+    from oracle import dataset_ref
+    B, nf, mf = 3, 1500, 900
+    cfg = {"arbitrary": False, "inverse": inverse, "num_surf_samples": 512, "num_space_samples": 400,
+           "partial_range": 0.1, "noise_level": noise_level, "partial_shape_ratio": 1.0}
+    mk = lambda tag, n: np.stack([synth.uniform(40 + b, tag, (n, 3), -0.5, 0.5) for b in range(B)])
+    raw = {r: {"surface_samples": mk(r + "s", nf), "surface_normals": mk(r + "n", nf), "space_samples": mk(r + "q", mf)}
+           for r in ("cano", "src", "tgt")}
+    dev = {r: {k: torch.from_numpy(v).to(DEV) for k, v in d.items()} for r, d in raw.items()}
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    surf_idx = dataset.random_subset(B, nf, 512, DEV, gen)
+    space_idx = dataset.random_subset(B, mf, 400, DEV, gen)
+    noise = torch.randn(B, 512, 3, device=DEV, generator=gen)
+    out = dataset.prepare_batch(cfg, dev["cano"], dev["src"], dev["tgt"], surf_idx, space_idx, noise)
+    assert out["surface_samples_inputs"].shape == (B, 512, 7) and out["space_samples_src"].shape == (B, 400, 3)
+    for b in range(B):
+        pick = lambda r: {k: v[b] for k, v in raw[r].items()}
+        ref = dataset_ref.sample_contract(cfg, pick("cano"), pick("src"), pick("tgt"),
+                                          surf_idxs=surf_idx[b].cpu().numpy(), noise=noise[b].cpu().numpy())
+        for key in ("surface_samples_cano", "surface_samples_tgt", "surface_normals_src", "surface_samples_inputs"):
+            np.testing.assert_allclose(out[key][b].cpu().numpy(), ref[key], rtol=0, atol=1e-7, err_msg=key)
+        assert np.array_equal(out["cano_handle_sample_idx"][b].cpu().numpy(), ref["cano_handle_sample_idx"])
+        sp = space_idx[b].cpu().numpy()
+        src_space = raw["tgt" if inverse else "src"]["space_samples"][b][sp]
+        np.testing.assert_array_equal(out["space_samples_src"][b].cpu().numpy(), src_space)
+    # every index set is a permutation prefix: unique rows
+    assert all(len(set(surf_idx[b].tolist())) == 512 for b in range(B))

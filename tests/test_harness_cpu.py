@@ -94,3 +94,24 @@ def test_eval_metric_oracle_matches_reference_vectors():
         assert eval_metric_ref.chamfer_distance(a, b) == fx[f"c{c}_chamfer"]
         assert eval_metric_ref.compute_dist_square(a[:k], b[:k]) == fx[f"c{c}_l2"]
         assert eval_metric_ref.normal_consistency(fx[f"c{c}_na"], fx[f"c{c}_nb"]) == fx[f"c{c}_fnc"]
+
+
+def test_dataset_contract_oracle_matches_reference_vectors():
+    from oracle import dataset_ref
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset_contract.npz"))
+    np.random.seed(123)
+    c, s, t, idxs = dataset_ref.subsample_surface_flow(300, fx["cano"], fx["src"], fx["tgt"])
+    assert np.array_equal(idxs, fx["idxs"]) and np.array_equal(c, fx["sub_cano"]) and np.array_equal(t, fx["sub_tgt"])
+    mask = dataset_ref.cano_sample_handle_mask(0.1, c, fx["cano"].min(axis=0), fx["cano"].max(axis=0))
+    assert np.array_equal(mask, fx["mask"])
+    np.random.seed(55)
+    sc, ss, st = dataset_ref.subsample_space_flow(200, fx["sp0"], fx["sp1"], fx["sp2"])
+    assert np.array_equal(sc, fx["sc"]) and np.array_equal(ss, fx["ss"]) and np.array_equal(st, fx["st"])
+    np.random.seed(321)
+    cfg = {"arbitrary": False, "inverse": False, "num_surf_samples": 300, "num_space_samples": 10 ** 9,
+           "partial_range": 0.1, "noise_level": 0.02}
+    d = lambda a: {"surface_samples": a, "surface_normals": a, "space_samples": fx["sp0"]}
+    out = dataset_ref.sample_contract(cfg, d(fx["cano"]), d(fx["src"]), d(fx["tgt"]), surf_idxs=fx["idxs"])
+    assert np.array_equal(out["surface_samples_src"], fx["src_noise"])          # same RNG stream as the reference's call
+    assert out["surface_samples_inputs"].shape == (300, 7) and out["surface_samples_inputs"].dtype == np.float32
+    assert np.array_equal(out["surface_samples_inputs"][:, 6] > 0, fx["mask"])
