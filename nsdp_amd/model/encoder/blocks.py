@@ -124,6 +124,33 @@ class TransformerSetAbstraction(nn.Module):
         return new_xyz, ops.batch_norm(new_points, self.bnorm2, addend=ops.index_points(points, fps_idx))
 
 
+class PointNetSetAbstraction(nn.Module):
+    """PointNet++-style set abstraction: FPS, per-point residual MLP, max over the k nearest input points
+    (registry alternate, reference model/encoder/blocks.py:162-217)."""
+
+    def __init__(self, npoint, nneigh, in_channel, dim):
+        super().__init__()
+        self.npoint = npoint
+        self.nneigh = nneigh
+        self.fc1 = nn.Linear(in_channel, dim)
+        self.conv1 = nn.Conv1d(dim, dim, 1)
+        self.conv2 = nn.Conv1d(dim, dim, 1)
+        self.bn1 = nn.BatchNorm1d(dim)
+        self.bn2 = nn.BatchNorm1d(dim)
+        self.bn = nn.BatchNorm1d(dim)
+
+    def forward(self, xyz, points):
+        fps_idx = ops.fps_indices(xyz, self.npoint)
+        new_xyz = ops.index_points(xyz, fps_idx)
+        points = ops.linear(points, self.fc1)
+        points_ori = ops.index_points(points, fps_idx)
+        h = ops.batch_norm(ops.linear(points, self.conv1), self.bn1, relu=True)
+        points = points + ops.batch_norm(ops.linear(h, self.conv2), self.bn2, relu=True)
+        idx = ops.knn_indices(new_xyz, xyz, self.nneigh)
+        new_points = points_ori + ops.index_points(points, idx).max(dim=2)[0]
+        return new_xyz, ops.batch_norm(new_points, self.bn)
+
+
 class TransitionDown(nn.Module):
     """Wrapper selecting the set-abstraction flavour (reference model/encoder/blocks.py:18-49)."""
 
@@ -132,9 +159,7 @@ class TransitionDown(nn.Module):
         if type == "attentive":
             self.sa = TransformerSetAbstraction(npoint, nneighbor, dim)
         elif type == "maxpool":
-            raise NotImplementedError(
-                "PointNetSetAbstraction ('maxpool') is a registry alternate no shipped config selects; "
-                "it is outside the MI355X hot path (SURVEY.md section 8 a20)")
+            self.sa = PointNetSetAbstraction(npoint, nneighbor, dim, dim)
         else:
             raise ValueError("Set Abstraction type " + type + " unknown!")
 

@@ -218,6 +218,54 @@ def point_transformer_encoder(m: _SD, x, kw, has_features):
     return {"z": z, "anchors": xyz, "anchor_feats": feats}
 
 
+def pointnet_set_abstraction(m: _SD, xyz, points, npoint, nneigh):
+    """PointNetSetAbstraction.forward, model/encoder/blocks.py:184-217 (registry alternate, max-pool SA)."""
+    with torch.no_grad():
+        fps_idx = furthest_point_sample(xyz, npoint).long()
+    new_xyz = index_points(xyz, fps_idx)
+    points = m.linear("fc1", points)
+    points_ori = index_points(points, fps_idx)
+    pt = points.permute(0, 2, 1)
+    pt = pt + F.relu(m.bn("bn2", m.conv1x1("conv2", F.relu(m.bn("bn1", m.conv1x1("conv1", pt))))))
+    points = pt.permute(0, 2, 1)
+    idx = knn_indices(new_xyz, xyz, nneigh)
+    new_points = points_ori + torch.max(index_points(points, idx), 2)[0]
+    new_points = m.bn("bn", new_points.permute(0, 2, 1)).permute(0, 2, 1)
+    return new_xyz, new_points
+
+
+def pointnetpp_encoder(m: _SD, x, kw, has_features):
+    """PointNetPlusPlusEncoder.forward, model/encoder/pointnetplusplus.py:70-96."""
+    npl = kw["npoints_per_layer"]
+    if has_features:
+        feats = m.mlp2("fc_begin", x[:, :, 3:].contiguous())
+        xyz = x[:, :, 0:3].contiguous()
+    else:
+        feats, xyz = m.mlp2("fc_begin", x), x
+    for i in range(len(npl) - 1):
+        xyz, feats = pointnet_set_abstraction(m.sub(f"transition_downs.{i}.sa"), xyz, feats, npl[i + 1],
+                                              min(kw["nneighbor"], npl[i]))
+        feats = elementwise_mlp(m.sub(f"elementwise.{i}"), feats)
+    for i in range(kw["nfinal_transformers"]):
+        feats = transformer_block(m.sub(f"final_transformers.{i}"), xyz, feats, -1, group_all=True)
+        feats = elementwise_mlp(m.sub(f"final_elementwise.{i}"), feats)
+    return {"z": m.mlp2("fc_middle", feats.max(dim=1)[0]), "anchors": xyz, "anchor_feats": feats}
+
+
+def point_interp_decoder(m: _SD, xyz_q, enc, kw, n_blocks=5):
+    """PointInterpDecoder.forward, model/decoder/interpolation_decoder.py:47-88 (Gaussian kernel, var = 0.2^2)."""
+    p, fea = enc["anchors"], enc["anchor_feats"]
+    dist = -((p.unsqueeze(1).expand(-1, xyz_q.size(1), -1, -1) - xyz_q.unsqueeze(2)).norm(dim=3) + 10e-6) ** 2
+    weight = (dist / 0.2 ** 2).exp()
+    weight = weight / weight.sum(dim=2).unsqueeze(-1)
+    lat = m.linear("fc0", weight @ fea)
+    net = m.linear("fc1", F.relu(lat))
+    for i in range(n_blocks):
+        net = net + m.linear(f"fc_c.{i}", lat)
+        net = net + m.linear(f"blocks.{i}.fc_1", F.relu(m.linear(f"blocks.{i}.fc_0", F.relu(net))))
+    return m.linear("fc_out", F.relu(net))
+
+
 def cross_transformer_block(m: _SD, xyz_q, lat_rep, xyz, points, nneigh, dim):
     """CrossTransformerBlock.forward, model/decoder/blocks.py:48-95 (separate_delta=True)."""
     knn_idx = knn_indices(xyz_q, xyz, nneigh)
@@ -258,17 +306,18 @@ def deformation_network(sd, model_cfg, points, surface_samples_inputs, no_input_
                         prefix="", tape=None):
     """Deformation_Networks.forward, model/deformation_networks.py:43-60 (+ ctor logic :17-30)."""
     m = _SD(sd, prefix, training, tape)
-    assert model_cfg["encoder"] == "pointransformer" and model_cfg["decoder"] == "crossatten"
     assert not model_cfg.get("use_normals", False)
+    encoder = {"pointransformer": point_transformer_encoder, "pointnet++": pointnetpp_encoder}[model_cfg["encoder"]]
     if no_input_corr:
-        enc = point_transformer_encoder(m.sub("encoder"), surface_samples_inputs[:, :, 0:3].contiguous(),
-                                        model_cfg["encoder_kwargs"], has_features=False)
+        enc = encoder(m.sub("encoder"), surface_samples_inputs[:, :, 0:3].contiguous(),
+                      model_cfg["encoder_kwargs"], has_features=False)
     else:
-        enc = point_transformer_encoder(m.sub("encoder"), surface_samples_inputs,
-                                        model_cfg["encoder_kwargs"], has_features=True)
+        enc = encoder(m.sub("encoder"), surface_samples_inputs, model_cfg["encoder_kwargs"], has_features=True)
     if tape is not None:
         tape[prefix + "anchors"] = enc["anchors"].detach().clone()
         tape[prefix + "anchor_feats"] = enc["anchor_feats"].detach().clone()
+    if model_cfg["decoder"] == "interp":
+        return point_interp_decoder(m.sub("decoder"), points, enc, model_cfg["decoder_kwargs"])
     return cross_transformer_decoder(m.sub("decoder"), points, enc, model_cfg["decoder_kwargs"])
 
 
