@@ -347,7 +347,12 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
       if constexpr (kXLds) xwait_older();   // next block's weights have landed (the activations after next may still fly)
       else xwait();                         // next block's weights (DMA) and the raw registers of the block after next
       X3_T(t_k2);
-      __syncthreads();    // every wave is done reading wbuf[buf]
+      // raw barrier: __syncthreads() carries a fence that drains vmcnt(0) whenever an LDS-DMA is pending -- exactly
+      // the activation prefetch this loop wants to keep in flight across the barrier.  Every wave has waited for
+      // its own share of the next weight block above, so after the barrier the whole block is in LDS.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();    // every wave is done reading wbuf[buf]
+      asm volatile("" ::: "memory");
       X3_T(t_k3);
       X3_ADD(0, t_k0, t_k1); X3_ADD(1, t_k1, t_k2); X3_ADD(2, t_k2, t_k3);
       cur = nxt;
