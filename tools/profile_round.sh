@@ -13,10 +13,12 @@ python bench.py --workload dense_inference --no-cpu-baseline > gpurun_out/${tag}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o ${tag} -- \
   python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}.log 2>&1
+NSDP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_iso -o ${tag}_iso -- \
+  python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_iso.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- \
-  python $R/bench.py --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
+  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- \
-  python $R/bench.py --steps 1 --warmup 1 --batch 8 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+  python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
 NSDP_WGRAD_STREAM=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -o s -- \
   python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1

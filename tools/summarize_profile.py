@@ -23,19 +23,23 @@ def short(name):
     return (m.group(1) if m else name)[:90]
 
 
-stats = os.path.join(root, "gpurun_out", f"prof_{tag}", f"{tag}_kernel_stats.csv")
-if os.path.exists(stats):
+for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
+                      ("_iso", "NSDP_WGRAD_STREAM=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
+                               "(weight gradients on the main stream: every duration is the kernel alone -- the profile "
+                               "that matches bench.py's `roofline`)")):
+    stats = os.path.join(root, "gpurun_out", f"prof_{tag}{suffix}", f"{tag}{suffix}_kernel_stats.csv")
+    if not os.path.exists(stats):
+        continue
     rows = list(csv.DictReader(open(stats)))
     total = sum(float(r["TotalDurationNs"]) for r in rows)
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats.md"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats ({tag}): python bench.py --steps 5 --warmup 2 --no-cpu-baseline\n\n")
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.md"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats ({tag}): {title}\n\n")
         f.write(f"total kernel time {total/1e6:.1f} ms over 7 steps (2 warm-up + 5 timed), B=32 shapes\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
-        for r in rows[:45]:
+        for r in rows[:50]:
             f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
                     f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-    # keep the raw stats CSV too (small)
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats.csv"), "w") as f:
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:   # keep the raw stats CSV too (small)
         f.write(open(stats).read())
 
 pmc = {}
@@ -56,7 +60,7 @@ if pmc:
     names = sorted(set().union(*[set(v) for v in pmc.values()]),
                    key=lambda n: -sum(pmc[k][n][1] for k in pmc if n in pmc[k]))
     with open(os.path.join(out_dir, f"{tag}_pmc_hbm.md"), "w") as f:
-        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 --batch 8\n\n")
+        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 (B = 32, the default workload)\n\n")
         f.write("Counter unit = KiB as reported.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
                 "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n")
         f.write("| kernel | launches | FETCH_SIZE sum KiB | fetch x2 MiB | WRITE_SIZE sum KiB | max launch fetch KiB | max launch write KiB |\n|---|---:|---:|---:|---:|---:|---:|\n")
