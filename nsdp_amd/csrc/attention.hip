@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     if (pt >= total) break;
     const int b = static_cast<int>(pt / s.n);
     const float *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d : nullptr;
-    float *dvfb = HAS_V ? dvf + static_cast<long long>(b) * s.N * s.d : nullptr;
+    float *dvfb = (HAS_V && dvf) ? dvf + static_cast<long long>(b) * s.N * s.d : nullptr;   // null: scatter done elsewhere
     const int32_t *ip = idx + pt * s.k;
     const long long r0 = pt * s.k * s.d;
     const Quad g = ldq(dy + pt * s.d, cq, lpp);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
       stq(da + rj, cq, lpp,
           Quad{ds.x * (sv.x - yb.x), ds.y * (sv.y - yb.y), ds.z * (sv.z - yb.z), ds.w * (sv.w - yb.w)});
       stq(dpos + rj, cq, lpp, ds);
-      if (HAS_V) atomic_addq(dvfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, ds);
+      if (HAS_V && dvfb) atomic_addq(dvfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, ds);
     }
     if (has_g) {
       if (b != gb) {
@@ -446,6 +446,82 @@ __global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-table scatter: table[b][idx[r]][c] += sign * src[r][c] over the rows r of shape b (and optionally the
+// column sum of src), for a table of at most 128 rows x 256 channels per shape (the decoder's 100 anchors).
+// One lane owns one channel and keeps its column of the table -- 128 floats -- in four 32-register vectors that
+// are indexed dynamically (s_set_gpr_idx): no LDS, no atomics in the loop (LDS float atomics retire ~1 lane per
+// clock and made the LDS-table kernels 5x slower than their traffic).  All four vectors are updated
+// unconditionally with a masked addend: a switch over the vector would make the tables loop-carried phis and
+// hipcc then copies whole vectors around.  Rows are fetched UNROLL at a time (one 4-byte scalar index and one
+// coalesced d*4-byte row each); the table is flushed with global atomics once per workgroup.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x32_t __attribute__((ext_vector_type(32)));
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *__restrict__ src,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  float *__restrict__ table, float *__restrict__ colsum,
+                                                                  long long rows_per_shape, long long rows_per_wg, int N,
+                                                                  int d, float sign, float colsum_sign) {
+  f32x32_t t0 = {}, t1 = {}, t2 = {}, t3 = {};
+  const int c = threadIdx.x, b = blockIdx.y;
+  const bool cv = c < d;
+  const long long begin = static_cast<long long>(blockIdx.x) * rows_per_wg;
+  long long end = begin + rows_per_wg;
+  end = end < rows_per_shape ? end : rows_per_shape;
+  const long long base = static_cast<long long>(b) * rows_per_shape;
+  const float *p = src + base * d + (cv ? c : 0);
+  const int32_t *ip = idx + base;
+  float total = 0.f;
+  for (long long r = begin; r < end; r += UNROLL) {
+    float x[UNROLL];
+    int a[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long rr = r + u < end ? r + u : end - 1;          // clamped: the tail re-reads the last row, masked below
+      x[u] = p[rr * d];
+      a[u] = __builtin_amdgcn_readfirstlane(ip[rr]);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int i = a[u] & 31, g = a[u] >> 5;
+      const float v = (cv && r + u < end) ? x[u] : 0.f;
+      total += v;
+      t0[i] += g == 0 ? v : 0.f;
+      t1[i] += g == 1 ? v : 0.f;
+      t2[i] += g == 2 ? v : 0.f;
+      t3[i] += g == 3 ? v : 0.f;
+    }
+  }
+  if (cv) {
+    float *o = table + static_cast<long long>(b) * N * d + c;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (i < N && t0[i] != 0.f) atomicAdd(o + static_cast<long long>(i) * d, sign * t0[i]);
+      if (32 + i < N && t1[i] != 0.f) atomicAdd(o + static_cast<long long>(32 + i) * d, sign * t1[i]);
+      if (64 + i < N && t2[i] != 0.f) atomicAdd(o + static_cast<long long>(64 + i) * d, sign * t2[i]);
+      if (96 + i < N && t3[i] != 0.f) atomicAdd(o + static_cast<long long>(96 + i) * d, sign * t3[i]);
+    }
+    if (colsum) atomicAdd(colsum + static_cast<long long>(b) * d + c, colsum_sign * total);
+  }
+}
+
+inline bool regtab_fits(int N, int d, long long rows_per_shape) { return N <= 128 && d <= 256 && rows_per_shape >= 4096; }
+
+// table (zero-filled by the caller) += sign * scatter(src); colsum (zero-filled, may be null) += colsum_sign * sum_r src[r]
+inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *table, float *colsum, int B,
+                                 long long rows_per_shape, int N, int d, float sign, float colsum_sign, hipStream_t st) {
+  long long wgs = (4LL * nsdp::num_cus() + B - 1) / B;                 // ~4 workgroups per CU in total
+  if (wgs * 512 > rows_per_shape) wgs = rows_per_shape / 512 > 0 ? rows_per_shape / 512 : 1;
+  long long per = (rows_per_shape + wgs - 1) / wgs;
+  per = (per + 7) / 8 * 8;
+  wgs = (rows_per_shape + per - 1) / per;
+  hipLaunchKernelGGL((scatter_rows_regtab_kernel<8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
+                     colsum, rows_per_shape, per, N, d, sign, colsum_sign);
+  return nsdp::launch_status("scatter_rows_regtab_kernel");
+}
+
 inline bool lds_table_fits(const AttnShape &s) {
   return static_cast<long long>(s.N) * s.d * 4 <= 110 * 1024 && s.B <= 65535 && s.n >= 4 * s.N;
 }
@@ -521,6 +597,10 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           4.0 * (rows(s) * (d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
+  if (q_per_shape && regtab_fits(N, d, static_cast<long long>(n) * k)) {
+    // decoder: one query vector per shape.  dkf = -scatter(du), dq = +column sum of du: the register-table scatter
+    return launch_regtab_scatter(du, idx, dkf, dq, B, static_cast<long long>(n) * k, N, d, -1.f, 1.f, st);
+  }
   if (lds_table_fits(s)) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
     allow_big_lds(attn_pre_bwd_lds_kernel, lds);
