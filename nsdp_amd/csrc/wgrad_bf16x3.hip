@@ -222,12 +222,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     const float colsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     dbsum[r] += real ? colsum : 0.f;     // (the split after the last block works on stale registers)
     u32x4 h, m, l;
+#ifdef WG3_ABLATE_NO_SPLIT
+    for (int q = 0; q < 4; ++q) { h[q] = __builtin_bit_cast(unsigned, v[2 * q]); m[q] = __builtin_bit_cast(unsigned, v[2 * q + 1]); l[q] = h[q] ^ m[q]; }
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       unsigned a, b, c;
       split_pair(v[2 * q], v[2 * q + 1], a, b, c);
       h[q] = a; m[q] = b; l[q] = c;
     }
+#endif
     char *dst = reinterpret_cast<char *>(&planes[0]) + buf_off + ldsA[r];
     *reinterpret_cast<u32x4 *>(dst) = h;
     *reinterpret_cast<u32x4 *>(dst + 1024) = m;
@@ -242,12 +246,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
       v[j] = g8B[r] + j < rows_left ? x : 0.f;
     }
     u32x4 h, m, l;
+#ifdef WG3_ABLATE_NO_SPLIT
+    for (int q = 0; q < 4; ++q) { h[q] = __builtin_bit_cast(unsigned, v[2 * q]); m[q] = __builtin_bit_cast(unsigned, v[2 * q + 1]); l[q] = h[q] ^ m[q]; }
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       unsigned a, b, c;
       split_pair(v[2 * q], v[2 * q + 1], a, b, c);
       h[q] = a; m[q] = b; l[q] = c;
     }
+#endif
     char *dst = reinterpret_cast<char *>(&planes[0]) + buf_off + ldsB[r];
     *reinterpret_cast<u32x4 *>(dst) = h;
     *reinterpret_cast<u32x4 *>(dst + 1024) = m;
@@ -324,10 +332,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
         // immediately and have a whole block of MFMAs to land.
         if constexpr (st < RA) {
           produce_a(st, nbuf, rl_next, ib + 1 < nblk);
+#ifndef WG3_ABLATE_NO_LOADS
           if (ib + 2 < nblk) issue_a(st, mb0 + ib + 2);
+#endif
         } else if constexpr (st < kSlots) {
           produce_b(st - RA, nbuf, rl_next);
+#ifndef WG3_ABLATE_NO_LOADS
           if (ib + 2 < nblk) issue_b(st - RA, mb0 + ib + 2);
+#endif
         }
         if constexpr (st == kSlots - 1) advance();
 #pragma unroll
