@@ -31,7 +31,7 @@ PER_FILE = {
     "pointnet2_ops.hip": EXACT,
     # -O3 turns the uniform base pointers of this file's hand-placed `global_load ... s[base]` asm operands into
     # VGPR copies (rejected by the assembler); -O2 keeps them scalar
-    "wgrad_bf16x3.hip": FAST + ["-O2"],
+    "wgrad_bf16x3.hip": FAST + ["-O2", "-fno-slp-vectorize"],
 }
 
 
@@ -40,7 +40,8 @@ def sources():
 
 
 def _deps_mtime():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER]
+    # (this file too: the compiler flags live here)
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER, os.path.abspath(__file__)]
     return max(os.path.getmtime(h) for h in hs)
 
 

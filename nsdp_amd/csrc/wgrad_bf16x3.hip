@@ -34,6 +34,16 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 
+#ifdef WG3_TIMING
+// phase timers (s_memtime ticks summed over waves): 0 producer steps, 1 plain steps, 2 bottom wait, 3 barrier, 4 total
+__device__ unsigned long long g_wg3_timers[8];
+#define WG3_T(var) var = __builtin_readcyclecounter()
+#define WG3_ADD(i, a, b) t_acc[i] += (b) - (a)
+#else
+#define WG3_T(var)
+#define WG3_ADD(i, a, b)
+#endif
+
 struct WgX3Params {
   const float *dY, *X, *mask;
   int relu_x;
@@ -296,7 +306,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   constexpr int kPasses = (TA + kAH - 1) / kAH;
   static_assert(kSlots <= kPasses * TB, "one producer slot per consumer step");
 
+#ifdef WG3_TIMING
+  unsigned long long t_acc[4] = {0, 0, 0, 0}, t_prev, t_now;
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   for (int ib = 0; ib < nblk; ++ib) {
+    WG3_T(t_prev);
     const unsigned buf = static_cast<unsigned>(ib & 1) * kBufBytes, nbuf = kBufBytes - buf;
     const int rl_next = rows_in(mb0 + ib + 1 < mb_all ? mb0 + ib + 1 : mb_all - 1);
     // A fragments are held for at most kAH n tiles at a time (TA > kAH: two passes over the k tiles; the extra
@@ -367,11 +382,24 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
           lds_wait3(nh, nm, nl);
           bh = nh; bm = nm; bl = nl;
         }
+        WG3_T(t_now);
+        WG3_ADD(st < kSlots ? 0 : 1, t_prev, t_now);
+        WG3_T(t_prev);
       });
     });
     gwait();            // the block after next has landed in the raw registers
+    WG3_T(t_now);
+    WG3_ADD(2, t_prev, t_now);
     __syncthreads();    // next buffer complete, this buffer free
+    WG3_T(t_prev);
+    WG3_ADD(3, t_now, t_prev);
   }
+#ifdef WG3_TIMING
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_wg3_timers[i], t_acc[i]);
+    atomicAdd(&g_wg3_timers[4], __builtin_readcyclecounter() - t_begin);
+  }
+#endif
 
   // ---- partial results: fragment-ordered float4 per (n tile, k tile), then the bias-gradient partial ----
   float *wsp = p.ws + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) *
@@ -521,5 +549,13 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
                      workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
   return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
 }
+
+#ifdef WG3_TIMING
+void nsdp_debug_wg3_timers(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg3_timers), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_wg3_timers), z, sizeof(z)); }
+}
+#endif
 
 }  // extern "C"
