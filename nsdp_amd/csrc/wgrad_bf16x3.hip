@@ -96,7 +96,9 @@ __device__ __forceinline__ void lds_wait3(u32x4 &a, u32x4 &b, u32x4 &c) {
 
 // NTA / KTB: 16-column tiles of dY / X.  Wave (a, b) = (wave >> 1, wave & 1) owns n tiles [a TA, a TA + TA) and
 // k tiles [b TB, b TB + TB).
-template <int NTA, int KTB, bool MASK>
+// TAIL: M is not a multiple of 32 (the last block of the matrix is partial).  Without it the row clamps and row
+// masks are compiled out: ~30 % of the VALU work of a producer step, and the producer steps are VALU-bound.
+template <int NTA, int KTB, bool MASK, bool TAIL>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
   constexpr int kTiles = NTA + KTB;
@@ -124,15 +126,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   // it loads, splits and writes exactly the same values to the same place.  Three registers per slot:
   unsigned offA[RA], offB[RB];       // byte offset of (row 32 mb + 8 g', column) in dY / X, mb = next block to load
   unsigned ldsA[RA], ldsB[RB];       // byte offset of the slot's fragment entry inside a plane buffer
-  int g8A[RA], g8B[RB];              // 8 g' if the column is inside the matrix, else a huge value: row j of the
-                                     // slot is valid  <=>  g8 + j < rows of the block
+  int g8A[RA], g8B[RB];              // 8 g' (TAIL only): row j of the slot is valid  <=>  g8 + j < rows of the block
+  // Padding columns (col >= N / Kpart) re-read the last real column and are NOT zeroed: they only reach rows /
+  // columns of the partial result that the reduce kernel never reads.
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
     int s = tid + 256 * r;
     s = s < 4 * kColsA ? s : s - 256;
     const int gp = s / kColsA, col = s % kColsA;
     const int colc = col < N ? col : (N - 1);
-    g8A[r] = col < N ? 8 * gp : (1 << 20);
+    g8A[r] = 8 * gp;
     offA[r] = static_cast<unsigned>(((mb0 * 32 + 8 * gp) * N + colc) * 4);
     ldsA[r] = static_cast<unsigned>((((col >> 4) * 3) * 64 + 16 * gp + (col & 15)) * 16);
   }
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     s = s < 4 * kColsB ? s : s - 256;
     const int gp = s / kColsB, col = s % kColsB;
     const int colc = k_off + (col < Kpart ? col : (Kpart - 1));
-    g8B[r] = col < Kpart ? 8 * gp : (1 << 20);
+    g8B[r] = 8 * gp;
     offB[r] = static_cast<unsigned>(((mb0 * 32 + 8 * gp) * K + colc) * 4);
     ldsB[r] = static_cast<unsigned>(((NTA * 3 + (col >> 4) * 3) * 64 + 16 * gp + (col & 15)) * 16);
   }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   // rows past M (only the very last block of the matrix can have them) are re-read from row M-1 and zeroed by
   // `rows_left` in the split; all other blocks take the unclamped path (one add per load)
   auto issue_a = [&](int r, long long mb) {
-    if (mb * 32 + 32 <= Mrows) {
+    if (!TAIL || mb * 32 + 32 <= Mrows) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned off = offA[r] + static_cast<unsigned>(j) * strideA;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
       const int last_row = static_cast<int>(Mrows - 1 - mb * 32);      // >= 0
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int g8 = g8A[r] & 31;                              // (padding columns: any in-range row will do)
+        const int g8 = g8A[r];
         int rr = g8 + j;
         rr = rr <= last_row ? rr : last_row;
         const unsigned off = offA[r] + static_cast<unsigned>(rr - g8) * strideA;
@@ -179,14 +182,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     }
   };
   auto issue_b = [&](int r, long long mb) {
-    if (mb * 32 + 32 <= Mrows) {
+    if (!TAIL || mb * 32 + 32 <= Mrows) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) gload(rawB[r][j], Xp, offB[r] + static_cast<unsigned>(j) * strideB);
     } else {
       const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int g8 = g8B[r] & 31;
+        const int g8 = g8B[r];
         int rr = g8 + j;
         rr = rr <= last_row ? rr : last_row;
         gload(rawB[r][j], Xp, offB[r] + static_cast<unsigned>(rr - g8) * strideB);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     for (int j = 0; j < 8; ++j) {
       float x = rawA[r][j];
       if (MASK) x = rawM[r][j] > 0.f ? x : 0.f;
-      v[j] = g8A[r] + j < rows_left ? x : 0.f;
+      v[j] = (!TAIL || g8A[r] + j < rows_left) ? x : 0.f;
     }
     const float colsum = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     dbsum[r] += real ? colsum : 0.f;     // (the split after the last block works on stale registers)
@@ -247,13 +250,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     *reinterpret_cast<u32x4 *>(dst + 1024) = m;
     *reinterpret_cast<u32x4 *>(dst + 2048) = l;
   };
+  const float relu_floor = p.relu_x ? 0.f : -__builtin_inff();
   auto produce_b = [&](int r, unsigned buf_off, int rows_left) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float x = rawB[r][j];
-      if (p.relu_x) x = fmaxf(x, 0.f);
-      v[j] = g8B[r] + j < rows_left ? x : 0.f;
+      // max(x, floor) in one instruction (floor = 0 or -inf, wave-uniform).  No row mask on this side: a zeroed
+      // dY row already removes the clamped re-read of row M-1 from every product
+      v[j] = __builtin_amdgcn_fmed3f(rawB[r][j], relu_floor, __builtin_inff());
     }
     u32x4 h, m, l;
 #ifdef WG3_ABLATE_NO_SPLIT
@@ -318,8 +322,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
     // LDS reads of B are cheap, 84 live fragment registers are not).  Global step index st = pass * TB + b.
     static_for<0, kPasses>([&](auto P) {
       constexpr int pass = decltype(P)::value;
-      constexpr int a0 = pass * kAH;
-      constexpr int na = (TA - a0) < kAH ? (TA - a0) : kAH;
+      // the short pass (TA % kAH tiles) goes first: the producer steps 0 .. kSlots-1 then run where fewest fragment
+      // registers are live (with the full pass first the scheduler gave up interleaving the split of the last
+      // two slots with the MFMAs -- register pressure at the pass switch)
+      constexpr int kShort = TA % kAH;
+      constexpr int a0 = (kShort == 0) ? pass * kAH : (pass == 0 ? 0 : kShort + (pass - 1) * kAH);
+      constexpr int na = (kShort != 0 && pass == 0) ? kShort : kAH;
+      static_assert(a0 + na <= TA, "pass geometry");
       u32x4 ah[na], am[na], al[na];
       static_for<0, na>([&](auto I) {
         constexpr int a = decltype(I)::value;
@@ -345,18 +354,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
         // MFMAs; unconditional: after the last block it re-splits stale registers into the unused buffer).  A
         // slot's raw registers are free as soon as it is split: the loads of the block after next follow
         // immediately and have a whole block of MFMAs to land.
-        if constexpr (st < RA) {
-          produce_a(st, nbuf, rl_next, ib + 1 < nblk);
-#ifndef WG3_ABLATE_NO_LOADS
-          if (ib + 2 < nblk) issue_a(st, mb0 + ib + 2);
-#endif
-        } else if constexpr (st < kSlots) {
-          produce_b(st - RA, nbuf, rl_next);
-#ifndef WG3_ABLATE_NO_LOADS
-          if (ib + 2 < nblk) issue_b(st - RA, mb0 + ib + 2);
-#endif
-        }
-        if constexpr (st == kSlots - 1) advance();
+        // split first, loads after the MFMAs: the (uniform) branches around the loads end the basic block, and the
+        // scheduler interleaves VALU with MFMAs only inside one block -- so the split and this step's MFMAs
+        // have to be in the same one
+        if constexpr (st < RA) produce_a(st, nbuf, rl_next, ib + 1 < nblk);
+        else if constexpr (st < kSlots) produce_b(st - RA, nbuf, rl_next);
 #pragma unroll
         for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(al[a], bh, acc[a0 + a][b]);
 #pragma unroll
@@ -378,6 +380,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
         }
 #pragma unroll
         for (int a = 0; a < na; ++a) asm volatile("" : "+a"(acc[a0 + a][b]));   // pin the MFMAs to this step
+#ifndef WG3_ABLATE_NO_LOADS
+        // a slot's raw registers are free as soon as it is split: the loads of the block after next follow
+        if constexpr (st < RA) {
+          if (ib + 2 < nblk) issue_a(st, mb0 + ib + 2);
+        } else if constexpr (st < kSlots) {
+          if (ib + 2 < nblk) issue_b(st - RA, mb0 + ib + 2);
+        }
+#endif
+        if constexpr (st == kSlots - 1) advance();
         if constexpr (b + 1 < TB) {
           lds_wait3(nh, nm, nl);
           bh = nh; bm = nm; bl = nl;
@@ -505,8 +516,14 @@ X3Plan plan_x3(long long M, int N, int K) {
 template <int NTA, int KTB>
 void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
   const dim3 g(grid, p.kparts);
-  if (p.mask) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true>), g, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false>), g, dim3(256), 0, st, p);
+  const bool tail = (p.M & 31) != 0;
+  if (p.mask) {
+    if (tail) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true, false>), g, dim3(256), 0, st, p);
+  } else {
+    if (tail) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false, false>), g, dim3(256), 0, st, p);
+  }
 }
 
 }  // namespace

@@ -97,6 +97,9 @@ WG_CASES = [  # (M, N, K, mask, relu_x)
     (5000, 256, 256, True, False),       # N = 256 (16 tiles), columns of X split over grid.y
     (3200, 200, 256, False, False),      # K = 256 with a 13-tile dY
     (2500, 256, 200, False, True),       # 16 + 13 tiles would not fit in LDS: K split 128 + 72
+    (4096, 120, 128, True, True),        # M % 32 == 0: the variants without row clamps / row masks
+    (65536, 200, 120, True, True),
+    (32768, 256, 200, False, True),
 ]
 
 

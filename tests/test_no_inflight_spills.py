@@ -1,7 +1,7 @@
 """The split-precision / fused kernels issue some loads by hand (`asm volatile` global_load / ds_read whose completion
 the compiler does not track).  That is only sound if the compiler never spills or copies a destination register
-while the load is in flight -- i.e. no scratch store and no VGPR->AGPR parking inside the MFMA regions of those
-kernels.  This test compiles the three translation units to gfx950 assembly and checks exactly that, per kernel
+while the load is in flight -- i.e. no scratch store and no VGPR->AGPR parking of a load destination inside the
+MFMA regions of those kernels.  This test compiles the three translation units to gfx950 assembly and checks exactly that, per kernel
 variant (the same audit that was used while writing them).
 
 A second, performance-only rule for the weight-gradient kernel: no scratch at all.  A reload in its block loop has
@@ -27,6 +27,37 @@ FILES = {  # translation unit -> kernel-name regex
     "decoder_fused.hip": r"decoder_fused_fwd_kernel",
 }
 NO_SCRATCH = ("decoder_fused.hip", "wgrad_bf16x3.hip")
+
+
+def _defines(line, reg):
+    """Does this instruction write VGPR `reg` (first operand vN or v[a:b])?"""
+    parts = line.strip().split(None, 1)
+    if len(parts) < 2 or parts[0].startswith(("s_", ";", ".")):
+        return False
+    dst = parts[1].split(",")[0].strip()
+    m = re.fullmatch(r"v(\d+)", dst)
+    if m:
+        return int(m.group(1)) == reg
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", dst)
+    return bool(m) and int(m.group(1)) <= reg <= int(m.group(2))
+
+
+def _parked_loads(body, lo, hi):
+    """v_accvgpr_write instructions in body[lo:hi] whose source VGPR was last written by a hand-issued load
+    (global_load / ds_read): a register the compiler must not copy before the matching s_waitcnt.  Accumulator
+    shuffles (v_accvgpr_read -> v_accvgpr_write) are the compiler's own business and are fine."""
+    bad = []
+    for i in range(lo, hi):
+        m = re.match(r"\s*v_accvgpr_write_b32 a\d+, v(\d+)", body[i])
+        if not m:
+            continue
+        reg = int(m.group(1))
+        for j in range(i - 1, -1, -1):
+            if _defines(body[j], reg):
+                if body[j].strip().startswith(("global_load", "ds_read")):
+                    bad.append(body[i].strip() + "   <- " + body[j].strip())
+                break
+    return bad
 
 
 def _asm(item):
@@ -59,7 +90,8 @@ def test_nothing_is_spilled_inside_the_mfma_regions():
             if src != "decoder_fused.hip":
                 # (the decoder is one MFMA chain whose accumulators are initialised from activation vectors:
                 # legitimate VGPR -> AGPR moves)
-                bad += [l.strip() for l in region if "scratch_store" in l or "v_accvgpr_write" in l]
+                bad += [l.strip() for l in region if "scratch_store" in l]
+                bad += _parked_loads(body, mf[0], mf[-1])
             assert not bad, (src, lines[a][:80], bad[:3])
             checked += 1
     assert checked >= 20
