@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
     }
     if (PRE == 2) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+      for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(v[c], 0.f, __builtin_inff());   // max(v, 0), one VALU op
     }
     unsigned h, m, l;
     split_pair(v[2 * (pr & 1)], v[2 * (pr & 1) + 1], h, m, l);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
   constexpr int kConvFirst = kXLds ? NT - kConvSteps : 0;     // first n-tile step that carries split work
   constexpr int kPairs = MT * 4;
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
-  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 11 : 9) + 6 * MT - 1) / (6 * MT);
+  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 10 : 9) + 6 * MT - 1) / (6 * MT);
 
 #ifdef NSDP_X3_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
