@@ -34,7 +34,11 @@ for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseli
     total = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.md"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats ({tag}): {title}\n\n")
-        f.write(f"total kernel time {total/1e6:.1f} ms over 7 steps (2 warm-up + 5 timed), B=32 shapes\n\n")
+        # the decoder's kNN runs exactly once per train step: its call count is the number of steps in the trace
+        # (set-up steps + warm-up + timed + the isolated roofline pass of bench.py)
+        nsteps = next((int(r["Calls"]) for r in rows if "fps_reg_kernel" in r["Name"]), 0)
+        per = f" = {total/1e6/nsteps:.1f} ms of kernel time per step" if nsteps else ""
+        f.write(f"total kernel time {total/1e6:.1f} ms over {nsteps} train steps{per}, B=32 shapes\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
         for r in rows[:50]:
             f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
@@ -70,8 +74,8 @@ if pmc:
             f.write(f"| `{n}` | {fe[0] or wr[0]} | {fe[1]:.0f} | {2*fe[1]/1024:.1f} | {wr[1]:.0f} | {fe[2]:.0f} | {wr[2]:.0f} |\n")
     json.dump({k: {n: v for n, v in agg.items()} for k, agg in pmc.items()},
               open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=0)
-for name in ("bench_default.json", f"prof_{tag}_bench.json"):
-    src = os.path.join(root, "gpurun_out", name)
-    if os.path.exists(src):
+for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json"):
+    src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
+    if os.path.exists(src) and open(src).read().strip():
         open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
 print("wrote", sorted(os.listdir(out_dir)))
