@@ -232,6 +232,10 @@ int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const
  * Kernel timing with HIP events on the launch stream (used by bench.py for the roofline object)
  * -------------------------------------------------------------------------------------------- */
 void nsdp_prof_enable(int on);            /* on=1 clears previous records and starts recording */
+/* same, for a subset: bit k of `mask` = time the kernels of kind k (nsdp_prof_name(k)); 0 stops.  An event pair per
+ * launch keeps consecutive kernels from overlapping head-to-tail: timing all ~500 launches of a train step costs
+ * ~3 ms of a 52 ms step, timing one kernel class a few hundred microseconds. */
+void nsdp_prof_enable_kinds(unsigned mask);
 int nsdp_prof_num_kinds(void);
 const char *nsdp_prof_name(int kind);
 /* Sums over all recorded launches of `kind`: count, elapsed ms, algorithmic flops and bytes. */

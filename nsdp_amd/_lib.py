@@ -7,6 +7,7 @@ tensors, _ext-src/src/sampling.cpp:82-84).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import re
@@ -52,7 +53,17 @@ def check(rc: int, what: str):
         raise NsdpHipError(f"{what} failed (status {rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+_NO_GUARD = contextlib.nullcontext()
+
+
 def stream_ptr() -> ctypes.c_void_p:
+    """The current HIP stream of the current device as a raw handle (one C call: the step launches ~500 kernels,
+    torch.cuda.current_stream() alone was 15 % of the host time of a small-batch step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -85,4 +96,6 @@ def on_device(t: torch.Tensor):
     """Context manager selecting the tensor's GPU; refuses CPU tensors (no fallback)."""
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise NsdpHipError("expected a GPU tensor (CPU not supported, no fallback)")
+    if t.device.index == torch.cuda.current_device():      # one process per GPU: the usual case, no guard needed
+        return _NO_GUARD
     return torch.cuda.device(t.device)

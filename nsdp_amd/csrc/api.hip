@@ -27,7 +27,7 @@ struct Record {
   hipEvent_t start, stop;
   double flops, bytes;
 };
-std::atomic<int> g_enabled{0};
+std::atomic<unsigned> g_enabled{0};   // bit k: kernels of Kind k are timed
 std::mutex g_mu;
 std::vector<Record> g_records;
 std::vector<hipEvent_t> g_pool;
@@ -53,7 +53,7 @@ const char *kind_name(int kind) {
 }
 
 Scope::Scope(Kind kind, hipStream_t stream, double flops, double bytes) : slot_(-1), stream_(stream) {
-  if (!g_enabled.load(std::memory_order_relaxed)) return;
+  if (!((g_enabled.load(std::memory_order_relaxed) >> static_cast<int>(kind)) & 1u)) return;
   std::lock_guard<std::mutex> lock(g_mu);
   Record r{static_cast<int>(kind), get_event(), get_event(), flops, bytes};
   if (!r.start || !r.stop) return;
@@ -86,9 +86,12 @@ int nsdp_device_count(void) {
   return n;
 }
 
-void nsdp_prof_enable(int on) {
+void nsdp_prof_enable(int on) { nsdp_prof_enable_kinds(on ? ~0u : 0u); }
+
+void nsdp_prof_enable_kinds(unsigned mask) {
   using namespace nsdp::prof;
   std::lock_guard<std::mutex> lock(g_mu);
+  const int on = mask != 0;
   if (on) {
     for (auto &r : g_records) {
       g_pool.push_back(r.start);
@@ -96,7 +99,7 @@ void nsdp_prof_enable(int on) {
     }
     g_records.clear();
   }
-  g_enabled.store(on ? 1 : 0);
+  g_enabled.store(mask);
 }
 
 int nsdp_prof_num_kinds(void) { return nsdp::prof::kNumKinds; }

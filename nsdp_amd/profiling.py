@@ -25,11 +25,23 @@ def available() -> bool:
     return hasattr(_lib.lib(), "nsdp_prof_enable")
 
 
-def start():
+def start(only=None):
+    """Start timing; ``only`` = iterable of kernel names (nsdp_prof_name) to restrict the HIP events to -- an event
+    pair per launch is not free (it keeps consecutive kernels from overlapping head-to-tail)."""
     global _active
-    if available():
-        _lib.lib().nsdp_prof_enable(1)
-        _active = True
+    if not available():
+        return
+    lib = _lib.lib()
+    if only is None:
+        lib.nsdp_prof_enable(1)
+    else:
+        lib.nsdp_prof_name.restype = ctypes.c_char_p
+        names = [lib.nsdp_prof_name(k).decode() for k in range(lib.nsdp_prof_num_kinds())]
+        mask = 0
+        for nm in only:
+            mask |= 1 << names.index(nm)
+        lib.nsdp_prof_enable_kinds(ctypes.c_uint(mask))
+    _active = True
 
 
 def stop():
