@@ -170,9 +170,12 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
  * by all centres (decoder: q = w_qs(z), model/decoder/blocks.py:63-66) */
 int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
                       int N, int k, int d, int q_per_shape, float *u, void *stream);
-/* dq = sum_j du (summed over the centres too when q_per_shape);  dkf (zero-filled here) -= scatter(du) */
+/* dq = sum_j du (summed over the centres too when q_per_shape);  dkf (zero-filled here) -= scatter(du);
+ * dpos_acc (B,n,k,d), may be NULL: dpos_acc += du in the same pass -- `pos` feeds both the logits (through u) and
+ * the values, so its gradient is d(u) + the dpos of nsdp_attn_post_bwd; accumulating here replaces a separate
+ * elementwise add over the largest tensor of the block. */
 int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
-                      int q_per_shape, float *dq, float *dkf, void *stream);
+                      int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream);
 /* y = sum_j softmax_j(a) * (vf[idx] + pos) [+ softmax weight of a_g * v_g] [+ residual];
  * lse (B,n,d) = log-sum-exp of the logits (kept for the backward pass).
  * vf == NULL: values are `pos` alone (pos_only block); a_g/v_g, residual may be NULL. */

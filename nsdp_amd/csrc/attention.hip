@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const fl
 // dq[b,i,c] = sum_j du[b,i,j,c];  dkf[b,idx,c] -= du   (dkf / per-shape dq zero-filled by the host wrapper)
 __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const float *__restrict__ du,
                                                            const int32_t *__restrict__ idx,
-                                                           float *__restrict__ dq, float *__restrict__ dkf) {
+                                                           float *__restrict__ dq, float *__restrict__ dkf,
+                                                           float *__restrict__ dpos_acc) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -120,12 +121,18 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const fl
     float *dkfb = dkf + static_cast<long long>(b) * s.N * s.d;
     const int32_t *ip = idx + pt * s.k;
     const float *dur = du + pt * s.k * s.d;
+    float *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
     Quad acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
       const Quad g = ldq(dur + static_cast<long long>(j) * s.d, cq, lpp);
       acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
       atomic_addq(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
+      if (par) {   // d(pos) += du while the row is in registers (saves the separate add kernel's re-read of du)
+        float *pr = par + static_cast<long long>(j) * s.d;
+        const Quad o = ldq(pr, cq, lpp);
+        stq(pr, cq, lpp, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
+      }
     }
     if (s.qb) {
       if (b != qb_b) {
@@ -332,7 +339,8 @@ __device__ __forceinline__ BlockLane block_lane_setup(const AttnShape &s) {
 __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape s, const float *__restrict__ du,
                                                                        const int32_t *__restrict__ idx,
                                                                        float *__restrict__ dq,
-                                                                       float *__restrict__ dkf) {
+                                                                       float *__restrict__ dkf,
+                                                                       float *__restrict__ dpos_acc) {
   extern __shared__ __attribute__((aligned(16))) float table[];  // [N][d] partial of -sum du
   const int b = blockIdx.y;
   const int tsz = s.N * s.d;
@@ -347,12 +355,18 @@ __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape
       if (pt >= L.pend) break;
       const int32_t *ip = idx + pt * s.k;
       const float *dur = du + pt * s.k * s.d;
+      float *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
       Quad acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int j = 0; j < s.k; ++j) {
         const Quad g = ldc(dur + static_cast<long long>(j) * s.d, cq);
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
         atomic_addc(table + ip[j] * s.d, cq, Quad{-g.x, -g.y, -g.z, -g.w});
+        if (par) {
+          float *pr = par + static_cast<long long>(j) * s.d;
+          const Quad o = ldc(pr, cq);
+          stc(pr, cq, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
+        }
       }
       if (s.qb) {
         qb_acc.x += acc.x; qb_acc.y += acc.y; qb_acc.z += acc.z; qb_acc.w += acc.w;
@@ -462,6 +476,7 @@ template <int UNROLL>
 __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *__restrict__ src,
                                                                   const int32_t *__restrict__ idx,
                                                                   float *__restrict__ table, float *__restrict__ colsum,
+                                                                  float *__restrict__ acc_rows,
                                                                   long long rows_per_shape, long long rows_per_wg, int N,
                                                                   int d, float sign, float colsum_sign) {
   f32x32_t t0 = {}, t1 = {}, t2 = {}, t3 = {};
@@ -472,21 +487,24 @@ __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *_
   end = end < rows_per_shape ? end : rows_per_shape;
   const long long base = static_cast<long long>(b) * rows_per_shape;
   const float *p = src + base * d + (cv ? c : 0);
+  float *pa = acc_rows ? acc_rows + base * d + (cv ? c : 0) : nullptr;      // acc_rows[row] += src[row] (optional)
   const int32_t *ip = idx + base;
   float total = 0.f;
   for (long long r = begin; r < end; r += UNROLL) {
-    float x[UNROLL];
+    float x[UNROLL], y[UNROLL];
     int a[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long long rr = r + u < end ? r + u : end - 1;          // clamped: the tail re-reads the last row, masked below
       x[u] = p[rr * d];
+      y[u] = pa ? pa[rr * d] : 0.f;
       a[u] = __builtin_amdgcn_readfirstlane(ip[rr]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int i = a[u] & 31, g = a[u] >> 5;
       const float v = (cv && r + u < end) ? x[u] : 0.f;
+      if (pa && cv && r + u < end) pa[(r + u) * d] = y[u] + x[u];
       total += v;
       t0[i] += g == 0 ? v : 0.f;
       t1[i] += g == 1 ? v : 0.f;
@@ -510,15 +528,16 @@ __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *_
 inline bool regtab_fits(int N, int d, long long rows_per_shape) { return N <= 128 && d <= 256 && rows_per_shape >= 4096; }
 
 // table (zero-filled by the caller) += sign * scatter(src); colsum (zero-filled, may be null) += colsum_sign * sum_r src[r]
-inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *table, float *colsum, int B,
-                                 long long rows_per_shape, int N, int d, float sign, float colsum_sign, hipStream_t st) {
+inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *table, float *colsum, float *acc_rows,
+                                 int B, long long rows_per_shape, int N, int d, float sign, float colsum_sign,
+                                 hipStream_t st) {
   long long wgs = (4LL * nsdp::num_cus() + B - 1) / B;                 // ~4 workgroups per CU in total
   if (wgs * 512 > rows_per_shape) wgs = rows_per_shape / 512 > 0 ? rows_per_shape / 512 : 1;
   long long per = (rows_per_shape + wgs - 1) / wgs;
   per = (per + 7) / 8 * 8;
   wgs = (rows_per_shape + per - 1) / per;
   hipLaunchKernelGGL((scatter_rows_regtab_kernel<8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
-                     colsum, rows_per_shape, per, N, d, sign, colsum_sign);
+                     colsum, acc_rows, rows_per_shape, per, N, d, sign, colsum_sign);
   return nsdp::launch_status("scatter_rows_regtab_kernel");
 }
 
@@ -585,7 +604,7 @@ int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const i
 }
 
 int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
-                      int q_per_shape, float *dq, float *dkf, void *stream) {
+                      int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream) {
   const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
   if (q_per_shape && dq && static_cast<long long>(B) * d > 0)
@@ -596,10 +615,10 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
-                          4.0 * (rows(s) * (d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
+                          4.0 * (rows(s) * ((dpos_acc ? 3.0 : 1.0) * d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
   if (q_per_shape && regtab_fits(N, d, static_cast<long long>(n) * k)) {
     // decoder: one query vector per shape.  dkf = -scatter(du), dq = +column sum of du: the register-table scatter
-    return launch_regtab_scatter(du, idx, dkf, dq, B, static_cast<long long>(n) * k, N, d, -1.f, 1.f, st);
+    return launch_regtab_scatter(du, idx, dkf, dq, dpos_acc, B, static_cast<long long>(n) * k, N, d, -1.f, 1.f, st);
   }
   if (lds_table_fits(s)) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
@@ -607,10 +626,10 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
     AttnShape sl = s;
     dim3 grid;
     lds_plan(sl, grid);
-    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf);
+    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf, dpos_acc);
     return nsdp::launch_status("attn_pre_bwd_lds_kernel");
   }
-  NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf);
+  NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf, dpos_acc);
   return nsdp::launch_status("attn_pre_bwd_kernel");
 }
 

@@ -14,11 +14,24 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _PosGrad:
+    """Hand-over of d(pos) between the two halves of one attention block.  `pos` feeds the logits (attn_pre) and the
+    values (attn_post); in the backward pass attn_post runs first (attn_pre's gradient depends on it through the
+    gamma MLP), parks its d(pos) here and reports no gradient for `pos`; attn_pre then adds d(u) to it inside its
+    kernel and returns the sum.  Without this autograd sums the two with an elementwise add over the largest tensor
+    of the block."""
+    __slots__ = ("dpos",)
+
+    def __init__(self):
+        self.dpos = None
+
+
 class _AttnPre(torch.autograd.Function):
     """u = q[:, :, None] - kf[idx] + pos."""
 
     @staticmethod
-    def forward(ctx, q, kf, pos, idx):
+    def forward(ctx, q, kf, pos, idx, link=None):
+        ctx.link = link
         q, kf, pos = _c(q), _c(kf), _c(pos)
         B, n, k, d = pos.shape
         N = kf.shape[1]
@@ -39,17 +52,21 @@ class _AttnPre(torch.autograd.Function):
         du = _c(du)
         dq = torch.empty((B, 1 if qb else n, d), dtype=torch.float32, device=du.device)
         dkf = torch.empty((B, N, d), dtype=torch.float32, device=du.device)
+        acc = None
+        if ctx.link is not None:
+            acc, ctx.link.dpos = ctx.link.dpos, None
         with on_device(du):
             check(lib().nsdp_attn_pre_bwd(fptr(du, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
-                                          fptr(dq), fptr(dkf), stream_ptr()), "nsdp_attn_pre_bwd")
-        return dq, dkf, du, None
+                                          fptr(dq), fptr(dkf), optptr(acc), stream_ptr()), "nsdp_attn_pre_bwd")
+        return dq, dkf, (du if acc is None else acc), None, None
 
 
 class _AttnPost(torch.autograd.Function):
     """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
 
     @staticmethod
-    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual):
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None):
+        ctx.link = link
         a, pos = _c(a), _c(pos)
         vf = None if vf is None else _c(vf)
         a_g = None if a_g is None else _c(a_g)
@@ -83,12 +100,20 @@ class _AttnPost(torch.autograd.Function):
                                            optptr(v_g), fptr(y), optptr(residual), fptr(lse), _ci(B), _ci(n), _ci(N),
                                            _ci(k), _ci(d), fptr(da), fptr(dpos), optptr(dvf), optptr(da_g),
                                            optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
-        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None)
+        if ctx.link is not None and ctx.needs_input_grad[2]:
+            ctx.link.dpos, dpos = dpos, None          # attn_pre's backward adds d(u) and reports the sum
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None
 
 
-def attn_pre(q, kf, pos, idx):
-    return _AttnPre.apply(q, kf, pos, idx)
+def pos_grad_link():
+    """One per attention block whose `pos` goes through both attn_pre and attn_post (and whose attn_post output
+    depends on the attn_pre output, which is what orders the two backward calls): pass it to both."""
+    return _PosGrad()
 
 
-def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None):
-    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual)
+def attn_pre(q, kf, pos, idx, link=None):
+    return _AttnPre.apply(q, kf, pos, idx, link)
+
+
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None):
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link)

@@ -138,7 +138,8 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         logits = mlp2(pos, fc_gamma)
         out = hip_attention.attn_post(logits, None, pos, idx, residual=residual)
     else:
-        u = hip_attention.attn_pre(q, kf, pos, idx)            # q_i - kf[idx] + pos, gather fused
+        link = hip_attention.pos_grad_link() if pos.requires_grad else None   # d(pos) summed inside attn_pre_bwd
+        u = hip_attention.attn_pre(q, kf, pos, idx, link)      # q_i - kf[idx] + pos, gather fused
         logits = mlp2(u, fc_gamma)
-        out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual)
+        out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link)
     return out, pos

@@ -92,3 +92,33 @@ def test_attn_pre_query_per_shape():
     for a_, e_ in zip(gm, gr):
         assert a_.shape == e_.shape
         assert float((a_.double() - e_).abs().max()) <= 2e-5 * (float(e_.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("B,n,N,k,d,per_shape", [
+    (2, 96, 40, 8, 32, False),         # generic kernel
+    (2, 640, 100, 16, 64, False),      # LDS-table kernel (n >= 4 N)
+    (3, 4096, 100, 7, 200, True),      # decoder form: register-table scatter
+])
+def test_pos_gradient_link_matches_autograd_sum(B, n, N, k, d, per_shape):
+    """d(pos) handed from attn_post to attn_pre (summed inside the attn_pre_bwd kernel) == autograd's own sum."""
+    from nsdp_amd.hip_attention import attn_post, attn_pre, pos_grad_link
+    g = torch.Generator().manual_seed(B * n + d)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    q0, kf0, vf0, pos0 = mk(B, 1 if per_shape else n, d), mk(B, N, d), mk(B, N, d), mk(B, n, k, d)
+    w = mk(d, d) * 0.2
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    go = mk(B, n, d)
+
+    def run(use_link):
+        q, kf, vf, pos = (t.clone().requires_grad_(True) for t in (q0, kf0, vf0, pos0))
+        link = pos_grad_link() if use_link else None
+        u = attn_pre(q, kf, pos, idx, link)
+        out = attn_post(u @ w, vf, pos, idx, link=link)
+        return torch.autograd.grad(out, [q, kf, vf, pos], go)
+
+    plain, fused = run(False), run(True)
+    for a_, e_ in zip(fused, plain):
+        assert a_.shape == e_.shape
+        # (dq / dkf come from fp32 atomics in both runs: summation order, not the hand-over, sets this tolerance)
+        assert float((a_ - e_).abs().max()) <= 2e-5 * (float(e_.abs().max()) + 1.0)
+    assert torch.equal(fused[3], plain[3])        # d(pos): the same two addends, added once, in either path
