@@ -74,6 +74,37 @@ if pmc:
             f.write(f"| `{n}` | {fe[0] or wr[0]} | {fe[1]:.0f} | {2*fe[1]/1024:.1f} | {wr[1]:.0f} | {fe[2]:.0f} | {wr[2]:.0f} |\n")
     json.dump({k: {n: v for n, v in agg.items()} for k, agg in pmc.items()},
               open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=0)
+# SQ counters (one pass, NSDP_WGRAD_STREAM=0 so that counters are per kernel): matrix-pipe busy fraction and wait split
+sq_path = os.path.join(root, "gpurun_out", "pmc_sq", "s_counter_collection.csv")
+if os.path.exists(sq_path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(sq_path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (r.get("Dispatch_Id"), k)
+        if key not in seen:
+            seen.add(key)
+            launches[k] += 1
+    rows_sq = sorted(agg.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0.0))
+    with open(os.path.join(out_dir, f"{tag}_pmc_mfma.md"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY "
+                "GRBM_GUI_ACTIVE --kernel-trace (one pass, no other trace domains): NSDP_WGRAD_STREAM=0 python bench.py "
+                "--steps 1 --warmup 1 --no-cpu-baseline, B=32\n\n")
+        f.write("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs): fraction of all SIMD cycles of the "
+                "kernel's lifetime in which the matrix pipe is busy.  A bf16 16x16x32 MFMA is busy 16 cycles and an fp32 "
+                "16x16x4 MFMA 32 cycles, so this is the fraction of the dense MFMA peak of the kernel's data type at the "
+                "running clock (for the bf16x3 kernels: of 2.5 PFLOP/s of bf16 products, six per fp32 multiply-add).\n"
+                "wait_mem = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked at s_waitcnt), wait_issue = SQ_WAIT_INST_ANY / "
+                "SQ_WAVE_CYCLES, active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES.\n\n")
+        f.write("| kernel | launches | GPU-busy Mcycles | MFMA busy | wait_mem | wait_issue | active |\n|---|---:|---:|---:|---:|---:|---:|\n")
+        for k, v in rows_sq[:32]:
+            gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+            wc = max(v.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(gui / 8.0 * 1024.0, 1.0)
+            f.write(f"| `{k}` | {launches[k]} | {gui/1e6:.1f} | {100*busy:.1f} % | {100*v.get('SQ_WAIT_ANY',0)/wc:.0f} % | "
+                    f"{100*v.get('SQ_WAIT_INST_ANY',0)/wc:.0f} % | {100*v.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f} % |\n")
 for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json"):
     src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
     if os.path.exists(src) and open(src).read().strip():
