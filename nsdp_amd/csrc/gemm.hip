@@ -44,7 +44,10 @@ struct LinearParams {
 // fragment with a select while the activation fragment re-reads in-row (finite) data.
 // WP: W is the fragment-major pack written by nsdp_pack_weight_f32 ([n tile][k block][lane][4], zero padded):
 // every wave-wide weight load is one contiguous KiB instead of 16 rows x 64 B, and needs no clamps or k-tail fix-up.
-template <int MT, int NT, int PRE, bool PIPE, bool WP = false>
+// DEEP > 0: ring of DEEP operand buffers instead of two.  The small-M split-N launch (MT = 1, NT = 4) has only
+// 16 MFMAs (~0.2 us) per k block to hide an L2 round trip (~0.6 us) behind: with two buffers every k block stalled
+// (13.9 us for 3200 x 256 x 256, 3.4 us of it MFMA time); its 20 operand registers per block allow eight in flight.
+template <int MT, int NT, int PRE, bool PIPE, bool WP = false, int DEEP = 0>
 __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -177,7 +180,25 @@ __global__ __launch_bounds__(256) void linear_nt_kernel(LinearParams p) {
     }
   };
 
-  if (PIPE) {
+  if constexpr (DEEP > 0) {
+    Frag f[DEEP];
+#pragma unroll
+    for (int d = 0; d < DEEP; ++d) issue(d < KB ? d : KB - 1, f[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    // KB % DEEP == 0 (checked at launch): straight-line phases, so that the compiler's s_waitcnt counts stay exact
+    // (a conditional phase made it drain vmcnt(0) at every loop header)
+    for (int kb = 0; kb < KB; kb += DEEP) {
+#pragma unroll
+      for (int d = 0; d < DEEP; ++d) {
+        fixup(kb + d, f[d]);
+        mma(f[d]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nx = kb + d + DEEP;
+        issue(nx < KB ? nx : KB - 1, f[d]);   // past the end: re-loads a valid block that is never used
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if (PIPE) {
     Frag f0, f1;
     issue(0, f0);
     __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +476,14 @@ int launch_nt(const LinearParams &p, hipStream_t st, int grid_y = 1, bool wp = f
   nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   const dim3 gr(static_cast<unsigned>(grid), grid_y);
-  if (wp) {
+  // small-M split-N launch with at most one wave per SIMD: nothing else hides the operand latency -> deep operand
+  // ring (with more waves per SIMD its 192 registers cost more occupancy than the ring wins: 16000 rows, 29 -> 40 us)
+  if (wp && MT == 1 && NT == 4 && ((p.K + 15) / 16) % 8 == 0 && grid * grid_y * 4 <= 4LL * nsdp::num_cus()) {
+    constexpr int kDeep = (MT == 1 && NT == 4) ? 8 : 0;
+    if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0, true, true, kDeep>), gr, dim3(256), 0, st, p);
+    else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1, true, true, kDeep>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2, true, true, kDeep>), gr, dim3(256), 0, st, p);
+  } else if (wp) {
     if (pre == 0) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 0, true, true>), gr, dim3(256), 0, st, p);
     else if (pre == 1) hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 1, true, true>), gr, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((linear_nt_kernel<MT, NT, 2, true, true>), gr, dim3(256), 0, st, p);
