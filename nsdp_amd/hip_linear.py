@@ -255,10 +255,32 @@ def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out):
     return fn(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out)
 
 
+class InputGradSum:
+    """Shared by the dense layers that read the SAME input tensor (the decoder feeds its latent code to six of them).
+    Autograd would produce six dX tensors and add them pairwise; with this hand-over each layer's dX GEMM takes the
+    running sum as its fused `residual` operand, all but the last report no gradient, and the last one reports the
+    total.  Contract: every layer given the link must take part in the backward pass (true when each of their outputs
+    feeds the loss, as in the decoder trunk); layers with a fused input ReLU cannot join (their dX is masked after
+    the residual is added)."""
+    __slots__ = ("total", "pending", "buf")
+
+    def __init__(self):
+        self.total = 0
+        self.pending = 0
+        self.buf = None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None):
+    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None):
         ctx.w_param, ctx.b_param = w_param, b_param
+        ctx.grad_sum = None
+        if grad_sum is not None and ctx.needs_input_grad[0]:
+            if relu_in or x.shape[-1] % 4:
+                raise ValueError("InputGradSum: layers with a fused input ReLU or a padded input width cannot join")
+            grad_sum.total += 1
+            grad_sum.pending += 1
+            ctx.grad_sum = grad_sum
         K = x.shape[-1]
         N = w.shape[0]
         x2 = x.reshape(-1, K)
@@ -307,17 +329,26 @@ class _LinearFn(torch.autograd.Function):
                 dyk = _pad_cols(dy2)
                 mk = _pad_cols(y) if y is not None else None
             # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
-            dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, None, mk, x2 if ctx.relu_in else None, False, False)
+            link = ctx.grad_sum
+            dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
+                      x2 if ctx.relu_in else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
+            if link is not None:         # running sum over the layers that share this input
+                link.pending -= 1
+                if link.pending > 0:
+                    link.buf, dx = dx.reshape(-1, ctx.k_orig), None
+                else:
+                    link.buf, link.pending = None, link.total      # (re-armed for a second pass over a retained graph)
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False):
+def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
-    produced on the side stream and published to ``.grad`` at the end of the backward pass (see above)."""
+    produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
+    ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``."""
     w_param = b_param = None
     if params and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
         w_param = weight
@@ -328,5 +359,5 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out))
+                               bool(relu_out), w_param, b_param, grad_sum)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum)

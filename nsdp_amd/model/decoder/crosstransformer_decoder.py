@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ... import hip_decoder
+from ... import hip_decoder, hip_linear
 from .blocks import CrossTransformerBlock, ResnetBlockFC
 
 
@@ -28,8 +28,10 @@ class CrossTransformerDecoder(nn.Module):
             # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
             return hip_decoder.decoder_forward(self, xyz_q, encoding)
         lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
-        net = ops.linear(lat, self.init_enc)
+        # the latent code feeds n_blocks + 1 layers: its gradient is summed inside their dX GEMMs
+        fan = hip_linear.InputGradSum() if (torch.is_grad_enabled() and lat.requires_grad) else None
+        net = ops.linear(lat, self.init_enc, grad_sum=fan)
         for i in range(self.n_blocks):
-            net = ops.linear(lat, self.fc_c[i], residual=net)             # net + fc_c[i](lat)
+            net = ops.linear(lat, self.fc_c[i], residual=net, grad_sum=fan)   # net + fc_c[i](lat)
             net = self.blocks[i](net)
         return ops.linear(net, self.fc_out, relu_in=True)                 # fc_out(relu(net))

@@ -101,11 +101,12 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # dense layers
 # ---------------------------------------------------------------------------------------------
-def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None) -> torch.Tensor:
+def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
-    relu?( relu_in?(x) @ W^T + b (+ residual) )."""
+    relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
+    the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
-                             params=True)
+                             params=True, grad_sum=grad_sum)
 
 
 def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:

@@ -69,3 +69,42 @@ def test_wgrad_is_deterministic():
     assert torch.equal(a, b) and torch.equal(da, db)
     ref = dy.double().t() @ x.double()
     assert float((a.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,K,N,n_layers", [(4096, 200, 128, 6), (40000, 200, 128, 3), (777, 64, 40, 4)])
+def test_input_grad_sum_matches_autograd(M, K, N, n_layers):
+    """Fan-out of one input over several layers: the gradient summed inside the dX GEMMs (InputGradSum) equals
+    autograd's pairwise sum of the separate dX tensors; weight gradients are untouched; a second backward pass over
+    the retained graph works (the link re-arms)."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator().manual_seed(M + n_layers)
+    x0 = torch.randn(M, K, generator=g).to(DEV)
+    ws = [(torch.randn(N, K, generator=g) * 0.1).to(DEV) for _ in range(n_layers)]
+    go = torch.randn(M, N, generator=g).to(DEV)
+
+    def run(use_link, passes=1):
+        x = x0.clone().requires_grad_(True)
+        wl = [w.clone().requires_grad_(True) for w in ws]
+        link = hip_linear.InputGradSum() if use_link else None
+        net = hip_linear.linear(x, wl[0], relu_out=True, grad_sum=link)
+        for w in wl[1:]:
+            net = hip_linear.linear(x, w, residual=net, grad_sum=link)
+        outs = []
+        for p in range(passes):
+            outs.append(torch.autograd.grad(net, [x] + wl, go, retain_graph=p + 1 < passes))
+        return outs
+
+    plain = run(False)[0]
+    fused = run(True, passes=2)
+    for got in fused:
+        for a_, e_ in zip(got, plain):
+            assert a_.shape == e_.shape
+            assert float((a_ - e_).abs().max()) <= 2e-6 * float(e_.abs().max()) + 1e-6
+
+
+def test_input_grad_sum_refuses_fused_input_relu():
+    from nsdp_amd import hip_linear
+    x = torch.randn(64, 32, device=DEV, requires_grad=True)
+    w = torch.randn(16, 32, device=DEV, requires_grad=True)
+    with pytest.raises(ValueError):
+        hip_linear.linear(x, w, relu_in=True, grad_sum=hip_linear.InputGradSum())
