@@ -199,7 +199,10 @@ __global__ __launch_bounds__(WV * 64) void linear_bf16x3_kernel(X3Params p) {
   // program on the same amount of work, and without it their epilogue store bursts hit HBM at the same moments
   // (measured: -7 % time on the 1.8 M-row layers).  Only worth it when a workgroup has several tiles to go.
   if (wg_tiles >= 4 * stride) {
-    for (int i = 0; i < static_cast<int>(blockIdx.x & 7) * KB; ++i) __builtin_amdgcn_s_sleep(10);
+    // (two workgroups per CU: the second half of the grid is shifted by half a tile against the first)
+    int phase = static_cast<int>(blockIdx.x & 7);
+    if (WV == 4 && gridDim.x > 256 && blockIdx.x >= gridDim.x / 2) phase = (phase + 4) & 7;
+    for (int i = 0; i < phase * KB; ++i) __builtin_amdgcn_s_sleep(10);
   }
   // prologue (once per workgroup): block 0 of the first tile, split; block 1 in flight
   stage(0, 0);
@@ -488,12 +491,13 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
 }
 
 template <int MT, int NT, int PRE, int WV>
-void launch_x3_pre(const X3Params &p, hipStream_t st) {
+void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
   // persistent workgroups, one per CU: the next tile's first k blocks are prefetched under the current tile's
   // last MFMAs and epilogue
-  const unsigned grid = static_cast<unsigned>(wg_tiles < nsdp::num_cus() ? wg_tiles : nsdp::num_cus());
+  const long long slots = static_cast<long long>(nsdp::num_cus()) * wgs_per_cu;
+  const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
   hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
@@ -505,13 +509,19 @@ int launch_x3(const X3Params &p, hipStream_t st) {
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   // measured per class: up to 13 n tiles two waves per SIMD with 2 row tiles each win (1.36 -> 1.20 ms on the
   // 1.8 M x 200 x 200 layers), at 16 n tiles one wave per SIMD with 3; the masked prologue keeps its raw activation
-  // and mask registers in flight and uses the one-wave, spill-free variants throughout
+  // and mask registers in flight and uses the one-wave, spill-free variants throughout.
+  // Up to 8 n tiles the two waves per SIMD come from TWO 4-wave workgroups per CU (2 x 80 KiB of LDS, exactly the
+  // CU's 160 KiB): they share no barrier, so one's epilogue stores overlap the other's MFMA steps (2-10 % faster than
+  // one 8-wave workgroup, bit-identical results).  13 n tiles would need 2 x 110 KiB.
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
   if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
-  else if (two_waves) {
-    if (pre == 0) launch_x3_pre<2, NT, 0, 8>(p, st);
-    else launch_x3_pre<2, NT, 2, 8>(p, st);
+  else if (NT <= 8 && two_waves) {
+    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4>(p, st, 2);
+    else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 4>(p, st, 2);
+  } else if (two_waves) {
+    if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8>(p, st);
+    else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
   } else {
     constexpr int MT0 = NT >= 16 ? 3 : 4;
     if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
