@@ -252,7 +252,8 @@ def main():
             "per_gpu": round(value / world, 1),
             "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2) if args.workload == "forward_train" else None,
             "final_loss": round(final_loss, 6),
-            "roofline": profiling.roofline(prof, prof_iso),
+            "roofline": profiling.roofline(prof, prof_iso,
+                                           pmc_matches=(args.workload == "forward_train" and args.batch == 32)),
             "kernels": profiling.summary(prof_iso if prof_iso else prof),
             "kernels_from": ("2 untimed steps, every launch timed, weight gradients on the main stream" if prof_iso
                              else "timed region"),

@@ -76,7 +76,7 @@ def summary(prof):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def roofline(prof, prof_isolated=None):
+def roofline(prof, prof_isolated=None, pmc_matches=True):
     """Roofline object of the dominant hand-written kernel class.
 
     Two measurements exist for every kernel, both taken live with HIP events on the launch stream: inside the timed
@@ -92,7 +92,8 @@ def roofline(prof, prof_isolated=None):
     name, v = max(base.items(), key=lambda kv: kv[1]["ms"])
     out = _roofline_one(name, v)
     out["measured"] = "isolated pass (no cross-stream overlap)" if prof_isolated else "timed region"
-    out.update(_pmc_traffic(name))
+    # the committed PMC passes are of the default workload (B = 32 forward.yaml train step) only
+    out.update(_pmc_traffic(name) if pmc_matches else {"traffic": None})
     if prof_isolated and name in prof:
         ins = _roofline_one(name, prof[name])
         out["in_step"] = {k: ins[k] for k in ("achieved", "frac", "launches", "avg_launch_ms")}
