@@ -131,9 +131,11 @@ int nsdp_linear_wp_f32(const float *X, const float *Wp, const float *bias, const
 /* fp32 dense layer on the bf16 matrix pipe by error-compensated 3-way splitting (x = h + m + l in bf16, 6 of the
  * 9 partial products, fp32 accumulate; accurate to fp32 rounding level, see csrc/gemm_bf16x3.hip).  Same
  * contract as nsdp_linear_f32, with W pre-split by nsdp_pack_weight_bf16x3:
- *   Wp  [ceil(K/32)][ceil(N/16)][plane h,m,l][lane 16 g + li][8 bf16] = planes of W[16 tn + li][32 kb + 8 g + j]
- *   WpT [ceil(N/32)][ceil(K/16)][3][64][8]                            = planes of W[32 nb + 8 g + j][16 tk + li]
- * (the pack of W^T, operand of dX = dY * W); sizes from nsdp_packed_weight_bf16x3_bytes(N, K, transposed). */
+ *   Wp  [ceil(K/32)][ceil(N/16)][plane h,m,l][lane 16 g + li][8 bf16] = planes of W[16 tn + li][32 kb + kperm(g, j)]
+ *   WpT [ceil(N/32)][ceil(K/16)][3][64][8]                            = planes of W[32 nb + kperm(g, j)][16 tk + li]
+ * (the pack of W^T, operand of dX = dY * W); kperm(g, j) = 16 (j / 4) + 4 g + j % 4 is the order in which a lane's
+ * eight activation values of a k block are loaded (the four lane groups of a row then read 64 contiguous bytes per
+ * instruction); sizes from nsdp_packed_weight_bf16x3_bytes(N, K, transposed). */
 long long nsdp_packed_weight_bf16x3_bytes(int N, int K, int transposed);
 int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, void *stream);
 int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,

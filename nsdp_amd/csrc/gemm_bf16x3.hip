@@ -17,7 +17,8 @@
 //     buffers, one barrier per k block) and read back with conflict-free ds_read_b128: per-wave register
 //     loads of W would need 62 B/clk/CU of L1 bandwidth at this MFMA rate.
 //   * X is read once from HBM, 32 B per lane and k block (k-permuted fragment convention: lane group g
-//     supplies k = 32 kb + 8 g .. + 7 to A and B alike, so row-major rows need no transposition), one
+//     supplies k = 32 kb + {4 g .. + 3, 16 + 4 g .. + 3} to A and B alike, so row-major rows need no transposition
+//     and the four lane groups of a row read 64 contiguous bytes per load instruction), one
 //     k block ahead, and split on the VALU (v_cvt_pk_bf16_f32 / v_pk_add_f32: 4.5 ops per value) during
 //     the first MFMA steps of the previous k block.
 #include <type_traits>
@@ -146,14 +147,14 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wbuf[0][lane])));
   constexpr unsigned kBufBytes = NT * 3 * 1024;
 
-  // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 8 g + 4 half ..)
+  // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 16 half + 4 g ..)
   f32x4 raw[kXLds ? 1 : MT][2], rawm[kXLds ? 1 : MT][2];
   auto xissue = [&](const float *const *x, const float *const *m, int kb, unsigned xb) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        int ko = kb * 32 + 8 * g + 4 * hf;
+        int ko = kb * 32 + 16 * hf + 4 * g;     // the four lane groups of a row read 64 contiguous bytes per instruction
         ko = ko < K ? ko : (K - 4);     // past the row end: re-read in-row data (the packed weights are zero there)
         if constexpr (kXLds) {
           __builtin_amdgcn_global_load_lds((gbl_ptr_t)(x[mt] + ko), (lds_ptr_t)(&xbuf[xb][wave][(mt * 2 + hf) * 64]), 16, 0, 0);
@@ -445,9 +446,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 }
 
 // bf16x3 packs.  Wp  [ceil(K/32)][ceil(N/16)][3 planes][64 lanes][8 bf16]:
-//   element j of lane 16 g + li of (kb, tn) = plane_p( W[16 tn + li][32 kb + 8 g + j] )
+//   element j of lane 16 g + li of (kb, tn) = plane_p( W[16 tn + li][32 kb + kperm(g, j)] ),
+//   kperm(g, j) = 16 (j / 4) + 4 g + j % 4: the k permutation of the activation loads (above)
 // WpT [ceil(N/32)][ceil(K/16)][3][64][8]: the pack of W^T (operand of dX = dY W):
-//   element j of lane 16 g + li of (nb, tk) = plane_p( W[32 nb + 8 g + j][16 tk + li] )
+//   element j of lane 16 g + li of (nb, tk) = plane_p( W[32 nb + kperm(g, j)][16 tk + li] )
 // zero outside [N,K].  One thread per (block, tile, lane) of each output.
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restrict__ W, int N, int K,
                                                           u32x4 *__restrict__ Wp, u32x4 *__restrict__ WpT) {
@@ -458,11 +460,11 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
     const int NT = (N + 15) >> 4, KB = (K + 31) >> 5;
     if (blk < static_cast<long long>(NT) * KB) {
       const int kb = static_cast<int>(blk / NT), tn = static_cast<int>(blk % NT);
-      const int n = tn * 16 + li, k0 = kb * 32 + 8 * g;
+      const int n = tn * 16 + li, k0 = kb * 32 + 4 * g;
       u32x4 h, m, l;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
-        const int k = k0 + 2 * pr;
+        const int k = k0 + 16 * (pr >> 1) + 2 * (pr & 1);
         const float x0 = n < N && k < K ? W[static_cast<long long>(n) * K + k] : 0.f;
         const float x1 = n < N && k + 1 < K ? W[static_cast<long long>(n) * K + k + 1] : 0.f;
         unsigned a, b, c;
@@ -477,11 +479,11 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
     const int KT = (K + 15) >> 4, NB = (N + 31) >> 5;
     if (blk < static_cast<long long>(KT) * NB) {
       const int nb = static_cast<int>(blk / KT), tk = static_cast<int>(blk % KT);
-      const int k = tk * 16 + li, n0 = nb * 32 + 8 * g;
+      const int k = tk * 16 + li, n0 = nb * 32 + 4 * g;
       u32x4 h, m, l;
 #pragma unroll
       for (int pr = 0; pr < 4; ++pr) {
-        const int n = n0 + 2 * pr;
+        const int n = n0 + 16 * (pr >> 1) + 2 * (pr & 1);
         const float x0 = k < K && n < N ? W[static_cast<long long>(n) * K + k] : 0.f;
         const float x1 = k < K && n + 1 < N ? W[static_cast<long long>(n + 1) * K + k] : 0.f;
         unsigned a, b, c;
