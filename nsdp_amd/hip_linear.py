@@ -138,9 +138,15 @@ def _wgrad_x3(dy2, x2, mask, relu_x, want_db):
 _OVERLAP_WGRAD = os.environ.get("NSDP_WGRAD_STREAM", "auto")
 _OVERLAP_WGRAD = {"0": False, "1": True}.get(_OVERLAP_WGRAD, "auto")
 _OVERLAP_MIN_ROWS = 131072       # rows of dY at the model's output layer (batch x query points)
-_overlap_now = {}                # device index -> decision for the backward pass in flight
+_overlap_now = {}                # (device index, graph task) -> decision for that backward pass
 _side = {}
-_pending = {}          # device index -> {id(param): [param, grad tensor living on the side stream]}
+_pending = {}          # (device index, graph task) -> {id(param): [param, grad tensor living on the side stream]}
+# Per-backward state is keyed by the autograd graph task that created it: a pass that died with an exception never runs
+# its end-of-backward callback, and its leftovers must not be published by (or suppress the callback of) the next pass.
+
+
+def _pass_key(device):
+    return (device.index, torch._C._current_graph_task_id())
 
 
 def _side_stream(device):
@@ -150,10 +156,10 @@ def _side_stream(device):
     return _side[key]
 
 
-def _publish(device):
+def _publish(device, key):
     """End-of-backward callback: join the streams, then hand the pending gradients to the parameters."""
-    _overlap_now.pop(device.index, None)
-    todo = _pending.pop(device.index, {})
+    _overlap_now.pop(key, None)
+    todo = _pending.pop(key, {})
     if not todo:
         return
     main = torch.cuda.current_stream(device)
@@ -177,13 +183,13 @@ def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig):
 def _use_side_stream(dy2):
     if _OVERLAP_WGRAD != "auto":
         return _OVERLAP_WGRAD
-    key = dy2.device.index
+    key = _pass_key(dy2.device)
     use = _overlap_now.get(key)
     if use is None:          # first weight gradient of this backward pass
         use = _overlap_now[key] = dy2.shape[0] >= _OVERLAP_MIN_ROWS
         if not use:          # still need the end-of-backward hook to forget the decision
             dev = dy2.device
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev))
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
     return use
 
 
@@ -192,10 +198,11 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param):
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
     side.wait_stream(main)
-    slot = _pending.get(dev.index)
+    key = _pass_key(dev)
+    slot = _pending.get(key)
     if slot is None:
-        slot = _pending[dev.index] = {}
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev))
+        slot = _pending[key] = {}
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
     with torch.cuda.stream(side):      # everything that touches dw/db before the join stays on `side`
         dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig)
         for param, g in ((w_param, dw), (b_param, db)):

@@ -108,3 +108,33 @@ def test_input_grad_sum_refuses_fused_input_relu():
     w = torch.randn(16, 32, device=DEV, requires_grad=True)
     with pytest.raises(ValueError):
         hip_linear.linear(x, w, relu_in=True, grad_sum=hip_linear.InputGradSum())
+
+
+def test_failed_backward_leaves_nothing_behind():
+    """Weight gradients wait on a side stream until an end-of-backward callback publishes them.  A pass that dies with
+    an exception never runs that callback: its leftovers must not leak into the next pass's gradients."""
+    from nsdp_amd import hip_linear
+    lin1, lin2 = torch.nn.Linear(64, 48).to(DEV), torch.nn.Linear(48, 32).to(DEV)
+    x = torch.randn(4096, 64, device=DEV)
+    was = hip_linear._OVERLAP_WGRAD
+    hip_linear._OVERLAP_WGRAD = True
+    try:
+        def run(fail):
+            for p in (*lin1.parameters(), *lin2.parameters()):
+                p.grad = None
+            h = hip_linear.linear(x, lin1.weight, lin1.bias, relu_out=True, params=True)
+            if fail:
+                h.register_hook(lambda g: (_ for _ in ()).throw(RuntimeError("boom")))
+            y = hip_linear.linear(h, lin2.weight, lin2.bias, params=True)
+            y.square().sum().backward()
+            torch.cuda.synchronize()
+            return [p.grad.clone() for p in (*lin1.parameters(), *lin2.parameters())]
+
+        good = run(False)
+        with pytest.raises(RuntimeError):
+            run(True)                      # lin2's weight gradient was already parked on the side stream
+        again = run(False)
+        for a_, e_ in zip(again, good):
+            assert torch.equal(a_, e_)
+    finally:
+        hip_linear._OVERLAP_WGRAD = was
