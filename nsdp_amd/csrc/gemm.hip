@@ -794,6 +794,83 @@ void dispatch_wgrad_k(const WgradParams &p, unsigned chunks, int ktiles, hipStre
   return launch_wgrad<kWgN, 16>(p, chunks, ktiles, st);
 }
 
+// K = 4 (the 3-d relative coordinates of a position-encoding layer, zero-padded): two multiply-adds per loaded
+// float -- nothing for the matrix pipe, a pure stream over dY (and its ReLU mask).  N/4 lanes per row read the row as
+// float4 (fully coalesced, 4 rows in flight per lane), each lane keeps the 4 x 4 products of its four channels and
+// their column sums; the row slots of a workgroup are combined through LDS in fixed order and written as one partial
+// in the layout of reduce_partials_kernel.  The MFMA kernel it replaces here ran at 2.9 TB/s with a quarter of its
+// tile rows padding.
+template <bool MASK>
+__global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
+  __shared__ float red[256][21];       // 16 products + 4 column sums per thread (padded: conflict-free columns)
+  const int N = p.N;
+  const int lpr = N >> 2;                              // lanes per row (N % 4 == 0, N <= 256)
+  const int slots = 256 / lpr;                         // rows per workgroup iteration
+  const int sub = threadIdx.x / lpr, cq = threadIdx.x - sub * lpr;
+  const bool active = sub < slots;
+  const long long r0 = static_cast<long long>(blockIdx.x) * p.rows_per_chunk;
+  long long r1 = r0 + p.rows_per_chunk;
+  r1 = r1 < p.M ? r1 : p.M;
+  float a[4][4], bsum[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    bsum[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[c][k] = 0.f;
+  }
+  if (active) {
+    constexpr int U = 4;
+    for (long long r = r0 + sub; r < r1; r += static_cast<long long>(U) * slots) {
+      float4 dy[U], mk[U], x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        long long rr = r + static_cast<long long>(u) * slots;
+        rr = rr < r1 ? rr : (r1 - 1);                  // clamped re-read, zeroed below
+        dy[u] = *reinterpret_cast<const float4 *>(p.dY + rr * N + 4 * cq);
+        if (MASK) mk[u] = *reinterpret_cast<const float4 *>(p.mask + rr * N + 4 * cq);
+        x[u] = *reinterpret_cast<const float4 *>(p.X + rr * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool rv = r + static_cast<long long>(u) * slots < r1;
+        float d[4] = {dy[u].x, dy[u].y, dy[u].z, dy[u].w};
+        if (MASK) {
+          d[0] = mk[u].x > 0.f ? d[0] : 0.f; d[1] = mk[u].y > 0.f ? d[1] : 0.f;
+          d[2] = mk[u].z > 0.f ? d[2] : 0.f; d[3] = mk[u].w > 0.f ? d[3] : 0.f;
+        }
+        float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+        if (p.relu_x) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xv[k] = fmaxf(xv[k], 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float dc = rv ? d[c] : 0.f;
+          bsum[c] += dc;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a[c][k] += dc * xv[k];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[threadIdx.x][4 * c + k] = a[c][k];
+    red[threadIdx.x][16 + c] = bsum[c];
+  }
+  __syncthreads();
+  // thread t < lpr * 20: value v of channel quad cq' = t / 20, summed over the row slots in fixed order
+  float *out = p.ws + static_cast<long long>(blockIdx.x) * (static_cast<long long>(N) * 4 + N);
+  for (int t = threadIdx.x; t < lpr * 20; t += 256) {
+    const int q = t / 20, v = t - q * 20;
+    float s = 0.f;
+    for (int u = 0; u < slots; ++u) s += red[u * lpr + q][v];
+    if (v < 16) out[(4 * q + (v >> 2)) * 4 + (v & 3)] = s;            // dW[n][k], n = 4 q + v / 4
+    else if (p.want_db) out[static_cast<long long>(N) * 4 + 4 * q + (v - 16)] = s;
+  }
+}
+
 __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long long stride,
                                        long long nw, float *__restrict__ dW, long long nb,
                                        float *__restrict__ db, int accumulate) {
@@ -1004,7 +1081,11 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
     nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K,
                             4.0 * (static_cast<double>(M) * (K + N)));
     const unsigned gx = static_cast<unsigned>(chunks);
-    if (pl.vec4) {
+    if (K == 4 && N % 4 == 0 && N >= 16 && pl.slots == chunks && pl.grid_y == 1 &&
+        ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0) {
+      if (mask) hipLaunchKernelGGL((linear_wgrad_k4_kernel<true>), dim3(gx), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((linear_wgrad_k4_kernel<false>), dim3(gx), dim3(256), 0, st, p);
+    } else if (pl.vec4) {
       const dim3 grid(gx, 1);
       if (pl.threads == 512)
         hipLaunchKernelGGL((linear_wgrad4_kernel<2, 512>), grid, dim3(512), 0, st, p, pl.waves_n, pl.kparts);

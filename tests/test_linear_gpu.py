@@ -138,3 +138,22 @@ def test_failed_backward_leaves_nothing_behind():
             assert torch.equal(a_, e_)
     finally:
         hip_linear._OVERLAP_WGRAD = was
+
+
+@pytest.mark.parametrize("M,N,mask,relu_x", [(70001, 200, True, False), (5000, 120, False, False), (131072, 256, True, True),
+                                             (33, 16, False, False)])
+def test_wgrad_k4_stream_kernel(M, N, mask, relu_x):
+    """K = 4 weight gradients (position-encoding layers) take the streaming kernel: against fp64, deterministic."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    x = torch.randn(M, 4, generator=g).to(DEV)
+    m = torch.randn(M, N, generator=g).to(DEV) if mask else None
+    dw, db = hip_linear._wgrad(dy, x, m, relu_x, True)
+    dyp = dy.double() * (m > 0) if mask else dy.double()
+    xp = F.relu(x.double()) if relu_x else x.double()
+    ref_w, ref_b = dyp.t() @ xp, dyp.sum(0)
+    assert float((dw.double() - ref_w).abs().max()) <= 3e-6 * float(ref_w.abs().max()) + 1e-5
+    assert float((db.double() - ref_b).abs().max()) <= 3e-6 * float(ref_b.abs().max()) + 1e-5
+    dw2, db2 = hip_linear._wgrad(dy, x, m, relu_x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
