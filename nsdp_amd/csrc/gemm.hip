@@ -468,6 +468,49 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
   else epilogue(std::false_type{});
 }
 
+// K = 4 forward (first layer of a position-encoding MLP: 3-d relative coordinates, zero-padded): 8 flops per output
+// float -- a pure output stream.  N/4 lanes per row, each with the 4 x 4 weights and the bias of its four channels in
+// registers, one 16-byte load of the row's coordinates and one float4 store per row.  WP selects where a weight
+// row lives (fragment-major pack: row n of the only k block is float4 number (n / 16) * 64 + n % 16).
+template <bool WP>
+__global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
+  const int N = p.N;
+  const int lpr = N >> 2, slots = 256 / lpr;
+  const int sub = threadIdx.x / lpr, cq = threadIdx.x - sub * lpr;
+  if (sub >= slots) return;
+  float4 w[4], b = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = 4 * cq + c;
+    w[c] = *reinterpret_cast<const float4 *>(p.W + (WP ? (static_cast<long long>(n >> 4) * 64 + (n & 15)) * 4
+                                                       : static_cast<long long>(n) * 4));
+  }
+  if (p.bias) b = *reinterpret_cast<const float4 *>(p.bias + 4 * cq);
+  const long long stride = static_cast<long long>(gridDim.x) * slots;
+  constexpr int U = 4;
+  for (long long r = static_cast<long long>(blockIdx.x) * slots + sub; r < p.M; r += U * stride) {
+    float4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * stride;
+      x[u] = *reinterpret_cast<const float4 *>(p.X + (rr < p.M ? rr : p.M - 1) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * stride;
+      float4 xv = x[u];
+      if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
+      float4 y;
+      y.x = b.x + (xv.x * w[0].x + xv.y * w[0].y + xv.z * w[0].z + xv.w * w[0].w);
+      y.y = b.y + (xv.x * w[1].x + xv.y * w[1].y + xv.z * w[1].z + xv.w * w[1].w);
+      y.z = b.z + (xv.x * w[2].x + xv.y * w[2].y + xv.z * w[2].z + xv.w * w[2].w);
+      y.w = b.w + (xv.x * w[3].x + xv.y * w[3].y + xv.z * w[3].z + xv.w * w[3].w);
+      if (p.relu_out) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+      if (rr < p.M) *reinterpret_cast<float4 *>(p.Y + rr * N + 4 * cq) = y;
+    }
+  }
+}
+
 template <int MT, int NT>
 int launch_nt(const LinearParams &p, hipStream_t st, int grid_y = 1, bool wp = false) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
@@ -954,6 +997,18 @@ static int linear_dispatch(const float *X, const float *W, const float *bias, co
   LinearParams p{X, W, bias, residual, mask, out_mask, Y, g_nt_dbg, M, N, K, relu_in, relu_out};
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
+  if (K == 4 && N % 4 == 0 && N >= 16 && M >= 4096 && !residual && !mask && !out_mask &&
+      ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0) {
+    nsdp::prof::Scope scope(nsdp::prof::kLinear, st, 2.0 * M * N * K,
+                            4.0 * (static_cast<double>(M) * (K + N) + static_cast<double>(N) * K));
+    const int slots = 256 / (N >> 2);
+    long long grid = (M + 4LL * slots - 1) / (4LL * slots);
+    const long long cap = 8LL * nsdp::num_cus();
+    grid = grid < cap ? grid : cap;
+    if (wp) hipLaunchKernelGGL((linear_k4_fwd_kernel<true>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((linear_k4_fwd_kernel<false>), dim3(static_cast<unsigned>(grid)), dim3(256), 0, st, p);
+    return nsdp::launch_status("linear_k4_fwd_kernel");
+  }
   // small M (per-point layers at the 500/100-anchor levels): one 16-row tile x 4 column tiles per wave and
   // the column tiles spread over grid.y, so that a few thousand rows still fill the chip
   if (M <= 32768 && nt > 4 && (wp || g_nt_pipe != 2)) return launch_nt<1, 4>(p, st, (nt + 3) / 4, wp);
