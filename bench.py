@@ -215,6 +215,12 @@ def main():
     elif args.workload == "dense_inference":
         dominant = None      # a handful of launches per step: time them all
     fence()
+    # Python's cyclic collector is kept out of the timed region (a generation-2 pass over the objects of a model this
+    # size was seen to stall the host for ~80 ms -- a whole inference step -- whenever it happened to fall inside);
+    # nothing the step allocates is cyclic garbage, and the collector is switched back on right after
+    import gc
+    gc.collect()
+    gc.disable()
     if os.environ.get("NSDP_BENCH_NO_EVENTS") != "1":    # (A/B knob: cost of the HIP events themselves)
         profiling.start(only=[dominant] if dominant else None)
     t0 = time.perf_counter()
@@ -222,6 +228,7 @@ def main():
         loss = run()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     prof = profiling.stop()
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
