@@ -136,6 +136,19 @@ int nsdp_linear_wp_f32(const float *X, const float *Wp, const float *bias, const
  * (the pack of W^T, operand of dX = dY * W); kperm(g, j) = 16 (j / 4) + 4 g + j % 4 is the order in which a lane's
  * eight activation values of a k block are loaded (the four lane groups of a row then read 64 contiguous bytes per
  * instruction); sizes from nsdp_packed_weight_bf16x3_bytes(N, K, transposed). */
+/* Every pack of a model in one launch per 64 descriptors (the optimizer rewrites all weights once per train step, so
+ * all packs are rebuilt once per step).  `descs` is a HOST array; kind 0 = nsdp_pack_weight_f32 layout, 1 =
+ * nsdp_pack_weight_bf16x3 layout; Wp / WpT may be NULL (not both); results are bit-identical to the single calls. */
+typedef struct {
+  const float *W; /* [N, K] row-major, device */
+  void *Wp;       /* forward pack or NULL */
+  void *WpT;      /* pack of W^T or NULL */
+  int N, K;
+  int kind;
+  int reserved;
+} NsdpPackDesc;
+int nsdp_pack_weights_batched(const NsdpPackDesc *descs, int count, void *stream);
+
 long long nsdp_packed_weight_bf16x3_bytes(int N, int K, int transposed);
 int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, void *stream);
 int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack_bodies.h"
 #include "prof.h"
 
 namespace {
@@ -941,31 +942,7 @@ __global__ void reduce_partials_kernel(const float *__restrict__ ws, int S, long
 // (the operand of dX = dY * W, i.e. the pack of W^T), zero outside [N,K].  One thread per float4 of each output.
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ W, int N, int K,
                                                           float *__restrict__ Wp, float *__restrict__ WpT) {
-  const int NB = (N + 15) >> 4, KB = (K + 15) >> 4;
-  const long long q = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  if (q >= static_cast<long long>(NB) * KB * 64) return;
-  const int lane = static_cast<int>(q & 63), li = lane & 15, g = lane >> 4;
-  const long long blk = q >> 6;
-  if (Wp) {
-    const int tn = static_cast<int>(blk / KB), kb = static_cast<int>(blk % KB);
-    const int n = tn * 16 + li, k0 = kb * 16 + 4 * g;
-    float4 v;
-    v.x = n < N && k0 + 0 < K ? W[static_cast<long long>(n) * K + k0 + 0] : 0.f;
-    v.y = n < N && k0 + 1 < K ? W[static_cast<long long>(n) * K + k0 + 1] : 0.f;
-    v.z = n < N && k0 + 2 < K ? W[static_cast<long long>(n) * K + k0 + 2] : 0.f;
-    v.w = n < N && k0 + 3 < K ? W[static_cast<long long>(n) * K + k0 + 3] : 0.f;
-    reinterpret_cast<float4 *>(Wp)[q] = v;
-  }
-  if (WpT) {
-    const int tk = static_cast<int>(blk / NB), nb = static_cast<int>(blk % NB);
-    const int k = tk * 16 + li, n0 = nb * 16 + 4 * g;
-    float4 v;
-    v.x = k < K && n0 + 0 < N ? W[static_cast<long long>(n0 + 0) * K + k] : 0.f;
-    v.y = k < K && n0 + 1 < N ? W[static_cast<long long>(n0 + 1) * K + k] : 0.f;
-    v.z = k < K && n0 + 2 < N ? W[static_cast<long long>(n0 + 2) * K + k] : 0.f;
-    v.w = k < K && n0 + 3 < N ? W[static_cast<long long>(n0 + 3) * K + k] : 0.f;
-    reinterpret_cast<float4 *>(WpT)[q] = v;
-  }
+  nsdp::pack::fp32_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
 }  // namespace

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "pack_bodies.h"
 #include "prof.h"
 
 namespace {
@@ -453,47 +454,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 // zero outside [N,K].  One thread per (block, tile, lane) of each output.
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restrict__ W, int N, int K,
                                                           u32x4 *__restrict__ Wp, u32x4 *__restrict__ WpT) {
-  const long long q = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
-  const int lane = static_cast<int>(q & 63), li = lane & 15, g = lane >> 4;
-  const long long blk = q >> 6;
-  if (Wp) {
-    const int NT = (N + 15) >> 4, KB = (K + 31) >> 5;
-    if (blk < static_cast<long long>(NT) * KB) {
-      const int kb = static_cast<int>(blk / NT), tn = static_cast<int>(blk % NT);
-      const int n = tn * 16 + li, k0 = kb * 32 + 4 * g;
-      u32x4 h, m, l;
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr) {
-        const int k = k0 + 16 * (pr >> 1) + 2 * (pr & 1);
-        const float x0 = n < N && k < K ? W[static_cast<long long>(n) * K + k] : 0.f;
-        const float x1 = n < N && k + 1 < K ? W[static_cast<long long>(n) * K + k + 1] : 0.f;
-        unsigned a, b, c;
-        split_pair(x0, x1, a, b, c);
-        h[pr] = a; m[pr] = b; l[pr] = c;
-      }
-      u32x4 *dst = Wp + (blk * 3) * 64 + lane;
-      dst[0] = h; dst[64] = m; dst[128] = l;
-    }
-  }
-  if (WpT) {
-    const int KT = (K + 15) >> 4, NB = (N + 31) >> 5;
-    if (blk < static_cast<long long>(KT) * NB) {
-      const int nb = static_cast<int>(blk / KT), tk = static_cast<int>(blk % KT);
-      const int k = tk * 16 + li, n0 = nb * 32 + 4 * g;
-      u32x4 h, m, l;
-#pragma unroll
-      for (int pr = 0; pr < 4; ++pr) {
-        const int n = n0 + 16 * (pr >> 1) + 2 * (pr & 1);
-        const float x0 = k < K && n < N ? W[static_cast<long long>(n) * K + k] : 0.f;
-        const float x1 = k < K && n + 1 < N ? W[static_cast<long long>(n + 1) * K + k] : 0.f;
-        unsigned a, b, c;
-        split_pair(x0, x1, a, b, c);
-        h[pr] = a; m[pr] = b; l[pr] = c;
-      }
-      u32x4 *dst = WpT + (blk * 3) * 64 + lane;
-      dst[0] = h; dst[64] = m; dst[128] = l;
-    }
-  }
+  nsdp::pack::x3_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
 template <int MT, int NT, int PRE, int WV, bool XREG = false>

@@ -57,7 +57,7 @@ class _Pack:
 
     def get(self, dec):
         params = list(dec.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = tuple((p.data_ptr(), p._version) for p in params) + (hip_linear._weights_epoch,)
         if key == self.key:
             return self
         ct = dec.ct1

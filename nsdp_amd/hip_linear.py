@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -236,17 +237,95 @@ def _x3_ok(M, N, K):
     return _USE_X3 and M >= _X3_MIN_ROWS and K > 32 and K % 4 == 0 and N % 4 == 0 and N <= 256
 
 
+# Pack caches are keyed by (storage pointer, tensor version, weights epoch).  The version counter alone is not enough:
+# PyTorch's fused optimizers (torch._fused_adam_ ...) and writes through `.data` update parameters WITHOUT bumping it.
+# Every optimizer step therefore advances a global epoch (hook on all torch optimizers, registered below); code that
+# rewrites weights by other untracked means calls invalidate_weight_packs() itself.
+_weights_epoch = 0
+
+
+def invalidate_weight_packs():
+    """Declare every cached weight pack stale (they are rebuilt at their next use)."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+def _pack_key(t):
+    return (t.data_ptr(), t._version, _weights_epoch)
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(lambda _opt, _args, _kwargs: invalidate_weight_packs())
+except ImportError:      # (PyTorch without global optimizer hooks: the version counter is all there is)
+    pass
+
+
+class _PackDesc(ctypes.Structure):      # NsdpPackDesc (include/nsdp_hip.h)
+    _fields_ = [("W", ctypes.c_void_p), ("Wp", ctypes.c_void_p), ("WpT", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("kind", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+# Every pack that belongs to a parameter is also listed here, so that after an optimizer step ALL of them are rebuilt
+# by one nsdp_pack_weights_batched call (in place, same buffers) instead of one launch per layer at its next use.
+# device index -> {"entries": {(id(param), kind): [weakref(param), kind, wp, wpt]}, "array": ctypes array or None}
+_pack_registry = {}
+_BATCH_MIN = 8          # below this many registered packs the per-layer launches are just as good
+
+
+def _repack_all(device):
+    """Rebuild every registered pack of `device` from the current parameter values (current stream), and mark the
+    per-parameter caches as valid for the parameters' current (storage pointer, version)."""
+    reg = _pack_registry[device.index]
+    ents = reg["entries"]
+    dead = [k for k, e in ents.items() if e[0]() is None]
+    for k in dead:
+        del ents[k]
+        reg["array"] = None
+    live = list(ents.values())
+    if reg["array"] is None or len(reg["array"]) != len(live):
+        reg["array"] = (_PackDesc * len(live))()
+    arr = reg["array"]
+    for i, (ref, kind, wp, wpt) in enumerate(live):
+        prm = ref()
+        w = prm.detach()
+        w = w.squeeze(-1) if w.dim() == 3 else w
+        if not w.is_contiguous():          # (never the case for nn.Linear / 1x1 Conv1d weights)
+            return False
+        d = arr[i]
+        d.W, d.Wp, d.WpT = w.data_ptr(), (wp.data_ptr() if wp is not None else None), (wpt.data_ptr() if wpt is not None else None)
+        d.N, d.K, d.kind = w.shape[0], w.shape[1], 1 if kind == "x3" else 0
+    with torch.cuda.device(device):
+        check(lib().nsdp_pack_weights_batched(arr, _ci(len(live)), stream_ptr()), "nsdp_pack_weights_batched")
+    for ref, kind, wp, wpt in live:
+        prm = ref()
+        cache = prm.__dict__.get("_nsdp_pack")
+        key = _pack_key(prm)
+        if cache is None or cache["key"] != key:
+            cache = prm.__dict__["_nsdp_pack"] = {"key": key}
+        cache[kind] = (wp, wpt)
+    return True
+
+
 def _packs(w, owner, kind, want_t):
     """(pack of W, pack of W^T or None) of w [N,K]; kind 'wp' = fp32 fragment-major, 'x3' = bf16x3 planes.
-    `owner` (the layer's nn.Parameter, or None) carries a cache keyed by (storage pointer, version counter):
-    optimizer steps and load_state_dict bump the version, .to(device) changes the pointer.  Without an owner
-    the pack is rebuilt per call (a reused address of a freed temporary must never hit a stale pack)."""
+    `owner` (the layer's nn.Parameter, or None) carries a cache keyed by (storage pointer, version counter, weights
+    epoch): load_state_dict bumps the version, every optimizer step the epoch, .to(device) changes the pointer.  Without an owner
+    the pack is rebuilt per call (a reused address of a freed temporary must never hit a stale pack).
+    A stale cache of a registered parameter triggers one batched rebuild of every registered pack (_repack_all)."""
     cache = None
     if owner is not None:
-        key = (w.data_ptr(), w._version)
+        key = _pack_key(w)
         cache = owner.__dict__.get("_nsdp_pack")
-        if cache is None or cache["key"] != key:
-            cache = owner.__dict__["_nsdp_pack"] = {"key": key}
+        stale = cache is not None and cache["key"] != key
+        if cache is None or stale:
+            reg = _pack_registry.get(w.device.index)
+            ent = reg["entries"].get((id(owner), kind)) if reg is not None else None
+            if (stale and ent is not None and ent[0]() is owner and len(reg["entries"]) >= _BATCH_MIN
+                    and (ent[3] is not None or not want_t) and _repack_all(w.device)):
+                cache = owner.__dict__["_nsdp_pack"]
+            else:
+                cache = owner.__dict__["_nsdp_pack"] = {"key": key}
         ent = cache.get(kind)
         if ent is not None and (ent[1] is not None or not want_t):
             return ent
@@ -254,6 +333,10 @@ def _packs(w, owner, kind, want_t):
     ent = pack_weight_x3(wc, True, want_t) if kind == "x3" else pack_weight(wc, True, want_t)
     if cache is not None:
         cache[kind] = ent
+        if wc is w:
+            reg = _pack_registry.setdefault(w.device.index, {"entries": {}, "array": None})
+            reg["entries"][(id(owner), kind)] = [weakref.ref(owner), kind, ent[0], ent[1]]
+            reg["array"] = None
     return ent
 
 

@@ -25,10 +25,8 @@ def optimizer_factory(config, parameters):
         group["momentum"] = config.get("momentum", 0.9)
         return schedule, torch.optim.SGD([group])
     if name == "Adam":
-        # same update rule as the reference's torch.optim.Adam; on GPU parameters PyTorch's single-kernel ("fused")
-        # implementation replaces a dozen multi-tensor launches per step
-        fused = bool(parameters) and all(p.is_cuda and p.is_floating_point() for p in parameters)
-        return schedule, torch.optim.Adam([group], fused=True) if fused else torch.optim.Adam([group])
+        # (PyTorch's fused=True variant was measured: no gain once the weight packs are rebuilt by one batched launch)
+        return schedule, torch.optim.Adam([group])
     raise NotImplementedError(name)
 
 

@@ -157,3 +157,71 @@ def test_wgrad_k4_stream_kernel(M, N, mask, relu_x):
     assert float((db.double() - ref_b).abs().max()) <= 3e-6 * float(ref_b.abs().max()) + 1e-5
     dw2, db2 = hip_linear._wgrad(dy, x, m, relu_x, True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_batched_repack_equals_single_packs():
+    """After an optimizer step all registered packs are rebuilt by one batched launch: bit-identical to the per-layer
+    pack kernels, for both pack formats, forward and transposed."""
+    from nsdp_amd import hip_linear
+    torch.manual_seed(0)
+    layers = [torch.nn.Linear(k, n).to(DEV) for k, n in [(64, 48), (48, 200), (200, 200), (200, 128), (128, 256),
+                                                         (256, 120), (120, 64), (64, 16), (16, 40), (40, 8)]]
+    x_small = torch.randn(300, 64, device=DEV, requires_grad=True)        # fp32 packs ("wp")
+    x_big = torch.randn(40000, 64, device=DEV, requires_grad=True)        # bf16x3 packs where the shapes allow
+    opt = torch.optim.SGD([p for l in layers for p in l.parameters()], lr=1e-6)
+
+    def fwd(x):
+        for l in layers:
+            x = hip_linear.linear(x, l.weight, l.bias, relu_out=True, params=True)
+        return x
+
+    for step in range(3):
+        opt.zero_grad()
+        (fwd(x_small).mean() + fwd(x_big).mean()).backward()
+        opt.step()
+    fwd(x_small); fwd(x_big)                      # stale caches -> one batched rebuild
+    reg = hip_linear._pack_registry[DEV.index]["entries"]
+    checked = 0
+    for l in layers:
+        w = l.weight.detach()
+        for kind in ("wp", "x3"):
+            ent = reg.get((id(l.weight), kind))
+            if ent is None:
+                continue
+            assert l.weight.__dict__["_nsdp_pack"]["key"] == hip_linear._pack_key(w)
+            single = (hip_linear.pack_weight_x3 if kind == "x3" else hip_linear.pack_weight)(w, ent[2] is not None, ent[3] is not None)
+            for got, want in zip(ent[2:4], single):
+                if got is not None:
+                    assert torch.isfinite(w).all()
+                    assert torch.equal(got.view(torch.uint8), want.view(torch.uint8))      # bit for bit
+                    checked += 1
+    assert checked >= 12
+    ref = x_small
+    for l in layers:
+        ref = F.relu(F.linear(ref.double(), l.weight.double(), l.bias.double()))
+    out = fwd(x_small)
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_packs_follow_every_optimizer(fused):
+    """torch's fused optimizers update parameters without bumping their version counters: the pack caches must be
+    invalidated by the optimizer-step hook, not by versions alone (a stale pack means training on frozen weights)."""
+    from nsdp_amd import hip_linear
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(64, 32).to(DEV)
+    x = torch.randn(512, 64, device=DEV)
+    opt = torch.optim.Adam(lin.parameters(), lr=0.05, fused=fused)
+    for _ in range(3):
+        opt.zero_grad()
+        y = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+        ref = F.linear(x.double(), lin.weight.double(), lin.bias.double())
+        assert float((y.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+        y.square().mean().backward()
+        opt.step()
+    with torch.no_grad():
+        lin.weight.data.mul_(2.0)                # untracked write: explicit invalidation is the contract
+    hip_linear.invalidate_weight_packs()
+    y = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+    ref = F.linear(x.double(), lin.weight.double(), lin.bias.double())
+    assert float((y.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)

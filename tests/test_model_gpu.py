@@ -178,3 +178,32 @@ def test_flat_bucket_gradients_equal_plain_gradients_on_gpu():
         g = plain[k]
         # two runs differ by fp32 atomic-ordering noise in the scatter-adds
         assert float((p.grad - g).abs().max()) <= 2e-3 * float(g.abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize("mtype", ["forward", "arbitrary"])
+def test_forward_after_optimizer_steps_uses_the_new_weights(mtype):
+    """Weight packs (per-layer and the fused decoder's) are caches of the parameters: after optimizer steps -- here
+    with PyTorch's fused Adam, which does NOT bump tensor version counters -- the model must compute exactly what a
+    freshly built model holding the same state_dict computes."""
+    fx, cfg, seed, data = fixture_setup("tiny_" + mtype, mtype)
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, fused=True)
+    dev_data = to_dev(data, DEV)
+    l0 = train_fn(model, opt, dev_data, cfg)
+    l1 = train_fn(model, opt, dev_data, cfg)
+    l2 = train_fn(model, opt, dev_data, cfg)
+    assert len({round(l0, 9), round(l1, 9), round(l2, 9)}) == 3          # the loss moves with the weights
+    fresh, _, _ = build_product(cfg, seed, DEV)
+    fresh.load_state_dict(model.state_dict())
+    for m in (model, fresh):
+        m.eval()
+    with torch.no_grad():
+        a = run_forward(model, cfg, dev_data)                             # fused decoder kernel (its own pack)
+        b = run_forward(fresh, cfg, dev_data)
+    assert torch.equal(a, b)
+    for m in (model, fresh):
+        m.train()
+    a = run_forward(model, cfg, dev_data)                                 # layer-by-layer path, packs per parameter
+    b = run_forward(fresh, cfg, dev_data)
+    assert torch.equal(a, b)
