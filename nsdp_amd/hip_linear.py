@@ -297,6 +297,9 @@ def _repack_all(device):
         d.N, d.K, d.kind = w.shape[0], w.shape[1], 1 if kind == "x3" else 0
     with torch.cuda.device(device):
         check(lib().nsdp_pack_weights_batched(arr, _ci(len(live)), stream_ptr()), "nsdp_pack_weights_batched")
+    # the buffers were rewritten in place behind autograd's back: bump their version counters, so that a graph retained
+    # from before the optimizer step (it saved a W^T pack for its dX) fails loudly instead of using the new weights
+    torch.autograd.graph.increment_version([t for e in live for t in e[2:4] if t is not None])
     for ref, kind, wp, wpt in live:
         prm = ref()
         cache = prm.__dict__.get("_nsdp_pack")

@@ -225,3 +225,27 @@ def test_packs_follow_every_optimizer(fused):
     y = hip_linear.linear(x, lin.weight, lin.bias, params=True)
     ref = F.linear(x.double(), lin.weight.double(), lin.bias.double())
     assert float((y.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1.0)
+
+
+def test_retained_graph_across_an_optimizer_step_fails_loudly():
+    """The batched rebuild rewrites pack buffers in place; a graph retained from before the step must not silently
+    compute dX with the new weights."""
+    from nsdp_amd import hip_linear
+    layers = [torch.nn.Linear(32, 32).to(DEV) for _ in range(9)]        # >= _BATCH_MIN registered packs
+    opt = torch.optim.SGD([p for l in layers for p in l.parameters()], lr=1e-3)
+    x = torch.randn(256, 32, device=DEV, requires_grad=True)
+
+    def fwd():
+        h = x
+        for l in layers:
+            h = hip_linear.linear(h, l.weight, l.bias, relu_out=True, params=True)
+        return h.mean()
+
+    fwd().backward()
+    opt.step()
+    old = fwd()                      # batched rebuild happens here; `old` saves the rebuilt packs
+    old.backward(retain_graph=True)
+    opt.step()
+    fwd()                            # next rebuild rewrites the buffers `old` saved
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        old.backward()
