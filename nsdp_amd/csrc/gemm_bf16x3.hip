@@ -482,7 +482,9 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   // one 8-wave workgroup, bit-identical results).  13 n tiles would need 2 x 110 KiB.
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
-  if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
+  // (the masked prologue as well, up to 8 n tiles: 10-25 % over one 4-wave workgroup with more row tiles)
+  if (pre == 1 && NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), 1, 4, true>(p, st, 2);
+  else if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
   else if (NT <= 8 && two_waves) {
     if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4>(p, st, 2);
     else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 4>(p, st, 2);
