@@ -3,7 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch B]
 
-One process per GPU (torch.distributed / RCCL for N > 1, launched by torch.distributed.run); a "step"
+One process per GPU (torch.distributed / RCCL for N > 1).  Started under torch.distributed.run (RANK / WORLD_SIZE in
+the environment) it is one rank of the job; started from a bare shell with --gpus N > 1 it launches the N ranks itself
+(re-exec through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` on a free
+port, rank r bound to GPU r).  A "step"
 is one pass of the reference's ``train_on_batch`` sequence (model/deformation_networks.py:63-77) over
 one synthetic batch of B shapes per GPU, 2048 surface + 8192 query points each, forward.yaml
 architecture, fp32, inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
@@ -74,24 +77,123 @@ def cpu_baseline(seconds_budget=20.0):
                                       f"on {torch.get_num_threads()} host threads ({os.cpu_count()} logical CPUs)"}
 
 
+def stub_main(args, rank, world):
+    """The multi-rank plumbing of this file on a box without GPUs: same rendezvous, barrier-bracketed timing, MAX over
+    ranks, flat-bucket all-reduce (nsdp_amd.parallel.GradAllReducer) and JSON line, around a tiny CPU model.  Used by
+    tests/test_bench_launch_cpu.py; the line is marked as a stub and is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    from nsdp_amd.parallel import GradAllReducer
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.backend == "nccl" and not torch.cuda.is_available() else args.backend,
+                                rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.ModuleDict({"encoder": torch.nn.Linear(16, 16), "decoder": torch.nn.Linear(16, 3)})
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    reducer = GradAllReducer(model, world) if world > 1 else None
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = torch.randn(args.batch * 64, 16, generator=g)
+    y = torch.randn(args.batch * 64, 3, generator=g)
+
+    def step():
+        reducer.zero_grad() if reducer is not None else opt.zero_grad()
+        loss = ((model["decoder"](torch.relu(model["encoder"](x))) - y) ** 2).mean()
+        loss.backward()
+        if reducer is not None:
+            reducer.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # every rank must hold the same weights after the same number of averaged steps
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        lo, hi = w.clone(), w.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+    else:
+        in_sync = True
+    if rank == 0:
+        total = world * args.batch * 64 * args.steps
+        print(json.dumps({"metric": "stub rows/s (plumbing test, NOT a measurement)", "value": round(total / elapsed, 1),
+                          "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stub", "global_batch": world * args.batch, "parallelism": f"dp{world}"},
+                          "per_gpu": round(total / elapsed / world, 1),
+                          "comm": {"backend": dist.get_backend() if world > 1 else None,
+                                   "world_size": dist.get_world_size() if world > 1 else 1,
+                                   "grad_bytes_per_step": reducer.nbytes if reducer is not None else None},
+                          "ranks_in_sync": in_sync, "final_loss": round(float(loss), 6), "stub": True}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` from a bare shell (no RANK / WORLD_SIZE): start the N ranks ourselves through
+    torch.distributed.run on 127.0.0.1 and a free port; the children take the worker path below.  Returns the exit
+    code of the launcher (rank 0's JSON line passes through on stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+DEFAULT_BATCH = {"forward_train": 32, "arbitrary_train": 32, "forward_eval": 8, "dense_inference": 4}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="shapes per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="shapes per GPU (weak scaling); default 32 for the train steps (BASELINE configs 3/4 per GPU), "
+                         "8 for forward_eval (config 2), 4 for dense_inference (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="forward_train",
-                    choices=["forward_train", "arbitrary_train", "dense_inference"],
-                    help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3 shape, "
-                         "fp32) | dense_inference (BASELINE config 5: eval, 100k queries per shape)")
+                    choices=["forward_train", "arbitrary_train", "forward_eval", "dense_inference"],
+                    help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3) | "
+                         "forward_eval (BASELINE config 2: eval forward, 8192 queries per shape) | dense_inference "
+                         "(BASELINE config 5: eval, 100k queries per shape)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole train step (fwd + bwd + Adam) in one hipGraph and replay it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to exercise the multi-rank code path on a single GPU)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
+    ap.add_argument("--stub-step", action="store_true",
+                    help="replace the TDNet step by a tiny CPU model (tests of the launch / rendezvous / all-reduce / "
+                         "timing / JSON plumbing on a box without GPUs; the line says so and is not a measurement)")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = DEFAULT_BATCH[args.workload]
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -99,7 +201,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
+    if args.stub_step:
+        return stub_main(args, rank, world)
+    if args.backend == "nccl" and torch.cuda.device_count() < world // max(1, int(os.environ.get("NNODES", "1"))):
+        sys.exit(f"bench.py: --gpus {args.gpus} needs {world} visible GPUs, found {torch.cuda.device_count()}")
     dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -121,10 +228,11 @@ def main():
         cfg["model"]["type"] = "arbitrary"
     elif args.workload == "dense_inference":
         n_query = 100000
+    is_eval = args.workload in ("forward_eval", "dense_inference")
     model, _train_on_batch, _, _ = build_model(cfg, device="cpu")
     state = synth.procedural_state_dict(model.state_dict(), 2048)  # identical weights on every rank
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-    model.to(device).train(args.workload != "dense_inference")
+    model.to(device).train(not is_eval)
     _, optimizer = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
                                       "weight_decay": 0.0}, model.parameters())
     reducer = GradAllReducer(model, world) if (world > 1 or args.force_reducer) else None
@@ -161,9 +269,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run = infer_step if args.workload == "dense_inference" else step
+    run = infer_step if is_eval else step
     graph = None
-    if args.graph and args.workload != "dense_inference" and world == 1:
+    if args.graph and not is_eval and world == 1:
         # whole-step capture: every kernel of the step (HIP library launches on the current stream, Adam's
         # foreach kernels) goes into one hipGraph; needs a capturable optimizer and static input buffers
         for g in optimizer.param_groups:
@@ -197,7 +305,7 @@ def main():
     # spans the time the kernel waits for CUs held by the other stream.
     prof_iso = None
     dominant = "linear_bf16x3_kernel"
-    if graph is None and args.workload != "dense_inference" and world == 1:
+    if graph is None and not is_eval and world == 1:
         from nsdp_amd import hip_linear
         was = hip_linear._OVERLAP_WGRAD
         hip_linear._OVERLAP_WGRAD = False
@@ -212,8 +320,8 @@ def main():
         if prof_iso:
             dominant = max(prof_iso.items(), key=lambda kv: kv[1]["ms"])[0]
         run()            # back on the overlapped schedule before the clock starts
-    elif args.workload == "dense_inference":
-        dominant = None      # a handful of launches per step: time them all
+    elif is_eval:
+        dominant = None      # few launches per step: time them all
     fence()
     # Python's cyclic collector is kept out of the timed region (a generation-2 pass over the objects of a model this
     # size was seen to stall the host for ~80 ms -- a whole inference step -- whenever it happened to fall inside);
@@ -243,6 +351,8 @@ def main():
                                    "forward.yaml TDNet train step (fwd + l2 loss + bwd + Adam)"),
                  "arbitrary_train": ("query-points/sec fwd+bwd, FlowArbitrary (2048 surf pts, 8192 queries)",
                                      "arbitrary.yaml FlowArbitrary train step (two TDNets, fwd + l2 loss + bwd + Adam)"),
+                 "forward_eval": ("query-points/sec forward (2048 surf pts, 8192 queries)",
+                                  "forward.yaml TDNet eval forward (no grad)"),
                  "dense_inference": ("query-points/sec forward (2048 surf pts, 100000 queries)",
                                      "forward.yaml TDNet eval forward, dense per-vertex decode")}[args.workload]
         line = {
@@ -257,6 +367,11 @@ def main():
                        "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1),
+            "comm": {"backend": (dist.get_backend() if world > 1 else None),
+                     "world_size": (dist.get_world_size() if world > 1 else 1),
+                     "grad_bytes_per_step": (reducer.nbytes if reducer is not None else None),
+                     "exchange": ("flat fp32 gradient, 2 in-place all-reduce buckets after backward (not overlapped)"
+                                  if reducer is not None else None)},
             "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2) if args.workload == "forward_train" else None,
             "final_loss": round(final_loss, 6),
             "roofline": profiling.roofline(prof, prof_iso,

@@ -255,6 +255,12 @@ void nsdp_prof_enable(int on);            /* on=1 clears previous records and st
  * ~3 ms of a 52 ms step, timing one kernel class a few hundred microseconds. */
 void nsdp_prof_enable_kinds(unsigned mask);
 int nsdp_prof_num_kinds(void);
+/* Kernel-variant trace (test instrumentation): while enabled every launcher records the template instance it chose
+ * ("linear_bf16x3<2,13,0,8,0>", "attn_post_bwd_lds", ...).  nsdp_trace_enable(1) clears and starts, (0) stops;
+ * nsdp_trace_read copies the newline-separated unique names (NUL-terminated, truncated to `capacity`) and returns the
+ * size needed. */
+void nsdp_trace_enable(int on);
+int nsdp_trace_read(char *buf, int capacity);
 const char *nsdp_prof_name(int kind);
 /* Sums over all recorded launches of `kind`: count, elapsed ms, algorithmic flops and bytes. */
 int nsdp_prof_collect(int kind, long long *launches, double *total_ms, double *flops, double *bytes);

@@ -3,7 +3,10 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <mutex>
+#include <set>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -62,6 +65,23 @@ Scope::Scope(Kind kind, hipStream_t stream, double flops, double bytes) : slot_(
   slot_ = static_cast<int>(g_records.size()) - 1;
 }
 
+namespace {
+std::atomic<int> g_trace{0};
+std::set<std::string> g_trace_names;
+}  // namespace
+
+bool trace_on() { return g_trace.load(std::memory_order_relaxed) != 0; }
+
+void trace_note(const char *fmt, ...) {
+  char buf[160];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  std::lock_guard<std::mutex> lock(g_mu);
+  g_trace_names.insert(buf);
+}
+
 Scope::~Scope() {
   if (slot_ < 0) return;
   std::lock_guard<std::mutex> lock(g_mu);
@@ -100,6 +120,29 @@ void nsdp_prof_enable_kinds(unsigned mask) {
     g_records.clear();
   }
   g_enabled.store(mask);
+}
+
+void nsdp_trace_enable(int on) {
+  using namespace nsdp::prof;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (on) g_trace_names.clear();
+  g_trace.store(on ? 1 : 0);
+}
+
+int nsdp_trace_read(char *buf, int capacity) {
+  using namespace nsdp::prof;
+  std::lock_guard<std::mutex> lock(g_mu);
+  std::string all;
+  for (const auto &n : g_trace_names) {
+    if (!all.empty()) all += '\n';
+    all += n;
+  }
+  if (buf && capacity > 0) {
+    const int n = static_cast<int>(all.size()) < capacity - 1 ? static_cast<int>(all.size()) : capacity - 1;
+    memcpy(buf, all.data(), n);
+    buf[n] = 0;
+  }
+  return static_cast<int>(all.size()) + 1;
 }
 
 int nsdp_prof_num_kinds(void) { return nsdp::prof::kNumKinds; }

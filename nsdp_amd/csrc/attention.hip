@@ -536,6 +536,7 @@ inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *ta
   long long per = (rows_per_shape + wgs - 1) / wgs;
   per = (per + 7) / 8 * 8;
   wgs = (rows_per_shape + per - 1) / per;
+  NSDP_TRACE("scatter_rows_regtab<8>");
   hipLaunchKernelGGL((scatter_rows_regtab_kernel<8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
                      colsum, acc_rows, rows_per_shape, per, N, d, sign, colsum_sign);
   return nsdp::launch_status("scatter_rows_regtab_kernel");
@@ -560,10 +561,15 @@ inline void lds_plan(AttnShape &s, dim3 &grid) {
 }
 
 template <typename Kern>
-inline void allow_big_lds(Kern kern, size_t bytes) {
-  if (bytes > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              static_cast<int>(bytes));
+inline int allow_big_lds(Kern kern, size_t bytes, const char *what) {
+  if (bytes <= 64 * 1024) return 0;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e != hipSuccess) {
+    nsdp::set_error("%s: opting in to %zu bytes of LDS failed: %s", what, bytes, hipGetErrorString(e));
+    return static_cast<int>(e);
+  }
+  return 0;
 }
 
 inline bool shape_ok(const AttnShape &s) {
@@ -622,13 +628,15 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   }
   if (lds_table_fits(s)) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
-    allow_big_lds(attn_pre_bwd_lds_kernel, lds);
+    if (const int rc = allow_big_lds(attn_pre_bwd_lds_kernel, lds, "attn_pre_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
     dim3 grid;
     lds_plan(sl, grid);
+    NSDP_TRACE("attn_pre_bwd_lds");
     hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf, dpos_acc);
     return nsdp::launch_status("attn_pre_bwd_lds_kernel");
   }
+  NSDP_TRACE("attn_pre_bwd_atomic");
   NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf, dpos_acc);
   return nsdp::launch_status("attn_pre_bwd_kernel");
 }
@@ -673,14 +681,16 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
   const bool has_v = vf != nullptr;
   if (lds_table_fits(s) && has_v) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
-    allow_big_lds(attn_post_bwd_lds_kernel<true>, lds);
+    if (const int rc = allow_big_lds(attn_post_bwd_lds_kernel<true>, lds, "attn_post_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
     dim3 grid;
     lds_plan(sl, grid);
+    NSDP_TRACE("attn_post_bwd_lds");
     hipLaunchKernelGGL((attn_post_bwd_lds_kernel<true>), grid, dim3(kLdsThreads), lds, st, sl, dy, a, vf, pos,
                        idx, a_g, v_g, y, residual, lse, da, dpos, dvf, da_g, dv_g);
     return nsdp::launch_status("attn_post_bwd_lds_kernel");
   }
+  NSDP_TRACE("attn_post_bwd_atomic");
   NSDP_ATTN_LAUNCH_V(attn_post_bwd_kernel, has_v, s, dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, da, dpos,
                      dvf, da_g, dv_g);
   return nsdp::launch_status("attn_post_bwd_kernel");

@@ -213,10 +213,8 @@ int launch_reg(const float *xyz, int B, int N, int M, int BS, int log2BS, int32_
   constexpr int W = T / 64;
   const size_t smem = 16 * (W > 1 ? W : 1) + (LDS_XYZ ? static_cast<size_t>(N) * 16 : 0);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<T, P, LDS_XYZ>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(smem));
-    (void)e;
+    NSDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_reg_kernel<T, P, LDS_XYZ>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
   }
   hipLaunchKernelGGL((fps_reg_kernel<T, P, LDS_XYZ>), dim3(B), dim3(T), smem, st, xyz, N, M, BS, log2BS,
                      idx);

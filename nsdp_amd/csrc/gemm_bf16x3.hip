@@ -465,6 +465,7 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   // last MFMAs and epilogue
   const long long slots = static_cast<long long>(nsdp::num_cus()) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
+  NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu);
   hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 

@@ -31,5 +31,15 @@ struct Scope {
   hipStream_t stream_;
 };
 
+// Kernel-variant trace (tests): when enabled, every launcher notes which template instance it picked, so a parity test
+// can assert that the code path it means to check (8-wave bf16x3 GEMM, LDS-table attention backward, ...) really ran.
+// Disabled by default: one relaxed atomic load per launch.
+bool trace_on();
+void trace_note(const char *fmt, ...);
+#define NSDP_TRACE(...)                                         \
+  do {                                                          \
+    if (nsdp::prof::trace_on()) nsdp::prof::trace_note(__VA_ARGS__); \
+  } while (0)
+
 }  // namespace prof
 }  // namespace nsdp

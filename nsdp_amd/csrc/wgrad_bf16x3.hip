@@ -518,9 +518,11 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
   const dim3 g(grid, p.kparts);
   const bool tail = (p.M & 31) != 0;
   if (p.mask) {
+    NSDP_TRACE("wgrad_bf16x3<%d,%d,mask,%s>", NTA, KTB, tail ? "tail" : "notail");
     if (tail) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true, true>), g, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true, false>), g, dim3(256), 0, st, p);
   } else {
+    NSDP_TRACE("wgrad_bf16x3<%d,%d,plain,%s>", NTA, KTB, tail ? "tail" : "notail");
     if (tail) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false, true>), g, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, false, false>), g, dim3(256), 0, st, p);
   }

@@ -365,8 +365,9 @@ class InputGradSum:
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None):
+    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None):
         ctx.w_param, ctx.b_param = w_param, b_param
+        owner = w_param if w_param is not None else owner     # whose __dict__ carries the pack cache
         ctx.grad_sum = None
         if grad_sum is not None and ctx.needs_input_grad[0]:
             if relu_in or x.shape[-1] % 4:
@@ -388,8 +389,8 @@ class _LinearFn(torch.autograd.Function):
         want_t = bool(ctx.needs_input_grad[0])                         # dX = dY' @ W needs a pack of W^T
         kind = "x3" if _x3_ok(M, N, Kp) else "wp"
         kind_t = "x3" if _x3_ok(M, Kp, N) else "wp"                    # dX: Kp outputs, N is the reduction dim
-        wp = _packs(w, w_param, kind, want_t and kind_t == kind)[0]
-        wpt = _packs(w, w_param, kind_t, True)[1] if want_t else None
+        wp = _packs(w, owner, kind, want_t and kind_t == kind)[0]
+        wpt = _packs(w, owner, kind_t, True)[1] if want_t else None
         y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
@@ -435,7 +436,34 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
+
+
+# Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
+# the side stream possible, but it is invisible to everything that observes gradients THROUGH autograd: tensor hooks,
+# post-accumulate-grad hooks (DDP / FSDP register those), `torch.autograd.grad(loss, params)` and
+# `backward(inputs=[...])`.  Hooks are detected per call and switch that layer to the plain autograd path; for the
+# other two use `with hip_linear.autograd_param_grads():` around forward + backward (or NSDP_PARAM_GRADS=autograd).
+_PARAM_GRADS_DIRECT = os.environ.get("NSDP_PARAM_GRADS", "direct") != "autograd"
+
+
+class autograd_param_grads:
+    """Context manager: layers called inside return dW / db through autograd (main stream, no direct `.grad` writes)."""
+
+    def __enter__(self):
+        global _PARAM_GRADS_DIRECT
+        self._was, _PARAM_GRADS_DIRECT = _PARAM_GRADS_DIRECT, False
+        return self
+
+    def __exit__(self, *exc):
+        global _PARAM_GRADS_DIRECT
+        _PARAM_GRADS_DIRECT = self._was
+        return False
+
+
+def _observed(t):
+    """True when something watches this tensor's gradient through autograd (tensor hook, post-accumulate-grad hook)."""
+    return bool(t._backward_hooks) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None):
@@ -443,14 +471,18 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``."""
     w_param = b_param = None
-    if params and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
+    if (params and _PARAM_GRADS_DIRECT and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf
+            and not _observed(weight)):
         w_param = weight
         b_param = bias if (bias is not None and bias.requires_grad and bias.is_leaf) else None
-        if bias is not None and b_param is None:
-            w_param = None             # mixed case: keep everything on the plain autograd path
+        if bias is not None and (b_param is None or _observed(bias)):
+            w_param = b_param = None   # mixed case: keep everything on the plain autograd path
     w2 = weight.squeeze(-1) if weight.dim() == 3 else weight   # 1x1 Conv1d weight [out, in, 1]
+    # the pack cache lives on the layer's leaf parameter whether or not gradients are being recorded (eval / no_grad
+    # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
+    owner = weight if (params and weight.is_leaf) else None
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
                                bool(relu_out), w_param, b_param, grad_sum)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner)

@@ -232,45 +232,39 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def _with_xyz(local_xyz, feats, use_xyz):
+    """Channel layout shared by both groupers: relative/absolute coordinates first, then the descriptors."""
+    if feats is None:
+        return local_xyz
+    return torch.cat((local_xyz, feats), dim=1) if use_xyz else feats
+
+
 class QueryAndGroup(nn.Module):
-    """Ball query + grouping (pointnet2_utils.py:279-335)."""
+    """Ball query around each centre, then the members' coordinates (relative to the centre) and descriptors as one
+    (B, 3 + C, npoint, nsample) tensor (same contract as pointnet2_utils.py:279-335)."""
 
     def __init__(self, radius, nsample, use_xyz=True):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz, new_xyz, features=None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        xyz_trans = xyz.transpose(1, 2).contiguous()
-        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
-        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
-        if features is not None:
-            grouped_features = grouping_operation(features, idx)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            new_features = grouped_xyz
-        return new_features
+        if features is None and not self.use_xyz:
+            raise AssertionError("QueryAndGroup: without descriptors the coordinates are the only features "
+                                 "(use_xyz=False leaves nothing to return)")
+        members = ball_query(self.radius, self.nsample, xyz, new_xyz)                  # (B, npoint, nsample) int32
+        centres = new_xyz.permute(0, 2, 1)[:, :, :, None]                               # (B, 3, npoint, 1)
+        local = grouping_operation(xyz.permute(0, 2, 1).contiguous(), members) - centres
+        picked = grouping_operation(features, members) if features is not None else None
+        return _with_xyz(local, picked, self.use_xyz)
 
 
 class GroupAll(nn.Module):
-    """Groups all features (pointnet2_utils.py:338-379)."""
+    """One group holding every point: (B, 3 + C, 1, N); ``new_xyz`` is ignored (pointnet2_utils.py:338-379)."""
 
     def __init__(self, use_xyz=True):
         super().__init__()
         self.use_xyz = use_xyz
 
     def forward(self, xyz, new_xyz, features=None):
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        if features is not None:
-            grouped_features = features.unsqueeze(2)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            new_features = grouped_xyz
-        return new_features
+        everything = xyz.permute(0, 2, 1)[:, :, None, :]                                # (B, 3, 1, N), absolute
+        return _with_xyz(everything, None if features is None else features[:, :, None, :], self.use_xyz)

@@ -94,12 +94,26 @@ class SyntheticLoader:
         return len(self.batches)
 
 
+def initial_weight_files(config, args=None):
+    """train.py:140-146: the three weight files that initialise the networks come from the config's ``training``
+    section (``weight_file``, ``weight_forward_file``, ``weight_backward_file``); a command-line value, where given,
+    overrides the config's.  Returns (weight_file, weight_forward_file, weight_backward_file)."""
+    out = []
+    for key in ("weight_file", "weight_forward_file", "weight_backward_file"):
+        v = config.get("training", {}).get(key, None)
+        cli = getattr(args, key, None) if args is not None else None
+        out.append(cli if cli is not None else v)
+    return tuple(out)
+
+
 def main(argv=None):
     import yaml
     ap = argparse.ArgumentParser(description="Train a deformation network on MI355X")
     ap.add_argument("config_file")
     ap.add_argument("experiment_directory")
-    ap.add_argument("--weight_file", default=None)
+    ap.add_argument("--weight_file", default=None, help="overrides training.weight_file of the config")
+    ap.add_argument("--weight_forward_file", default=None, help="overrides training.weight_forward_file")
+    ap.add_argument("--weight_backward_file", default=None, help="overrides training.weight_backward_file")
     ap.add_argument("--continue_from_epoch", default=0, type=int)
     ap.add_argument("--seed", type=int, default=27)
     ap.add_argument("--synthetic", type=int, default=4, help="procedural batches per epoch (no dataset readers yet)")
@@ -114,7 +128,14 @@ def main(argv=None):
     if args.epochs is not None:
         config["training"]["epochs"] = args.epochs
     os.makedirs(args.experiment_directory, exist_ok=True)
-    model, train_fn, val_fn, _ = build_model(config, args.weight_file, device=device)
+    weights = initial_weight_files(config, args)
+    for key, path in zip(("weight_file", "weight_forward_file", "weight_backward_file"), weights):
+        if path is not None:
+            print("initialising from {} = {}".format(key, path))
+    if config["model"]["type"] == "arbitrary" and weights[1] is None and weights[2] is None and weights[0] is None:
+        print("WARNING: FlowArbitrary starts from random weights (no weight_forward_file / weight_backward_file in the "
+              "config's training section or on the command line)")
+    model, train_fn, val_fn, _ = build_model(config, *weights, device=device)
     lr_scheduler, optimizer = optimizer_factory(config["training"], model.parameters())
     train = SyntheticLoader(args.seed, args.synthetic, args.batch)
     val = SyntheticLoader(args.seed + 10000, max(1, args.synthetic // 4), args.batch)

@@ -1,5 +1,6 @@
 """One tiny forward+backward of the TDNet hot path on the GPU, checked against the CPU oracle
-(called from __graft_entry__.smoke(); imports the oracle as the checker only)."""
+(called from __graft_entry__.smoke(); imports the oracle as the checker only).  Lives at the repo root, NOT inside the
+product package: nothing under nsdp_amd/ may import oracle/ (tests/test_no_oracle_in_product.py)."""
 from __future__ import annotations
 
 import copy

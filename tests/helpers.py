@@ -55,7 +55,7 @@ def sample_flat(t, n):
     f = t.detach().reshape(-1).cpu()
     if f.numel() <= n:
         return f.numpy()
-    return f[torch.linspace(0, f.numel() - 1, n).long()].numpy()
+    return f[torch.linspace(0, f.numel() - 1, n).long().clamp_(max=f.numel() - 1)].numpy()   # (as oracle/make_golden.py)
 
 
 def l2_err(a, b):

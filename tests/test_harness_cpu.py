@@ -115,3 +115,31 @@ def test_dataset_contract_oracle_matches_reference_vectors():
     assert np.array_equal(out["surface_samples_src"], fx["src_noise"])          # same RNG stream as the reference's call
     assert out["surface_samples_inputs"].shape == (300, 7) and out["surface_samples_inputs"].dtype == np.float32
     assert np.array_equal(out["surface_samples_inputs"][:, 6] > 0, fx["mask"])
+
+
+def test_initial_weight_files_come_from_the_config_like_the_reference():
+    """Reference train.py:140-146 reads the three weight files from config['training']; the CLI may override each."""
+    cfg = {"training": {"weight_forward_file": "fwd.pt", "weight_backward_file": "bwd.pt"}}
+    assert train.initial_weight_files(cfg) == (None, "fwd.pt", "bwd.pt")
+    args = argparse.Namespace(weight_file="w.pt", weight_forward_file=None, weight_backward_file="other.pt")
+    assert train.initial_weight_files(cfg, args) == ("w.pt", "fwd.pt", "other.pt")
+    assert train.initial_weight_files({"training": {}}) == (None, None, None)
+
+
+def test_main_passes_all_three_weight_files_to_build_model(tmp_path, monkeypatch):
+    import yaml
+    seen = {}
+
+    def fake_build(config, weight_file=None, weight_forward_file=None, weight_backward_file=None, device="cpu"):
+        seen["args"] = (weight_file, weight_forward_file, weight_backward_file)
+        raise SystemExit(0)                      # nothing below build_model matters for this test
+    monkeypatch.setattr(train, "build_model", fake_build)
+    cfg = {"model": {"type": "arbitrary"}, "training": {"weight_forward_file": "F", "weight_backward_file": "B"},
+           "validation": {}}
+    path = tmp_path / "c.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    try:
+        train.main([str(path), str(tmp_path / "exp")])
+    except SystemExit:
+        pass
+    assert seen["args"] == (None, "F", "B")

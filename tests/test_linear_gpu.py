@@ -249,3 +249,67 @@ def test_retained_graph_across_an_optimizer_step_fails_loudly():
     fwd()                            # next rebuild rewrites the buffers `old` saved
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         old.backward()
+
+
+def _layer(seed=0, n=64, k=128):
+    torch.manual_seed(seed)
+    lin = torch.nn.Linear(k, n).to(DEV)
+    x = torch.randn(4096, k, device=DEV, requires_grad=True)
+    return lin, x
+
+
+def test_param_gradients_reach_hooks_and_autograd_grad():
+    """Direct publication of weight gradients (params=True) bypasses autograd; anything that observes gradients through
+    autograd must still work: a tensor hook / post-accumulate-grad hook switches the layer to the autograd path, and
+    `autograd_param_grads()` does the same for torch.autograd.grad / backward(inputs=...)."""
+    from nsdp_amd import hip_linear
+    lin, x = _layer()
+    ref_y = F.linear(x, lin.weight, lin.bias)
+    gw_ref, gb_ref = torch.autograd.grad(ref_y.square().sum(), [lin.weight, lin.bias])
+    # default: published straight into .grad
+    hip_linear.linear(x, lin.weight, lin.bias, params=True).square().sum().backward()
+    assert torch.allclose(lin.weight.grad, gw_ref, rtol=1e-4, atol=1e-3)
+    lin.zero_grad()
+    # tensor hook on the weight: must fire, with the right gradient
+    fired = []
+    h = lin.weight.register_hook(lambda g: fired.append(g.clone()))
+    hip_linear.linear(x, lin.weight, lin.bias, params=True).square().sum().backward()
+    h.remove()
+    assert len(fired) == 1 and torch.allclose(fired[0], gw_ref, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(lin.weight.grad, gw_ref, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(lin.bias.grad, gb_ref, rtol=1e-4, atol=1e-3)
+    lin.zero_grad()
+    # post-accumulate-grad hook (what DDP / FSDP use)
+    fired = []
+    h = lin.bias.register_post_accumulate_grad_hook(lambda p: fired.append(p.grad.clone()))
+    hip_linear.linear(x, lin.weight, lin.bias, params=True).square().sum().backward()
+    h.remove()
+    assert len(fired) == 1 and torch.allclose(fired[0], gb_ref, rtol=1e-4, atol=1e-3)
+    lin.zero_grad()
+    # torch.autograd.grad on parameters: inside the context manager it returns them and leaves .grad alone
+    with hip_linear.autograd_param_grads():
+        y = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+        gw, gb = torch.autograd.grad(y.square().sum(), [lin.weight, lin.bias])
+    assert torch.allclose(gw, gw_ref, rtol=1e-4, atol=1e-3) and torch.allclose(gb, gb_ref, rtol=1e-4, atol=1e-3)
+    assert lin.weight.grad is None and lin.bias.grad is None
+
+
+def test_no_grad_forward_reuses_the_weight_pack():
+    """Eval / no_grad forwards must hit the per-parameter pack cache (one pack kernel per layer per model lifetime, not
+    per call) and still see weight updates."""
+    from nsdp_amd import hip_linear
+    lin, x = _layer(1)
+    calls = []
+    orig = hip_linear.pack_weight
+    hip_linear.pack_weight = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            y0 = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+            y1 = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+            assert len(calls) == 1 and torch.equal(y0, y1)
+            lin.weight.mul_(2.0)                         # in-place edit: version counter moves -> repack
+            y2 = hip_linear.linear(x, lin.weight, lin.bias, params=True)
+        assert len(calls) == 2
+        assert torch.allclose(y2, F.linear(x, lin.weight, lin.bias), rtol=1e-4, atol=1e-4)
+    finally:
+        hip_linear.pack_weight = orig

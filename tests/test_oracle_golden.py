@@ -48,7 +48,7 @@ def _sample_flat(t, n):
     f = t.detach().reshape(-1)
     if f.numel() <= n:
         return f.numpy()
-    return f[torch.linspace(0, f.numel() - 1, n).long()].numpy()
+    return f[torch.linspace(0, f.numel() - 1, n).long().clamp_(max=f.numel() - 1)].numpy()
 
 
 @pytest.mark.parametrize("mtype", ["forward", "backward", "arbitrary"])

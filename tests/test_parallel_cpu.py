@@ -94,3 +94,121 @@ def test_flat_bucket_layout_for_tdnet():
     assert red.nbytes == 4492267 * 4
     assert red.named[0][0].startswith("decoder.") and red.named[-1][0].startswith("encoder.")
     assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for (_, p), v in zip(red.named, red.views))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The product's dense layers do NOT return weight gradients through autograd: hip_linear publishes them to
+# `param.grad` itself -- immediately inside backward (small batches) or from an end-of-backward engine callback after the
+# side stream joined (large batches): `param.grad = g` when there is none, `param.grad.add_(g)` otherwise.  The mock
+# below reproduces exactly that publication protocol on CPU (same statements as hip_linear._LinearFn.backward /
+# hip_linear._publish), so the interplay with the flat bucket is tested at world size 2 without a GPU.
+# ---------------------------------------------------------------------------------------------------------
+class _DirectLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, w_param, b_param, deferred):
+        ctx.save_for_backward(x, w)
+        ctx.w_param, ctx.b_param, ctx.deferred = w_param, b_param, deferred
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        gw, gb = dy.t() @ x, dy.sum(0)
+
+        def publish():
+            with torch.no_grad():
+                for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
+                    prm.grad = g if prm.grad is None else prm.grad.add_(g)
+        if ctx.deferred:
+            torch.autograd.Variable._execution_engine.queue_callback(publish)
+        else:
+            publish()
+        return dy @ w, None, None, None, None, None
+
+
+class _DirectToy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.ModuleDict({"lin": torch.nn.Linear(5, 4)})
+        self.decoder = torch.nn.ModuleDict({"lin": torch.nn.Linear(4, 2)})
+
+    def forward(self, x, direct=True):
+        e, d = self.encoder["lin"], self.decoder["lin"]
+        if not direct:
+            return d(torch.tanh(e(x)))
+        h = torch.tanh(_DirectLinearFn.apply(x, e.weight.detach(), e.bias.detach(), e.weight, e.bias, True))
+        return _DirectLinearFn.apply(h, d.weight.detach(), d.bias.detach(), d.weight, d.bias, False)
+
+
+def _train_on_batch(model, optimizer, data, config):
+    """Shape of the reference's train_on_batch_with_cano: its own optimizer.zero_grad() (set_to_none) included."""
+    optimizer.zero_grad()
+    loss = ((model(data["x"]) - data["y"]) ** 2).mean()
+    loss.backward()
+    optimizer.step()
+    return loss.item()
+
+
+def _worker_direct(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nsdp_amd.parallel import GradAllReducer, data_parallel_step
+        g = torch.Generator().manual_seed(7)
+        x_all, y_all = torch.randn(world * 6, 5, generator=g), torch.randn(world * 6, 2, generator=g)
+        data = {"x": x_all[rank * 6:(rank + 1) * 6], "y": y_all[rank * 6:(rank + 1) * 6]}
+        torch.manual_seed(0)
+        ref = _DirectToy()
+        ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+        for _ in range(3):
+            ropt.zero_grad()
+            ((ref(x_all, direct=False) - y_all) ** 2).mean().backward()
+            ropt.step()
+        errs = {}
+        # (a) reducer.zero_grad() protocol: direct publication adds into the attached flat views
+        torch.manual_seed(0)
+        model = _DirectToy()
+        red = GradAllReducer(model, world)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        for _ in range(3):
+            red.zero_grad()
+            ((model(data["x"]) - data["y"]) ** 2).mean().backward()
+            assert red.adopt_grads() == 0                 # nothing strayed from the flat buffer
+            red.all_reduce_mean()
+            opt.step()
+        errs["views"] = max(float((a - b).abs().max()) for a, b in zip(model.parameters(), ref.parameters()))
+        # (b) the shipped step functions call optimizer.zero_grad() (grads -> None): wrapped, they must still reduce
+        torch.manual_seed(0)
+        model = _DirectToy()
+        red = GradAllReducer(model, world)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        step = data_parallel_step(_train_on_batch, red)
+        for _ in range(3):
+            step(model, opt, data, None)
+        errs["wrapped"] = max(float((a - b).abs().max()) for a, b in zip(model.parameters(), ref.parameters()))
+        assert not opt._optimizer_step_pre_hooks           # the wrapper removes its hook
+        # (c) stale-buffer hazard: without re-attachment the flat buffer would still hold the previous step
+        opt.zero_grad()
+        ((model(data["x"]) - data["y"]) ** 2).mean().backward()
+        assert all(p.grad.data_ptr() != v.data_ptr() for (_, p), v in zip(red.named, red.views))
+        assert red.adopt_grads() == len(red.named)
+        assert all(p.grad.data_ptr() == v.data_ptr() for (_, p), v in zip(red.named, red.views))
+        out.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_direct_grad_publication_with_flat_bucket_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, errs in res:
+        assert errs["views"] < 1e-6 and errs["wrapped"] < 1e-6, (rank, errs)
