@@ -185,6 +185,10 @@ def main():
                     "to exercise the multi-rank code path on a single GPU)")
     ap.add_argument("--force-reducer", action="store_true",
                     help="use the flat-bucket gradient path even at world size 1 (exercises the DP code on one GPU)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage precision of the activations: f32 (default; dense layers as error-compensated bf16x3 "
+                         "products, fp32 accuracy) | bf16 (BASELINE config 3: bf16 activations and saved tensors, fp32 "
+                         "accumulation, fp32 master weights)")
     ap.add_argument("--stub-step", action="store_true",
                     help="replace the TDNet step by a tiny CPU model (tests of the launch / rendezvous / all-reduce / "
                          "timing / JSON plumbing on a box without GPUs; the line says so and is not a measurement)")
@@ -217,8 +221,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from nsdp_amd import profiling, synth
+    from nsdp_amd import precision, profiling, synth
     from nsdp_amd.model import build_model, optimizer_factory
+    precision.set_storage(args.dtype)
     from nsdp_amd.parallel import GradAllReducer
     from nsdp_amd.model.utils import compute_l2_error
 
@@ -359,11 +364,13 @@ def main():
             "metric": names[0],
             "value": round(value, 1), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{names[1]}, "
                                    f"{args.batch} shapes/GPU, {N_SURF} surface + {n_query} query points per shape, "
-                                   "fp32, procedural random-init weights",
+                                   + ("fp32 (dense layers as bf16x3 split products)" if args.dtype == "f32" else
+                                      "bf16 storage / fp32 accumulate / fp32 master weights")
+                                   + ", procedural random-init weights",
                        "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1),

@@ -174,6 +174,27 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
                                  size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * bf16-STORAGE dense layers (BASELINE config 3: flow_arbitrary.py:30-48 step with activations and saved tensors in
+ * bf16, fp32 accumulation, fp32 master weights / weight gradients).  Same layer contract as nsdp_linear_f32 /
+ * nsdp_linear_wgrad_f32 with X, residual, mask, out_mask, dY (and Y unless out_f32) as bf16 tensors; one bf16 MFMA
+ * product per multiply-add.  csrc/gemm_bf16.hip.
+ *   Wp  [ceil(K/32)][ceil(N/16)][lane 16 g + i][8 bf16] = W[chan(nt, i)][32 kb + 8 g + j]
+ *   WpT [ceil(N/32)][ceil(K/16)][lane][8]               = W[32 nb + 8 g + j][chan(tk, i)]
+ *   chan(t, i) = 32 (t / 2) + 8 (i / 4) + 4 (t % 2) + i % 4 for paired tiles (16 t + i for an unpaired last tile): the
+ *   eight accumulator values a lane holds for one row are eight consecutive channels -> 16-byte bf16 stores.
+ * nsdp_pack_weights_bf16 takes the NsdpPackDesc array of nsdp_pack_weights_batched (`kind` ignored).
+ * Shapes: K % 8 == 0, 8 <= K <= 256, N <= 256, N % 4 == 0 (any N with out_f32); wgrad: N, K even, <= 256. */
+long long nsdp_packed_weight_bf16_bytes(int N, int K, int transposed);
+int nsdp_pack_weights_bf16(const NsdpPackDesc *descs, int count, void *stream);
+int nsdp_linear_bf16(const void *X, const void *Wp, const float *bias, const void *residual, const void *mask,
+                     const void *out_mask, void *Y, long long M, int N, int K, int relu_in, int relu_out, int out_f32,
+                     void *stream);
+size_t nsdp_linear_wgrad_bf16_workspace_bytes(long long M, int N, int K);
+int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
+                           long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                           void *stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Point-Transformer vector attention glue (everything between the dense layers of one block), replacing
  * the materialised ATen gather / sub / add / softmax / einsum sequence of model/encoder/blocks.py:104-124,
  * :290-308 and model/decoder/blocks.py:72-91.  Channels-last fp32, d <= 256:

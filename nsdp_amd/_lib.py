@@ -83,6 +83,16 @@ def fptr(t: torch.Tensor, name: str = "tensor") -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr())
 
 
+def hptr(t: torch.Tensor, name: str = "tensor") -> ctypes.c_void_p:
+    """bf16 tensor (the storage precision of BASELINE config 3)."""
+    _require(t, name, torch.bfloat16)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def opthptr(t, name: str = "tensor"):
+    return ctypes.c_void_p(0) if t is None else hptr(t, name)
+
+
 def iptr(t: torch.Tensor, name: str = "tensor") -> ctypes.c_void_p:
     _require(t, name, torch.int32)
     return ctypes.c_void_p(t.data_ptr())

@@ -51,7 +51,8 @@ const char *kind_name(int kind) {
   static const char *names[kNumKinds] = {"linear_nt_kernel",  "linear_wgrad_kernel", "fps_kernel",
                                          "knn_kernel",        "gather_rows_kernel",  "scatter_add_rows_kernel",
                                          "attn_fwd_kernels",  "attn_bwd_kernels",    "batch_norm_kernels",
-                                         "decoder_fwd_kernel", "linear_bf16x3_kernel", "wgrad_bf16x3_kernel"};
+                                         "decoder_fwd_kernel", "linear_bf16x3_kernel", "wgrad_bf16x3_kernel",
+                                         "linear_bf16_kernel", "wgrad_bf16_kernel"};
   return (kind >= 0 && kind < kNumKinds) ? names[kind] : "?";
 }
 

@@ -19,6 +19,8 @@ enum Kind {
   kDecoderFwd,   // fused decoder forward
   kLinearX3,     // linear_bf16x3_kernel (bf16 MFMA, 3-way split, 6 products per fp32 product)
   kWgradX3,      // wgrad_bf16x3_kernel + its reduce
+  kLinearB16,    // linear_bf16_kernel (bf16 storage, one bf16 MFMA product)
+  kWgradB16,     // wgrad_bf16_kernel + its reduce
   kNumKinds
 };
 

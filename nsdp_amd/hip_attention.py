@@ -111,9 +111,20 @@ def pos_grad_link():
     return _PosGrad()
 
 
+NATIVE_BF16 = False       # bf16-storage kernels present (otherwise the calls below cast around the fp32 ones)
+
+
+def _f(t):
+    return None if t is None else (t if t.dtype is torch.float32 else t.float())
+
+
 def attn_pre(q, kf, pos, idx, link=None):
+    if pos.dtype is torch.bfloat16 and not NATIVE_BF16:
+        return _AttnPre.apply(_f(q), _f(kf), _f(pos), idx, link).to(torch.bfloat16)
     return _AttnPre.apply(q, kf, pos, idx, link)
 
 
 def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None):
+    if a.dtype is torch.bfloat16 and not NATIVE_BF16:
+        return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link).to(torch.bfloat16)
     return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link)

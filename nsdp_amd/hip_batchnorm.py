@@ -9,6 +9,7 @@ import torch
 
 from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
 
+NATIVE_BF16 = False       # bf16-storage kernels present (otherwise ops.batch_norm casts around the fp32 ones)
 _ll = ctypes.c_longlong
 _ci = ctypes.c_int
 _cf = ctypes.c_float

@@ -14,6 +14,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
+from . import precision
 from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
 
 _ll = ctypes.c_longlong
@@ -194,7 +195,8 @@ def _use_side_stream(dy2):
     return use
 
 
-def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param):
+def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
+    """``fn``: weight-gradient routine (dy2, x2, mask, relu_x, want_db) -> (dw, db) of another storage precision."""
     dev = dy2.device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
@@ -205,7 +207,10 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param):
         slot = _pending[key] = {}
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
     with torch.cuda.stream(side):      # everything that touches dw/db before the join stays on `side`
-        dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig)
+        if fn is None:
+            dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig)
+        else:
+            dw, db = fn(dy2, x2, mask, relu_x, b_param is not None)
         for param, g in ((w_param, dw), (b_param, db)):
             if param is None:
                 continue
@@ -282,7 +287,8 @@ def _repack_all(device):
     for k in dead:
         del ents[k]
         reg["array"] = None
-    live = list(ents.values())
+    live = sorted(ents.values(), key=lambda e: e[1] == "b16")      # fp32 / bf16x3 packs first, then the bf16 ones
+    n_b16 = sum(1 for e in live if e[1] == "b16")
     if reg["array"] is None or len(reg["array"]) != len(live):
         reg["array"] = (_PackDesc * len(live))()
     arr = reg["array"]
@@ -294,9 +300,14 @@ def _repack_all(device):
             return False
         d = arr[i]
         d.W, d.Wp, d.WpT = w.data_ptr(), (wp.data_ptr() if wp is not None else None), (wpt.data_ptr() if wpt is not None else None)
-        d.N, d.K, d.kind = w.shape[0], w.shape[1], 1 if kind == "x3" else 0
+        d.N, d.K, d.kind = w.shape[0], w.shape[1], {"wp": 0, "x3": 1, "b16": 2}[kind]
     with torch.cuda.device(device):
-        check(lib().nsdp_pack_weights_batched(arr, _ci(len(live)), stream_ptr()), "nsdp_pack_weights_batched")
+        n_f = len(live) - n_b16
+        if n_f:
+            check(lib().nsdp_pack_weights_batched(arr, _ci(n_f), stream_ptr()), "nsdp_pack_weights_batched")
+        if n_b16:
+            tail = ctypes.cast(ctypes.byref(arr, n_f * ctypes.sizeof(_PackDesc)), ctypes.POINTER(_PackDesc))
+            check(lib().nsdp_pack_weights_bf16(tail, _ci(n_b16), stream_ptr()), "nsdp_pack_weights_bf16")
     # the buffers were rewritten in place behind autograd's back: bump their version counters, so that a graph retained
     # from before the optimizer step (it saved a W^T pack for its dX) fails loudly instead of using the new weights
     torch.autograd.graph.increment_version([t for e in live for t in e[2:4] if t is not None])
@@ -333,7 +344,11 @@ def _packs(w, owner, kind, want_t):
         if ent is not None and (ent[1] is not None or not want_t):
             return ent
     wc = w if w.is_contiguous() else w.contiguous()
-    ent = pack_weight_x3(wc, True, want_t) if kind == "x3" else pack_weight(wc, True, want_t)
+    if kind == "b16":
+        from .hip_linear_bf16 import pack_weight_b16
+        ent = pack_weight_b16(wc, True, want_t)
+    else:
+        ent = pack_weight_x3(wc, True, want_t) if kind == "x3" else pack_weight(wc, True, want_t)
     if cache is not None:
         cache[kind] = ent
         if wc is w:
@@ -466,10 +481,12 @@ def _observed(t):
     return bool(t._backward_hooks) or bool(getattr(t, "_post_accumulate_grad_hooks", None))
 
 
-def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None):
+def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
+           out_f32=False):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
-    ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``."""
+    ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
+    ``out_f32``: with bf16 storage (nsdp_amd.precision) this layer's output stays fp32 (the network output)."""
     w_param = b_param = None
     if (params and _PARAM_GRADS_DIRECT and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf
             and not _observed(weight)):
@@ -481,6 +498,24 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # the pack cache lives on the layer's leaf parameter whether or not gradients are being recorded (eval / no_grad
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
+    if precision.is_bf16():
+        from . import hip_linear_bf16 as hb
+        K, N = x.shape[-1], w2.shape[0]
+        if x.dtype is torch.bfloat16 and 8 <= K <= 256 and K % 8 == 0 and N <= 256 and (out_f32 or N % 4 == 0):
+            if residual is not None and residual.dtype is not torch.bfloat16:
+                residual = residual.to(torch.bfloat16)
+            return hb.linear(x, weight, bias, relu_in, relu_out, residual, w_param, b_param, grad_sum, owner, out_f32)
+        # the narrow ends of the network (3-wide coordinate inputs, ...): fp32 kernels, result rounded to the storage type
+        if grad_sum is not None:
+            raise ValueError("InputGradSum needs a bf16 layer in bf16 storage mode")
+        xf = x if x.dtype is torch.float32 else x.float()
+        rf = residual if (residual is None or residual.dtype is torch.float32) else residual.float()
+        if w_param is not None:
+            y = _LinearFn.apply(xf, w2.detach(), None if bias is None else bias.detach(), rf, bool(relu_in),
+                                bool(relu_out), w_param, b_param, None)
+        else:
+            y = _LinearFn.apply(xf, w2, bias, rf, bool(relu_in), bool(relu_out), None, None, None, owner)
+        return y if out_f32 else y.to(torch.bfloat16)
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),

@@ -6,6 +6,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ... import precision
 
 
 class CrossTransformerBlock(nn.Module):
@@ -60,6 +61,9 @@ class ResnetBlockFC(nn.Module):
         nn.init.zeros_(self.fc_1.weight)
 
     def forward(self, x):
-        h = ops.linear(x, self.fc_0, relu_in=True, relu=True)             # relu(fc_0(relu(x)))
         x_s = x if self.shortcut is None else ops.linear(x, self.shortcut)
+        if precision.is_bf16():        # (see ops.mlp2: the inner ReLU as fc_1's input ReLU -- no mask streams in backward)
+            h = ops.linear(x, self.fc_0, relu_in=True)
+            return ops.linear(h, self.fc_1, relu_in=True, residual=x_s)
+        h = ops.linear(x, self.fc_0, relu_in=True, relu=True)             # relu(fc_0(relu(x)))
         return ops.linear(h, self.fc_1, residual=x_s)                     # x_s + fc_1(h), fused epilogue

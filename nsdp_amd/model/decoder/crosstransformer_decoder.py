@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ... import hip_decoder, hip_linear
+from ... import hip_decoder, hip_linear, precision
 from .blocks import CrossTransformerBlock, ResnetBlockFC
 
 
@@ -24,7 +24,8 @@ class CrossTransformerDecoder(nn.Module):
         self.fc_out = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, xyz_q, encoding):
-        if hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self):
+        if (hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self)
+                and not precision.is_bf16()):
             # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
             return hip_decoder.decoder_forward(self, xyz_q, encoding)
         lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
@@ -34,4 +35,4 @@ class CrossTransformerDecoder(nn.Module):
         for i in range(self.n_blocks):
             net = ops.linear(lat, self.fc_c[i], residual=net, grad_sum=fan)   # net + fc_c[i](lat)
             net = self.blocks[i](net)
-        return ops.linear(net, self.fc_out, relu_in=True)                 # fc_out(relu(net))
+        return ops.linear(net, self.fc_out, relu_in=True, out_f32=True)   # fc_out(relu(net)); fp32 in every storage mode

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import hip_attention, hip_batchnorm, hip_linear
+from .. import hip_attention, hip_batchnorm, hip_linear, precision
 from .. import pointnet2_utils as pu
 
 
@@ -83,7 +83,12 @@ class _GatherRows(torch.autograd.Function):
         flat = idx.reshape(B, -1)
         ctx.save_for_backward(flat)
         ctx.n = N
-        out = pu.gather_rows(points.contiguous(), flat)
+        points = points.contiguous()
+        if points.dtype is torch.bfloat16 and C % 2 == 0:
+            # a row gather moves bytes: bf16 rows of C channels are fp32 rows of C / 2 words
+            out = pu.gather_rows(points.view(torch.float32), flat).view(torch.bfloat16)
+        else:
+            out = pu.gather_rows(points.float(), flat).to(points.dtype)
         return out.reshape(*idx.shape, C)
 
     @staticmethod
@@ -91,6 +96,8 @@ class _GatherRows(torch.autograd.Function):
         (flat,) = ctx.saved_tensors
         B = flat.shape[0]
         g = grad_out.reshape(B, flat.shape[1], -1).contiguous()
+        if g.dtype is torch.bfloat16:      # the scatter accumulates in fp32 (a point is gathered up to k times)
+            return pu.scatter_add_rows(g.float(), flat, ctx.n).to(torch.bfloat16), None
         return pu.scatter_add_rows(g, flat, ctx.n), None
 
 
@@ -101,16 +108,24 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # dense layers
 # ---------------------------------------------------------------------------------------------
-def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None) -> torch.Tensor:
+def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
+           out_f32: bool = False) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
-                             params=True, grad_sum=grad_sum)
+                             params=True, grad_sum=grad_sum, out_f32=out_f32)
 
 
 def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
-    """nn.Sequential(Linear, ReLU, Linear) (fc_delta / fc_gamma / fc_middle)."""
+    """nn.Sequential(Linear, ReLU, Linear) (fc_delta / fc_gamma / fc_middle).
+    bf16 storage: the ReLU is the SECOND layer's fused input ReLU (the tensor in between holds the pre-activation): same
+    values, but in the backward pass the second layer's dX epilogue applies the ReLU mask once, and neither the first
+    layer's dX kernel nor its weight gradient has to stream a mask tensor next to dY (those kernels are pure streams).
+    fp32 storage keeps the ReLU in the first layer's epilogue: the bf16x3 GEMM's ReLU prologue costs more than the mask
+    operand it saves (measured: +1.9 ms of GEMM time per B = 32 step against -1.2 ms of weight-gradient time)."""
+    if precision.is_bf16():
+        return linear(linear(x, seq[0]), seq[2], relu_in=True)
     return linear(linear(x, seq[0], relu=True), seq[2])
 
 
@@ -118,6 +133,9 @@ def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = Fa
     """relu?( BatchNorm1d(x + addend) ) over the (B*n) rows of a channels-last tensor: batch statistics +
     running update when training, running statistics in eval.  The residual add in front and the ReLU
     behind are fused into the HIP kernels (hip_batchnorm)."""
+    if x.dtype is torch.bfloat16 and not hip_batchnorm.NATIVE_BF16:
+        a = None if addend is None else addend.float()
+        return hip_batchnorm.batch_norm(x.float(), bn, addend=a, relu=relu).to(torch.bfloat16)
     return hip_batchnorm.batch_norm(x, bn, addend=addend, relu=relu)
 
 
