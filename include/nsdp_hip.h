@@ -173,6 +173,21 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
                                  float *db, long long M, int N, int K, int accumulate, float *workspace,
                                  size_t workspace_bytes, void *stream);
 
+/* bf16-storage variants of the attention glue (csrc/attention.hip, same kernels instantiated for a bf16 storage type):
+ * q, kf, vf, pos, u, a, y, residual, a_g, v_g and the activation gradients du, dy, da, dpos, dpos_acc are bf16 tensors;
+ * lse and the scatter / reduction outputs dq, dkf, dvf, da_g, dv_g are fp32.  Arithmetic is fp32 throughout. */
+int nsdp_attn_pre_fwd_bf16(const void *q, const void *kf, const void *pos, const int32_t *idx, int B, int n, int N, int k,
+                           int d, int q_per_shape, void *u, void *stream);
+int nsdp_attn_pre_bwd_bf16(const void *du, const int32_t *idx, int B, int n, int N, int k, int d, int q_per_shape,
+                           float *dq, float *dkf, void *dpos_acc, void *stream);
+int nsdp_attn_post_fwd_bf16(const void *a, const void *vf, const void *pos, const int32_t *idx, const void *a_g,
+                            const void *v_g, const void *residual, int B, int n, int N, int k, int d, void *y, float *lse,
+                            void *stream);
+int nsdp_attn_post_bwd_bf16(const void *dy, const void *a, const void *vf, const void *pos, const int32_t *idx,
+                            const void *a_g, const void *v_g, const void *y, const void *residual, const float *lse, int B,
+                            int n, int N, int k, int d, void *da, void *dpos, float *dvf, float *da_g, float *dv_g,
+                            void *stream);
+
 /* ----------------------------------------------------------------------------------------------
  * bf16-STORAGE dense layers (BASELINE config 3: flow_arbitrary.py:30-48 step with activations and saved tensors in
  * bf16, fp32 accumulation, fp32 master weights / weight gradients).  Same layer contract as nsdp_linear_f32 /
@@ -193,6 +208,24 @@ size_t nsdp_linear_wgrad_bf16_workspace_bytes(long long M, int N, int K);
 int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
                            long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                            void *stream);
+
+/* bf16-storage variants of the BatchNorm kernels (x, addend, y, dy, dx bf16; statistics and affine parameters fp32). */
+int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
+                       float *running_mean, float *running_var, float *mean, float *invstd, float *workspace, void *stream);
+int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
+                       const float *beta, long long R, int C, int relu, void *y, void *stream);
+int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, const void *addend, const float *mean,
+                          const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
+                          float *dgamma, float *dbeta, float *workspace, void *stream);
+
+/* K = 4 layers with bf16 storage (first layer of every position-encoding MLP: fp32 relative coordinates zero-padded
+ * to 4 columns in, bf16 out; csrc/k4_bf16.hip).  W is the plain [N,4] fp32 matrix.  N % 8 == 0.
+ * dX of such a layer is an nsdp_linear_bf16 call with 4 outputs. */
+int nsdp_linear_k4_bf16(const float *X, const float *W, const float *bias, void *Y, long long M, int N, int relu_out,
+                        void *stream);
+size_t nsdp_linear_wgrad_k4_bf16_workspace_bytes(long long M, int N);
+int nsdp_linear_wgrad_k4_bf16(const void *dY, const float *X, const void *mask, float *dW, float *db, long long M, int N,
+                              float *workspace, size_t workspace_bytes, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Point-Transformer vector attention glue (everything between the dense layers of one block), replacing

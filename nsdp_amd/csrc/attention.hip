@@ -60,11 +60,39 @@ __device__ __forceinline__ Lane lane_setup(const AttnShape &s) {
 struct Quad {
   float x, y, z, w;
 };
+
+// Storage type of the activation tensors: float, or bf16 (BASELINE config 3: bf16 storage, all arithmetic in fp32).
+// Every accessor below exists for both; scatter targets (dkf, dvf, dq, global-token gradients) and the log-sum-exp
+// are fp32 in either mode.
+struct bf16_t {
+  unsigned short v;
+};
+__device__ __forceinline__ float b2f(unsigned short h) { return __builtin_bit_cast(float, static_cast<unsigned>(h) << 16); }
+__device__ __forceinline__ unsigned short f2b(float f) {          // round to nearest even
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  return static_cast<unsigned short>(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{f, 0.f}, bf16x2)) & 0xffffu);
+}
+__device__ __forceinline__ unsigned f2b2(float a, float b) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ float ldf(const float *p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t *p) { return b2f(p->v); }
+__device__ __forceinline__ void stf(float *p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t *p, float v) { p->v = f2b(v); }
 __device__ __forceinline__ Quad ldq(const float *row, int cq, int lpp) {
   return Quad{row[cq], row[cq + lpp], row[cq + 2 * lpp], row[cq + 3 * lpp]};
 }
 __device__ __forceinline__ void stq(float *row, int cq, int lpp, Quad v) {
   row[cq] = v.x; row[cq + lpp] = v.y; row[cq + 2 * lpp] = v.z; row[cq + 3 * lpp] = v.w;
+}
+__device__ __forceinline__ Quad ldq(const bf16_t *row, int cq, int lpp) {
+  return Quad{b2f(row[cq].v), b2f(row[cq + lpp].v), b2f(row[cq + 2 * lpp].v), b2f(row[cq + 3 * lpp].v)};
+}
+__device__ __forceinline__ void stq(bf16_t *row, int cq, int lpp, Quad v) {
+  row[cq].v = f2b(v.x); row[cq + lpp].v = f2b(v.y); row[cq + 2 * lpp].v = f2b(v.z); row[cq + 3 * lpp].v = f2b(v.w);
 }
 __device__ __forceinline__ void atomic_addq(float *row, int cq, int lpp, Quad v) {
   atomicAdd(row + cq, v.x); atomicAdd(row + cq + lpp, v.y);
@@ -72,16 +100,25 @@ __device__ __forceinline__ void atomic_addq(float *row, int cq, int lpp, Quad v)
 }
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16_t *p) {           // 4 channels = one 8-byte load
+  const uint2 r = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(bf16_t *p, float4 v) {
+  *reinterpret_cast<uint2 *>(p) = make_uint2(f2b2(v.x, v.y), f2b2(v.z, v.w));
+}
 __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
   atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
 }
 
 // u[b,i,j,c] = q[b,i,c] - kf[b,idx[b,i,j],c] + pos[b,i,j,c]
-__global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const float *__restrict__ q,
-                                                           const float *__restrict__ kf,
-                                                           const float *__restrict__ pos,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const T *__restrict__ q,
+                                                           const T *__restrict__ kf,
+                                                           const T *__restrict__ pos,
                                                            const int32_t *__restrict__ idx,
-                                                           float *__restrict__ u) {
+                                                           T *__restrict__ u) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const long long total = static_cast<long long>(s.B) * s.n;
@@ -90,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const fl
     if (pt >= total) return;
     const int b = static_cast<int>(pt / s.n);
     const float4 qv = ld4(q + (s.qb ? static_cast<long long>(b) : pt) * s.d + 4 * L.cq);
-    const float *kfb = kf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq;
+    const T *kfb = kf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq;
     const int32_t *ip = idx + pt * s.k;
     const long long e0 = pt * s.k * s.d + 4 * L.cq;
 #pragma unroll 4
@@ -104,10 +141,11 @@ __global__ __launch_bounds__(256) void attn_pre_fwd_kernel(AttnShape s, const fl
 }
 
 // dq[b,i,c] = sum_j du[b,i,j,c];  dkf[b,idx,c] -= du   (dkf / per-shape dq zero-filled by the host wrapper)
-__global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const float *__restrict__ du,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T *__restrict__ du,
                                                            const int32_t *__restrict__ idx,
                                                            float *__restrict__ dq, float *__restrict__ dkf,
-                                                           float *__restrict__ dpos_acc) {
+                                                           T *__restrict__ dpos_acc) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -120,8 +158,8 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const fl
     const int b = static_cast<int>(pt / s.n);
     float *dkfb = dkf + static_cast<long long>(b) * s.N * s.d;
     const int32_t *ip = idx + pt * s.k;
-    const float *dur = du + pt * s.k * s.d;
-    float *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
+    const T *dur = du + pt * s.k * s.d;
+    T *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
     Quad acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
@@ -129,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const fl
       acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
       atomic_addq(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
       if (par) {   // d(pos) += du while the row is in registers (saves the separate add kernel's re-read of du)
-        float *pr = par + static_cast<long long>(j) * s.d;
+        T *pr = par + static_cast<long long>(j) * s.d;
         const Quad o = ldq(pr, cq, lpp);
         stq(pr, cq, lpp, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
       }
@@ -160,15 +198,15 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const fl
 
 // y = sum_j softmax_j(a) (vf[idx] + pos) [+ w_g v_g] [+ residual];  lse = log-sum-exp of the logits.
 // HAS_V = false: pos_only block (values = pos).  a_g / v_g: per-shape global token (decoder) or NULL.
-template <bool HAS_V>
-__global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const float *__restrict__ a,
-                                                            const float *__restrict__ vf,
-                                                            const float *__restrict__ pos,
+template <typename T, bool HAS_V>
+__global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const T *__restrict__ a,
+                                                            const T *__restrict__ vf,
+                                                            const T *__restrict__ pos,
                                                             const int32_t *__restrict__ idx,
-                                                            const float *__restrict__ a_g,
-                                                            const float *__restrict__ v_g,
-                                                            const float *__restrict__ residual,
-                                                            float *__restrict__ y, float *__restrict__ lse) {
+                                                            const T *__restrict__ a_g,
+                                                            const T *__restrict__ v_g,
+                                                            const T *__restrict__ residual,
+                                                            T *__restrict__ y, float *__restrict__ lse) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const long long total = static_cast<long long>(s.B) * s.n;
@@ -177,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const f
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) return;
     const int b = static_cast<int>(pt / s.n);
-    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq : nullptr;
+    const T *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq : nullptr;
     const int32_t *ip = idx + pt * s.k;
     const long long e0 = pt * s.k * s.d + 4 * L.cq;
     float4 m, l, acc;
@@ -217,12 +255,12 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const f
 //   da_j = w_j dy (s_j - yb);  ds_j = w_j dy  (written to dpos, scattered into dvf)
 //   global token: da_g += sum_i w_g dy (v_g - yb), dv_g += sum_i w_g dy   (register partial sums over the
 //   wave's points, one atomic per lane and shape)
-template <bool HAS_V>
+template <typename T, bool HAS_V>
 __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
-    AttnShape s, const float *__restrict__ dy, const float *__restrict__ a, const float *__restrict__ vf,
-    const float *__restrict__ pos, const int32_t *__restrict__ idx, const float *__restrict__ a_g,
-    const float *__restrict__ v_g, const float *__restrict__ y, const float *__restrict__ residual,
-    const float *__restrict__ lse, float *__restrict__ da, float *__restrict__ dpos,
+    AttnShape s, const T *__restrict__ dy, const T *__restrict__ a, const T *__restrict__ vf,
+    const T *__restrict__ pos, const int32_t *__restrict__ idx, const T *__restrict__ a_g,
+    const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
+    const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos,
     float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     const long long pt = L.p0 + static_cast<long long>(it) * L.ppw + L.sub;
     if (pt >= total) break;
     const int b = static_cast<int>(pt / s.n);
-    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d : nullptr;
+    const T *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d : nullptr;
     float *dvfb = (HAS_V && dvf) ? dvf + static_cast<long long>(b) * s.N * s.d : nullptr;   // null: scatter done elsewhere
     const int32_t *ip = idx + pt * s.k;
     const long long r0 = pt * s.k * s.d;
@@ -306,6 +344,11 @@ __device__ __forceinline__ Quad ldc(const float *row, int cq) {
 __device__ __forceinline__ void stc(float *row, int cq, Quad v) {
   *reinterpret_cast<float4 *>(row + 4 * cq) = make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ Quad ldc(const bf16_t *row, int cq) {
+  const float4 v = ld4(row + 4 * cq);
+  return Quad{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void stc(bf16_t *row, int cq, Quad v) { st4(row + 4 * cq, make_float4(v.x, v.y, v.z, v.w)); }
 __device__ __forceinline__ void atomic_addc(float *row, int cq, Quad v) {
   atomicAdd(row + 4 * cq, v.x); atomicAdd(row + 4 * cq + 1, v.y);
   atomicAdd(row + 4 * cq + 2, v.z); atomicAdd(row + 4 * cq + 3, v.w);
@@ -336,11 +379,12 @@ __device__ __forceinline__ BlockLane block_lane_setup(const AttnShape &s) {
   return L;
 }
 
-__global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape s, const float *__restrict__ du,
+template <typename T>
+__global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape s, const T *__restrict__ du,
                                                                        const int32_t *__restrict__ idx,
                                                                        float *__restrict__ dq,
                                                                        float *__restrict__ dkf,
-                                                                       float *__restrict__ dpos_acc) {
+                                                                       T *__restrict__ dpos_acc) {
   extern __shared__ __attribute__((aligned(16))) float table[];  // [N][d] partial of -sum du
   const int b = blockIdx.y;
   const int tsz = s.N * s.d;
@@ -354,8 +398,8 @@ __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape
       const long long pt = L.p0 + static_cast<long long>(it) * L.stride + L.sub;
       if (pt >= L.pend) break;
       const int32_t *ip = idx + pt * s.k;
-      const float *dur = du + pt * s.k * s.d;
-      float *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
+      const T *dur = du + pt * s.k * s.d;
+      T *par = dpos_acc ? dpos_acc + pt * s.k * s.d : nullptr;
       Quad acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
       for (int j = 0; j < s.k; ++j) {
@@ -363,7 +407,7 @@ __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape
         acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
         atomic_addc(table + ip[j] * s.d, cq, Quad{-g.x, -g.y, -g.z, -g.w});
         if (par) {
-          float *pr = par + static_cast<long long>(j) * s.d;
+          T *pr = par + static_cast<long long>(j) * s.d;
           const Quad o = ldc(pr, cq);
           stc(pr, cq, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
         }
@@ -384,12 +428,12 @@ __global__ __launch_bounds__(kLdsThreads) void attn_pre_bwd_lds_kernel(AttnShape
   }
 }
 
-template <bool HAS_V>
+template <typename T, bool HAS_V>
 __global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
-    AttnShape s, const float *__restrict__ dy, const float *__restrict__ a, const float *__restrict__ vf,
-    const float *__restrict__ pos, const int32_t *__restrict__ idx, const float *__restrict__ a_g,
-    const float *__restrict__ v_g, const float *__restrict__ y, const float *__restrict__ residual,
-    const float *__restrict__ lse, float *__restrict__ da, float *__restrict__ dpos,
+    AttnShape s, const T *__restrict__ dy, const T *__restrict__ a, const T *__restrict__ vf,
+    const T *__restrict__ pos, const int32_t *__restrict__ idx, const T *__restrict__ a_g,
+    const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
+    const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos,
     float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
   extern __shared__ __attribute__((aligned(16))) float table[];  // [N][d] partial of dvf
   const int b = blockIdx.y;
@@ -402,7 +446,7 @@ __global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
   const int cq = L.cq;
   const bool has_g = a_g != nullptr;
   if (L.active) {
-    const float *vfb = HAS_V ? vf + static_cast<long long>(b) * tsz : nullptr;
+    const T *vfb = HAS_V ? vf + static_cast<long long>(b) * tsz : nullptr;
     Quad dag{0.f, 0.f, 0.f, 0.f}, dvg{0.f, 0.f, 0.f, 0.f};
     Quad ag{0.f, 0.f, 0.f, 0.f}, vg{0.f, 0.f, 0.f, 0.f};
     if (has_g) {
@@ -472,11 +516,11 @@ __global__ __launch_bounds__(kLdsThreads) void attn_post_bwd_lds_kernel(
 // ------------------------------------------------------------------------------------------------
 typedef float f32x32_t __attribute__((ext_vector_type(32)));
 
-template <int UNROLL>
-__global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *__restrict__ src,
+template <typename T, int UNROLL>
+__global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const T *__restrict__ src,
                                                                   const int32_t *__restrict__ idx,
                                                                   float *__restrict__ table, float *__restrict__ colsum,
-                                                                  float *__restrict__ acc_rows,
+                                                                  T *__restrict__ acc_rows,
                                                                   long long rows_per_shape, long long rows_per_wg, int N,
                                                                   int d, float sign, float colsum_sign) {
   f32x32_t t0 = {}, t1 = {}, t2 = {}, t3 = {};
@@ -486,8 +530,8 @@ __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *_
   long long end = begin + rows_per_wg;
   end = end < rows_per_shape ? end : rows_per_shape;
   const long long base = static_cast<long long>(b) * rows_per_shape;
-  const float *p = src + base * d + (cv ? c : 0);
-  float *pa = acc_rows ? acc_rows + base * d + (cv ? c : 0) : nullptr;      // acc_rows[row] += src[row] (optional)
+  const T *p = src + base * d + (cv ? c : 0);
+  T *pa = acc_rows ? acc_rows + base * d + (cv ? c : 0) : nullptr;      // acc_rows[row] += src[row] (optional)
   const int32_t *ip = idx + base;
   float total = 0.f;
   for (long long r = begin; r < end; r += UNROLL) {
@@ -496,15 +540,15 @@ __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *_
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const long long rr = r + u < end ? r + u : end - 1;          // clamped: the tail re-reads the last row, masked below
-      x[u] = p[rr * d];
-      y[u] = pa ? pa[rr * d] : 0.f;
+      x[u] = ldf(p + rr * d);
+      y[u] = pa ? ldf(pa + rr * d) : 0.f;
       a[u] = __builtin_amdgcn_readfirstlane(ip[rr]);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int i = a[u] & 31, g = a[u] >> 5;
       const float v = (cv && r + u < end) ? x[u] : 0.f;
-      if (pa && cv && r + u < end) pa[(r + u) * d] = y[u] + x[u];
+      if (pa && cv && r + u < end) stf(pa + (r + u) * d, y[u] + x[u]);
       total += v;
       t0[i] += g == 0 ? v : 0.f;
       t1[i] += g == 1 ? v : 0.f;
@@ -528,7 +572,8 @@ __global__ __launch_bounds__(256) void scatter_rows_regtab_kernel(const float *_
 inline bool regtab_fits(int N, int d, long long rows_per_shape) { return N <= 128 && d <= 256 && rows_per_shape >= 4096; }
 
 // table (zero-filled by the caller) += sign * scatter(src); colsum (zero-filled, may be null) += colsum_sign * sum_r src[r]
-inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *table, float *colsum, float *acc_rows,
+template <typename T>
+inline int launch_regtab_scatter(const T *src, const int32_t *idx, float *table, float *colsum, T *acc_rows,
                                  int B, long long rows_per_shape, int N, int d, float sign, float colsum_sign,
                                  hipStream_t st) {
   long long wgs = (4LL * nsdp::num_cus() + B - 1) / B;                 // ~4 workgroups per CU in total
@@ -537,7 +582,7 @@ inline int launch_regtab_scatter(const float *src, const int32_t *idx, float *ta
   per = (per + 7) / 8 * 8;
   wgs = (rows_per_shape + per - 1) / per;
   NSDP_TRACE("scatter_rows_regtab<8>");
-  hipLaunchKernelGGL((scatter_rows_regtab_kernel<8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
+  hipLaunchKernelGGL((scatter_rows_regtab_kernel<T, 8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
                      colsum, acc_rows, rows_per_shape, per, N, d, sign, colsum_sign);
   return nsdp::launch_status("scatter_rows_regtab_kernel");
 }
@@ -588,29 +633,33 @@ inline dim3 attn_grid(const AttnShape &s) {
 
 #define NSDP_ATTN_LAUNCH(KERNEL, ...) hipLaunchKernelGGL(KERNEL, attn_grid(s), dim3(256), 0, st, __VA_ARGS__)
 
-#define NSDP_ATTN_LAUNCH_V(KERNEL, HASV, ...)                                                   \
-  do {                                                                                          \
-    if (HASV) hipLaunchKernelGGL((KERNEL<true>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((KERNEL<false>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);      \
+#define NSDP_ATTN_LAUNCH_V(KERNEL, HASV, ...)                                                      \
+  do {                                                                                             \
+    if (HASV) hipLaunchKernelGGL((KERNEL<T, true>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERNEL<T, false>), attn_grid(s), dim3(256), 0, st, __VA_ARGS__);      \
   } while (0)
 
-extern "C" {
+namespace {
 
-int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
-                      int N, int k, int d, int q_per_shape, float *u, void *stream) {
+template <typename T>
+int attn_pre_fwd_t(const T *q, const T *kf, const T *pos, const int32_t *idx, int B, int n, int N, int k, int d,
+                   int q_per_shape, T *u, void *stream) {
+  constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_pre_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(q && kf && pos && idx && u, "attn_pre_fwd: null pointer");
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kAttnFwd, st, 0.0,
-                          4.0 * (rows(s) * (2.0 * d + 1) + static_cast<double>(B) * (n + N) * d));
-  NSDP_ATTN_LAUNCH(attn_pre_fwd_kernel, s, q, kf, pos, idx, u);
+                          kEl * (rows(s) * (2.0 * d + 1) + static_cast<double>(B) * (n + N) * d));
+  NSDP_ATTN_LAUNCH(attn_pre_fwd_kernel<T>, s, q, kf, pos, idx, u);
   return nsdp::launch_status("attn_pre_fwd_kernel");
 }
 
-int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
-                      int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream) {
+template <typename T>
+int attn_pre_bwd_t(const T *du, const int32_t *idx, int B, int n, int N, int k, int d, int q_per_shape, float *dq,
+                   float *dkf, T *dpos_acc, void *stream) {
+  constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
   if (q_per_shape && dq && static_cast<long long>(B) * d > 0)
@@ -621,29 +670,30 @@ int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, 
   NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
-                          4.0 * (rows(s) * ((dpos_acc ? 3.0 : 1.0) * d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
+                          kEl * (rows(s) * ((dpos_acc ? 3.0 : 1.0) * d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
   if (q_per_shape && regtab_fits(N, d, static_cast<long long>(n) * k)) {
     // decoder: one query vector per shape.  dkf = -scatter(du), dq = +column sum of du: the register-table scatter
     return launch_regtab_scatter(du, idx, dkf, dq, dpos_acc, B, static_cast<long long>(n) * k, N, d, -1.f, 1.f, st);
   }
   if (lds_table_fits(s)) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
-    if (const int rc = allow_big_lds(attn_pre_bwd_lds_kernel, lds, "attn_pre_bwd_lds_kernel")) return rc;
+    if (const int rc = allow_big_lds(attn_pre_bwd_lds_kernel<T>, lds, "attn_pre_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
     dim3 grid;
     lds_plan(sl, grid);
     NSDP_TRACE("attn_pre_bwd_lds");
-    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf, dpos_acc);
+    hipLaunchKernelGGL(attn_pre_bwd_lds_kernel<T>, grid, dim3(kLdsThreads), lds, st, sl, du, idx, dq, dkf, dpos_acc);
     return nsdp::launch_status("attn_pre_bwd_lds_kernel");
   }
   NSDP_TRACE("attn_pre_bwd_atomic");
-  NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel, s, du, idx, dq, dkf, dpos_acc);
+  NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel<T>, s, du, idx, dq, dkf, dpos_acc);
   return nsdp::launch_status("attn_pre_bwd_kernel");
 }
 
-int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const int32_t *idx,
-                       const float *a_g, const float *v_g, const float *residual, int B, int n, int N,
-                       int k, int d, float *y, float *lse, void *stream) {
+template <typename T>
+int attn_post_fwd_t(const T *a, const T *vf, const T *pos, const int32_t *idx, const T *a_g, const T *v_g,
+                    const T *residual, int B, int n, int N, int k, int d, T *y, float *lse, void *stream) {
+  constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   if (static_cast<long long>(B) * n * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_post_fwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
@@ -651,16 +701,17 @@ int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const 
   NSDP_REQUIRE((a_g == nullptr) == (v_g == nullptr), "attn_post_fwd: a_g and v_g go together");
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kAttnFwd, st, 0.0,
-                          4.0 * (rows(s) * (2.0 * d + 1) + static_cast<double>(B) * (2.0 * n + (vf ? N : 0)) * d));
+                          kEl * (rows(s) * (2.0 * d + 1) + static_cast<double>(B) * (2.0 * n + (vf ? N : 0)) * d));
   const bool has_v = vf != nullptr;
   NSDP_ATTN_LAUNCH_V(attn_post_fwd_kernel, has_v, s, a, vf, pos, idx, a_g, v_g, residual, y, lse);
   return nsdp::launch_status("attn_post_fwd_kernel");
 }
 
-int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const float *pos,
-                       const int32_t *idx, const float *a_g, const float *v_g, const float *y,
-                       const float *residual, const float *lse, int B, int n, int N, int k, int d, float *da, float *dpos,
-                       float *dvf, float *da_g, float *dv_g, void *stream) {
+template <typename T>
+int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const int32_t *idx, const T *a_g, const T *v_g,
+                    const T *y, const T *residual, const float *lse, int B, int n, int N, int k, int d, T *da, T *dpos,
+                    float *dvf, float *da_g, float *dv_g, void *stream) {
+  constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
   if (dvf && static_cast<long long>(B) * N * d > 0)
@@ -677,16 +728,16 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                    (a_g == nullptr) == (dv_g == nullptr),
                "attn_post_bwd: global-token pointers go together");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
-                          4.0 * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + (vf ? 2.0 * N : 0)) * d));
+                          kEl * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + (vf ? 2.0 * N : 0)) * d));
   const bool has_v = vf != nullptr;
   if (lds_table_fits(s) && has_v) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
-    if (const int rc = allow_big_lds(attn_post_bwd_lds_kernel<true>, lds, "attn_post_bwd_lds_kernel")) return rc;
+    if (const int rc = allow_big_lds(attn_post_bwd_lds_kernel<T, true>, lds, "attn_post_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
     dim3 grid;
     lds_plan(sl, grid);
     NSDP_TRACE("attn_post_bwd_lds");
-    hipLaunchKernelGGL((attn_post_bwd_lds_kernel<true>), grid, dim3(kLdsThreads), lds, st, sl, dy, a, vf, pos,
+    hipLaunchKernelGGL((attn_post_bwd_lds_kernel<T, true>), grid, dim3(kLdsThreads), lds, st, sl, dy, a, vf, pos,
                        idx, a_g, v_g, y, residual, lse, da, dpos, dvf, da_g, dv_g);
     return nsdp::launch_status("attn_post_bwd_lds_kernel");
   }
@@ -695,5 +746,58 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                      dvf, da_g, dv_g);
   return nsdp::launch_status("attn_post_bwd_kernel");
 }
+
+}  // namespace
+
+extern "C" {
+
+int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
+                      int N, int k, int d, int q_per_shape, float *u, void *stream) {
+  return attn_pre_fwd_t<float>(q, kf, pos, idx, B, n, N, k, d, q_per_shape, u, stream);
+}
+int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
+                      int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream) {
+  return attn_pre_bwd_t<float>(du, idx, B, n, N, k, d, q_per_shape, dq, dkf, dpos_acc, stream);
+}
+int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const int32_t *idx,
+                       const float *a_g, const float *v_g, const float *residual, int B, int n, int N,
+                       int k, int d, float *y, float *lse, void *stream) {
+  return attn_post_fwd_t<float>(a, vf, pos, idx, a_g, v_g, residual, B, n, N, k, d, y, lse, stream);
+}
+int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const float *pos,
+                       const int32_t *idx, const float *a_g, const float *v_g, const float *y,
+                       const float *residual, const float *lse, int B, int n, int N, int k, int d, float *da, float *dpos,
+                       float *dvf, float *da_g, float *dv_g, void *stream) {
+  return attn_post_bwd_t<float>(dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, B, n, N, k, d, da, dpos, dvf, da_g, dv_g,
+                                stream);
+}
+
+// bf16-storage variants: every activation tensor (q, kf, vf, pos, u, a, y, residual, a_g, v_g and the gradients du, dy,
+// da, dpos, dpos_acc) is bf16; lse and the scatter / reduction outputs (dq, dkf, dvf, da_g, dv_g) stay fp32.
+#define B16(p) reinterpret_cast<const bf16_t *>(p)
+#define B16W(p) reinterpret_cast<bf16_t *>(p)
+int nsdp_attn_pre_fwd_bf16(const void *q, const void *kf, const void *pos, const int32_t *idx, int B, int n, int N, int k,
+                           int d, int q_per_shape, void *u, void *stream) {
+  return attn_pre_fwd_t<bf16_t>(B16(q), B16(kf), B16(pos), idx, B, n, N, k, d, q_per_shape, B16W(u), stream);
+}
+int nsdp_attn_pre_bwd_bf16(const void *du, const int32_t *idx, int B, int n, int N, int k, int d, int q_per_shape,
+                           float *dq, float *dkf, void *dpos_acc, void *stream) {
+  return attn_pre_bwd_t<bf16_t>(B16(du), idx, B, n, N, k, d, q_per_shape, dq, dkf, B16W(dpos_acc), stream);
+}
+int nsdp_attn_post_fwd_bf16(const void *a, const void *vf, const void *pos, const int32_t *idx, const void *a_g,
+                            const void *v_g, const void *residual, int B, int n, int N, int k, int d, void *y, float *lse,
+                            void *stream) {
+  return attn_post_fwd_t<bf16_t>(B16(a), B16(vf), B16(pos), idx, B16(a_g), B16(v_g), B16(residual), B, n, N, k, d, B16W(y),
+                                 lse, stream);
+}
+int nsdp_attn_post_bwd_bf16(const void *dy, const void *a, const void *vf, const void *pos, const int32_t *idx,
+                            const void *a_g, const void *v_g, const void *y, const void *residual, const float *lse, int B,
+                            int n, int N, int k, int d, void *da, void *dpos, float *dvf, float *da_g, float *dv_g,
+                            void *stream) {
+  return attn_post_bwd_t<bf16_t>(B16(dy), B16(a), B16(vf), B16(pos), idx, B16(a_g), B16(v_g), B16(y), B16(residual), lse, B, n,
+                                 N, k, d, B16W(da), B16W(dpos), dvf, da_g, dv_g, stream);
+}
+#undef B16
+#undef B16W
 
 }  // extern "C"

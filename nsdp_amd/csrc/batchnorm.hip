@@ -26,11 +26,40 @@ __device__ __forceinline__ Geo geo(int C) {
   return g;
 }
 
+// Storage type of x / addend / y / dy / dx: float, or bf16 (BASELINE config 3).  Statistics, affine parameters and all
+// arithmetic are fp32 in either mode.
+struct bf16_t {
+  unsigned short v;
+};
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float4 ld4(const bf16_t *p) {
+  const uint2 r = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__builtin_bit_cast(float, r.x << 16), __builtin_bit_cast(float, r.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.y << 16), __builtin_bit_cast(float, r.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(bf16_t *p, float4 v) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  *reinterpret_cast<uint2 *>(p) = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.x, v.y}, bf16x2)),
+                                             __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v.z, v.w}, bf16x2)));
+}
+// per-channel pivot of the shifted sums (row 0 of the batch): sum (v - p) and sum (v - p)^2 do not cancel when
+// |mean| >> std, unlike E[v^2] - mean^2 on raw fp32 sums
+template <typename T>
+__device__ __forceinline__ float4 pivot4(const T *x, const T *addend, int c4) {
+  float4 p = ld4(x + 4 * c4);
+  if (addend) {
+    const float4 a = ld4(addend + 4 * c4);
+    p.x += a.x; p.y += a.y; p.z += a.z; p.w += a.w;
+  }
+  return p;
+}
 
-// column sums of v and v*v (v = x [+ addend]) over this workgroup's row chunk -> part[blk][2][C]
-__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restrict__ x,
-                                                            const float *__restrict__ addend, long long R,
+// column sums of (v - pivot) and (v - pivot)^2 (v = x [+ addend]) over this workgroup's row chunk -> part[blk][2][C]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict__ x,
+                                                            const T *__restrict__ addend, long long R,
                                                             int C, long long rows_per_blk,
                                                             float *__restrict__ part) {
   __shared__ float4 red[2][kThreads];
@@ -41,12 +70,14 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const float *__restr
   const long long r1 = min(R, r0 + rows_per_blk);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
   if (active) {
+    const float4 pv = pivot4(x, addend, cq);
     for (long long r = r0 + sub; r < r1; r += g.rpi) {
       float4 v = ld4(x + r * C + 4 * cq);
       if (addend) {
         const float4 a = ld4(addend + r * C + 4 * cq);
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
       }
+      v.x -= pv.x; v.y -= pv.y; v.z -= pv.z; v.w -= pv.w;
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
       q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
     }
@@ -89,7 +120,9 @@ __device__ __forceinline__ void combine_partials(const float *__restrict__ part,
 
 // mean / invstd from the partials + running-statistics update
 // (momentum form of nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance for running_var)
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ part, int nparts, long long R,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const T *__restrict__ x, const T *__restrict__ addend,
+                                                          const float *__restrict__ part, int nparts, long long R,
                                                           int C, float eps, float momentum,
                                                           float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, float *__restrict__ mean,
@@ -99,9 +132,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
   double s, q;
   combine_partials(part, nparts, C, c, sub16, s, q);
   if (c >= C || sub16 != 0) return;
-  const double m = s / static_cast<double>(R);
-  double var = q / static_cast<double>(R) - m * m;
+  const float4 pv4 = pivot4(x, addend, c >> 2);
+  const float pv = (c & 3) == 0 ? pv4.x : (c & 3) == 1 ? pv4.y : (c & 3) == 2 ? pv4.z : pv4.w;
+  const double ms = s / static_cast<double>(R);            // mean of the shifted values
+  double var = q / static_cast<double>(R) - ms * ms;
   if (var < 0.0) var = 0.0;
+  const double m = static_cast<double>(pv) + ms;
   mean[c] = static_cast<float>(m);
   invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
   if (running_mean) {
@@ -112,13 +148,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
 }
 
 // y = ((x [+ addend]) - mean) * invstd * gamma + beta, optional ReLU
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restrict__ x,
-                                                            const float *__restrict__ addend,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const T *__restrict__ x,
+                                                            const T *__restrict__ addend,
                                                             const float *__restrict__ mean,
                                                             const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta, long long total4,
-                                                            int C4, int relu, float *__restrict__ y) {
+                                                            int C4, int relu, T *__restrict__ y) {
   for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total4;
        e += static_cast<long long>(gridDim.x) * kThreads) {
     const int cq = static_cast<int>(e % C4);
@@ -133,14 +170,15 @@ __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float *__restr
     if (relu) {
       o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
     }
-    *reinterpret_cast<float4 *>(y + 4 * e) = o;
+    st4(y + 4 * e, o);
   }
 }
 
 // backward column sums: dbeta = sum dy', dgamma = sum dy' * xhat, with dy' = dy * (y > 0) when relu
+template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
-    const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
-    const float *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const T *__restrict__ dy, const T *__restrict__ y, const T *__restrict__ x,
+    const T *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
     long long R, int C, long long rows_per_blk, float *__restrict__ part) {
   __shared__ float4 red[2][kThreads];
   const Geo g = geo(C);
@@ -198,11 +236,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__res
 
 // dx = gamma * invstd * (dy' - dbeta/R - xhat * dgamma/R)   (training)
 // dx = gamma * invstd * dy'                                   (eval: statistics are constants)
+template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
-    const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
-    const float *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const T *__restrict__ dy, const T *__restrict__ y, const T *__restrict__ x,
+    const T *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ gamma, const float *__restrict__ dgamma, const float *__restrict__ dbeta,
-    long long total4, int C4, float inv_r, int training, float *__restrict__ dx) {
+    long long total4, int C4, float inv_r, int training, T *__restrict__ dx) {
   for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total4;
        e += static_cast<long long>(gridDim.x) * kThreads) {
     const int cq = static_cast<int>(e % C4);
@@ -228,7 +267,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     } else {
       o = make_float4(ga.x * is.x * d.x, ga.y * is.y * d.y, ga.z * is.z * d.z, ga.w * is.w * d.w);
     }
-    *reinterpret_cast<float4 *>(dx + 4 * e) = o;
+    st4(dx + 4 * e, o);
   }
 }
 
@@ -254,6 +293,54 @@ inline int ew_grid(long long total4) {
 }
 inline bool c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 1024; }
 
+template <typename T>
+int bn_stats_t(const T *x, const T *addend, long long R, int C, float eps, float momentum, float *running_mean,
+               float *running_var, float *mean, float *invstd, float *workspace, void *stream) {
+  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_stats: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
+  NSDP_REQUIRE(x && mean && invstd && workspace, "bn_stats: null pointer");
+  NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats go together");
+  hipStream_t st = nsdp::as_stream(stream);
+  const Plan p = plan(R, C);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, sizeof(T) * 1.0 * R * C * (addend ? 2 : 1));
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk, workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 15) / 16), dim3(256), 0, st, x, addend, workspace, p.parts, R, C, eps,
+                     momentum, running_mean, running_var, mean, invstd);
+  return nsdp::launch_status("bn_stats_kernel");
+}
+
+template <typename T>
+int bn_apply_t(const T *x, const T *addend, const float *mean, const float *invstd, const float *gamma, const float *beta,
+               long long R, int C, int relu, T *y, void *stream) {
+  if (R <= 0) return 0;
+  NSDP_REQUIRE(c_ok(C), "bn_apply: C=%d must be a multiple of 4, <= 1024", C);
+  NSDP_REQUIRE(x && mean && invstd && gamma && beta && y, "bn_apply: null pointer");
+  hipStream_t st = nsdp::as_stream(stream);
+  const long long total4 = R * (C >> 2);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, sizeof(T) * 1.0 * R * C * (addend ? 3 : 2));
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid(total4)), dim3(kThreads), 0, st, x, addend, mean, invstd, gamma, beta,
+                     total4, C >> 2, relu, y);
+  return nsdp::launch_status("bn_apply_kernel");
+}
+
+template <typename T>
+int bn_backward_t(const T *dy, const T *y_relu, const T *x, const T *addend, const float *mean, const float *invstd,
+                  const float *gamma, long long R, int C, int training, T *dx, float *dgamma, float *dbeta,
+                  float *workspace, void *stream) {
+  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_backward: need R > 0 and C %% 4 == 0, C <= 1024");
+  NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace, "bn_backward: null pointer");
+  hipStream_t st = nsdp::as_stream(stream);
+  const Plan p = plan(R, C);
+  const long long total4 = R * (C >> 2);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
+                          sizeof(T) * 1.0 * R * C * (5.0 + (y_relu ? 2 : 0) + (addend ? 2 : 0)));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean, invstd, R,
+                     C, p.rows_per_blk, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, C, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total4)), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
+                     invstd, gamma, dgamma, dbeta, total4, C >> 2, 1.0f / static_cast<float>(R), training, dx);
+  return nsdp::launch_status("bn_backward");
+}
+
 }  // namespace
 
 extern "C" {
@@ -263,50 +350,34 @@ size_t nsdp_bn_workspace_bytes(int C) { return static_cast<size_t>(kMaxParts) * 
 int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
                   void *stream) {
-  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_stats: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
-  NSDP_REQUIRE(x && mean && invstd && workspace, "bn_stats: null pointer");
-  NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats go together");
-  hipStream_t st = nsdp::as_stream(stream);
-  const Plan p = plan(R, C);
-  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, 4.0 * R * C * (addend ? 2 : 1));
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk,
-                     workspace);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, R, C, eps,
-                     momentum, running_mean, running_var, mean, invstd);
-  return nsdp::launch_status("bn_stats_kernel");
+  return bn_stats_t<float>(x, addend, R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace, stream);
 }
-
 int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
                   const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream) {
-  if (R <= 0) return 0;
-  NSDP_REQUIRE(c_ok(C), "bn_apply: C=%d must be a multiple of 4, <= 1024", C);
-  NSDP_REQUIRE(x && mean && invstd && gamma && beta && y, "bn_apply: null pointer");
-  hipStream_t st = nsdp::as_stream(stream);
-  const long long total4 = R * (C >> 2);
-  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, 4.0 * R * C * (addend ? 3 : 2));
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(total4)), dim3(kThreads), 0, st, x, addend, mean, invstd, gamma,
-                     beta, total4, C >> 2, relu, y);
-  return nsdp::launch_status("bn_apply_kernel");
+  return bn_apply_t<float>(x, addend, mean, invstd, gamma, beta, R, C, relu, y, stream);
 }
-
 int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const float *addend,
                      const float *mean, const float *invstd, const float *gamma, long long R, int C,
                      int training, float *dx, float *dgamma, float *dbeta, float *workspace, void *stream) {
-  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_backward: need R > 0 and C %% 4 == 0, C <= 1024");
-  NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace,
-               "bn_backward: null pointer");
-  hipStream_t st = nsdp::as_stream(stream);
-  const Plan p = plan(R, C);
-  const long long total4 = R * (C >> 2);
-  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
-                          4.0 * R * C * (5.0 + (y_relu ? 2 : 0) + (addend ? 2 : 0)));
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(p.parts), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
-                     invstd, R, C, p.rows_per_blk, workspace);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, C, dgamma,
-                     dbeta);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(total4)), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
-                     invstd, gamma, dgamma, dbeta, total4, C >> 2, 1.0f / static_cast<float>(R), training, dx);
-  return nsdp::launch_status("bn_backward");
+  return bn_backward_t<float>(dy, y_relu, x, addend, mean, invstd, gamma, R, C, training, dx, dgamma, dbeta, workspace, stream);
 }
+
+// bf16-storage variants: x, addend, y, dy, dx are bf16 tensors; statistics / affine parameters / their gradients fp32
+#define B16(p) reinterpret_cast<const bf16_t *>(p)
+int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
+                       float *running_mean, float *running_var, float *mean, float *invstd, float *workspace, void *stream) {
+  return bn_stats_t<bf16_t>(B16(x), B16(addend), R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace, stream);
+}
+int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
+                       const float *beta, long long R, int C, int relu, void *y, void *stream) {
+  return bn_apply_t<bf16_t>(B16(x), B16(addend), mean, invstd, gamma, beta, R, C, relu, reinterpret_cast<bf16_t *>(y), stream);
+}
+int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, const void *addend, const float *mean,
+                          const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
+                          float *dgamma, float *dbeta, float *workspace, void *stream) {
+  return bn_backward_t<bf16_t>(B16(dy), B16(y_relu), B16(x), B16(addend), mean, invstd, gamma, R, C, training,
+                               reinterpret_cast<bf16_t *>(dx), dgamma, dbeta, workspace, stream);
+}
+#undef B16
 
 }  // extern "C"

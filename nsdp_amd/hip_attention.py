@@ -10,8 +10,26 @@ from ._lib import check, fptr, iptr, lib, on_device, optptr, stream_ptr
 _ci = ctypes.c_int
 
 
+BF16 = torch.bfloat16
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t, dtype, name="tensor"):
+    """Device pointer of an activation tensor of the storage type of this call (fp32 or bf16), or NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if t.dtype is not dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype} (all activation tensors of one call share a storage type)")
+    if not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name} must be a contiguous GPU tensor")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _fn(name, dtype):
+    return getattr(lib(), name + ("_bf16" if dtype is BF16 else ""))
 
 
 class _PosGrad:
@@ -37,9 +55,10 @@ class _AttnPre(torch.autograd.Function):
         N = kf.shape[1]
         qb = int(q.shape[1] == 1 and n != 1)  # (B,1,d): one query vector per shape
         u = torch.empty_like(pos)
+        dt = pos.dtype
         with on_device(pos):
-            check(lib().nsdp_attn_pre_fwd(fptr(q, "q"), fptr(kf, "kf"), fptr(pos, "pos"), iptr(idx, "idx"), _ci(B),
-                                          _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb), fptr(u), stream_ptr()),
+            check(_fn("nsdp_attn_pre_fwd", dt)(_p(q, dt, "q"), _p(kf, dt, "kf"), _p(pos, dt, "pos"), iptr(idx, "idx"), _ci(B),
+                                               _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb), _p(u, dt), stream_ptr()),
                   "nsdp_attn_pre_fwd")
         ctx.save_for_backward(idx)
         ctx.dims = (B, n, N, k, d, qb)
@@ -50,14 +69,17 @@ class _AttnPre(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, n, N, k, d, qb = ctx.dims
         du = _c(du)
+        dt = du.dtype
         dq = torch.empty((B, 1 if qb else n, d), dtype=torch.float32, device=du.device)
         dkf = torch.empty((B, N, d), dtype=torch.float32, device=du.device)
         acc = None
         if ctx.link is not None:
             acc, ctx.link.dpos = ctx.link.dpos, None
         with on_device(du):
-            check(lib().nsdp_attn_pre_bwd(fptr(du, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
-                                          fptr(dq), fptr(dkf), optptr(acc), stream_ptr()), "nsdp_attn_pre_bwd")
+            check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
+                                               fptr(dq), fptr(dkf), _p(acc, dt, "dpos"), stream_ptr()), "nsdp_attn_pre_bwd")
+        if dt is BF16:           # (scatter / reduction outputs are produced in fp32; the tables are small)
+            dq, dkf = dq.to(BF16), dkf.to(BF16)
         return dq, dkf, (du if acc is None else acc), None, None
 
 
@@ -74,12 +96,14 @@ class _AttnPost(torch.autograd.Function):
         residual = None if residual is None else _c(residual)
         B, n, k, d = a.shape
         N = vf.shape[1] if vf is not None else 1
-        y = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
+        dt = a.dtype
+        y = torch.empty((B, n, d), dtype=dt, device=a.device)
         lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
         with on_device(a):
-            check(lib().nsdp_attn_post_fwd(fptr(a, "a"), optptr(vf), fptr(pos, "pos"), iptr(idx, "idx"), optptr(a_g),
-                                           optptr(v_g), optptr(residual), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
-                                           fptr(y), fptr(lse), stream_ptr()), "nsdp_attn_post_fwd")
+            check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
+                                                _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
+                                                _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse), stream_ptr()),
+                  "nsdp_attn_post_fwd")
         ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse)
         ctx.dims = (B, n, N, k, d)
         return y
@@ -90,16 +114,21 @@ class _AttnPost(torch.autograd.Function):
         B, n, N, k, d = ctx.dims
         dy = _c(dy)
         dev = dy.device
+        dt = a.dtype
         da = torch.empty_like(a)
         dpos = torch.empty_like(a)
         dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if vf is not None else None
         da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         with on_device(dy):
-            check(lib().nsdp_attn_post_bwd(fptr(dy, "dy"), fptr(a), optptr(vf), fptr(pos), iptr(idx), optptr(a_g),
-                                           optptr(v_g), fptr(y), optptr(residual), fptr(lse), _ci(B), _ci(n), _ci(N),
-                                           _ci(k), _ci(d), fptr(da), fptr(dpos), optptr(dvf), optptr(da_g),
-                                           optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+            check(_fn("nsdp_attn_post_bwd", dt)(_p(dy, dt, "dy"), _p(a, dt), _p(vf, dt), _p(pos, dt), iptr(idx), _p(a_g, dt),
+                                                _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B), _ci(n), _ci(N),
+                                                _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(dvf), optptr(da_g),
+                                                optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+        if dt is BF16:
+            dvf = None if dvf is None else dvf.to(BF16)
+            da_g = None if da_g is None else da_g.to(BF16)
+            dv_g = None if dv_g is None else dv_g.to(BF16)
         if ctx.link is not None and ctx.needs_input_grad[2]:
             ctx.link.dpos, dpos = dpos, None          # attn_pre's backward adds d(u) and reports the sum
         return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None
@@ -111,7 +140,7 @@ def pos_grad_link():
     return _PosGrad()
 
 
-NATIVE_BF16 = False       # bf16-storage kernels present (otherwise the calls below cast around the fp32 ones)
+NATIVE_BF16 = True        # bf16-storage kernels (False: cast around the fp32 ones -- the reference semantics the tests compare with)
 
 
 def _f(t):

@@ -9,7 +9,21 @@ import torch
 
 from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
 
-NATIVE_BF16 = False       # bf16-storage kernels present (otherwise ops.batch_norm casts around the fp32 ones)
+NATIVE_BF16 = True        # bf16-storage kernels (False: ops.batch_norm casts around the fp32 ones -- reference semantics for tests)
+BF16 = torch.bfloat16
+
+
+def _p(t, dtype, name="tensor"):
+    if t is None:
+        return ctypes.c_void_p(0)
+    if t.dtype is not dtype or not t.is_cuda or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous GPU {dtype} tensor, got {t.dtype}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _fn(name, dtype):
+    return getattr(lib(), name + ("_bf16" if dtype is BF16 else ""))
+
 _ll = ctypes.c_longlong
 _ci = ctypes.c_int
 _cf = ctypes.c_float
@@ -34,19 +48,22 @@ class _BatchNormFn(torch.autograd.Function):
             a2 = a2 if a2.is_contiguous() else a2.contiguous()
         R = x2.shape[0]
         dev = x2.device
+        dt = x2.dtype
+        if a2 is not None and a2.dtype is not dt:
+            a2 = a2.to(dt)
         with on_device(x2):
             if training:
                 mean = torch.empty(C, dtype=torch.float32, device=dev)
                 invstd = torch.empty(C, dtype=torch.float32, device=dev)
-                check(lib().nsdp_bn_stats(fptr(x2, "x"), optptr(a2), _ll(R), _ci(C), _cf(eps), _cf(momentum),
-                                          optptr(running_mean), optptr(running_var), fptr(mean), fptr(invstd),
-                                          fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_stats")
+                check(_fn("nsdp_bn_stats", dt)(_p(x2, dt, "x"), _p(a2, dt, "addend"), _ll(R), _ci(C), _cf(eps), _cf(momentum),
+                                               optptr(running_mean), optptr(running_var), fptr(mean), fptr(invstd),
+                                               fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_stats")
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)
             y = torch.empty_like(x2)
-            check(lib().nsdp_bn_apply(fptr(x2), optptr(a2), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
-                                      fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), fptr(y), stream_ptr()),
+            check(_fn("nsdp_bn_apply", dt)(_p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
+                                           fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), _p(y, dt), stream_ptr()),
                   "nsdp_bn_apply")
         ctx.save_for_backward(x2, a2, gamma, mean, invstd, y if relu else None)
         ctx.training, ctx.shape, ctx.has_addend = bool(training), shape, addend is not None
@@ -59,13 +76,16 @@ class _BatchNormFn(torch.autograd.Function):
         dy2 = dy.reshape(R, C)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dev = dy2.device
+        dt = x2.dtype
+        if dy2.dtype is not dt:
+            dy2 = dy2.to(dt)
         dx = torch.empty_like(x2)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         with on_device(dy2):
-            check(lib().nsdp_bn_backward(fptr(dy2, "dy"), optptr(y), fptr(x2), optptr(a2), fptr(mean), fptr(invstd),
-                                         fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), fptr(dx), fptr(dgamma),
-                                         fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
+            check(_fn("nsdp_bn_backward", dt)(_p(dy2, dt, "dy"), _p(y, dt), _p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd),
+                                              fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), _p(dx, dt), fptr(dgamma),
+                                              fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
         dx = dx.reshape(ctx.shape)
         return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None
 
@@ -77,5 +97,10 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
-    return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, float(bn.momentum), float(bn.eps),
-                              bool(relu))
+    if bn.momentum is None:
+        # nn.BatchNorm's cumulative moving average: factor 1 / num_batches_tracked (already counted above); this reads the
+        # counter back from the device, i.e. one host sync per call -- none of the NSDP configurations uses it
+        momentum = 1.0 / max(1.0, float(bn.num_batches_tracked)) if (bn.training and bn.track_running_stats) else 0.0
+    else:
+        momentum = float(bn.momentum)
+    return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, momentum, float(bn.eps), bool(relu))

@@ -505,7 +505,9 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
             if residual is not None and residual.dtype is not torch.bfloat16:
                 residual = residual.to(torch.bfloat16)
             return hb.linear(x, weight, bias, relu_in, relu_out, residual, w_param, b_param, grad_sum, owner, out_f32)
-        # the narrow ends of the network (3-wide coordinate inputs, ...): fp32 kernels, result rounded to the storage type
+        if not out_f32 and grad_sum is None and hb.k4_supported(x, N, relu_in, residual):
+            return hb.linear_k4(x, weight, bias, relu_out, w_param, b_param)       # fp32 coordinates in, bf16 out
+        # the other narrow ends of the network (enc_sdf's 4 / 7 input features): fp32 kernels, result rounded to bf16
         if grad_sum is not None:
             raise ValueError("InputGradSum needs a bf16 layer in bf16 storage mode")
         xf = x if x.dtype is torch.float32 else x.float()

@@ -173,6 +173,91 @@ class _LinearB16Fn(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
+def k4_forward(x2, w4, b, relu_out):
+    """bf16 Y [M,N] = act(x2 [M,4] fp32 @ w4 [N,4]^T + b)  (nsdp_linear_k4_bf16)."""
+    M, N = x2.shape[0], w4.shape[0]
+    y = torch.empty((M, N), dtype=BF16, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_k4_bf16(fptr(x2, "x"), fptr(w4, "weight"), optptr(b), ctypes.c_void_p(y.data_ptr()), _ll(M),
+                                        _ci(N), _ci(int(relu_out)), stream_ptr()), "nsdp_linear_k4_bf16")
+    return y
+
+
+def k4_wgrad(dy2, x2, mask, relu_x, want_db):
+    """dW [N,4], db [N] (fp32) from bf16 dY [M,N] and fp32 X [M,4] (nsdp_linear_wgrad_k4_bf16)."""
+    assert not relu_x
+    M, N = dy2.shape
+    L = lib()
+    L.nsdp_linear_wgrad_k4_bf16_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.nsdp_linear_wgrad_k4_bf16_workspace_bytes(_ll(M), _ci(N)))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+    dw = torch.empty((N, 4), dtype=torch.float32, device=dy2.device)
+    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    with on_device(dy2):
+        check(L.nsdp_linear_wgrad_k4_bf16(hptr(dy2, "dy"), fptr(x2, "x"), opthptr(mask, "mask"), fptr(dw), optptr(db), _ll(M),
+                                          _ci(N), fptr(ws), ctypes.c_size_t(nbytes), stream_ptr()),
+              "nsdp_linear_wgrad_k4_bf16")
+    return dw, db
+
+
+class _LinearK4B16Fn(torch.autograd.Function):
+    """First layer of a position-encoding MLP with bf16 storage: fp32 coordinates [.., 3 or 4] in, bf16 [.., N] out."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu_out, w_param, b_param):
+        ctx.w_param, ctx.b_param = w_param, b_param
+        K = x.shape[-1]
+        N = w.shape[0]
+        x2 = x.reshape(-1, K)
+        x2 = torch.nn.functional.pad(x2, (0, 4 - K)) if K < 4 else (x2 if x2.is_contiguous() else x2.contiguous())
+        w4 = torch.nn.functional.pad(w, (0, 4 - K)) if K < 4 else w.contiguous()
+        y = k4_forward(x2, w4, b, relu_out)
+        ctx.k_orig, ctx.n_out, ctx.x_shape, ctx.has_bias = K, N, x.shape, b is not None
+        ctx.save_for_backward(x2, y if relu_out else None, w4 if ctx.needs_input_grad[0] else None)
+        return y.reshape(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, w4 = ctx.saved_tensors
+        N, K = ctx.n_out, ctx.k_orig
+        dy2 = dy.reshape(-1, N)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        dx = dw = db = None
+
+        def wg(dy2_, x2_, mask_, relu_x_, want_db_):
+            gw, gb = k4_wgrad(dy2_, x2_, mask_, relu_x_, want_db_)
+            return (gw[:, :K].contiguous() if K < 4 else gw), gb
+        if ctx.w_param is not None:
+            if hip_linear._use_side_stream(dy2):
+                hip_linear._wgrad_deferred(dy2, x2, y, False, K, ctx.w_param, ctx.b_param, fn=wg)
+            else:
+                gw, gb = wg(dy2, x2, y, False, ctx.b_param is not None)
+                with torch.no_grad():
+                    for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
+                        if prm is not None:
+                            g = g.view_as(prm)
+                            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+        elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = wg(dy2, x2, y, False, ctx.has_bias)
+        if ctx.needs_input_grad[0]:
+            # dX [M,4] = dY' [M,N] W [N,4]: an ordinary bf16 layer with 4 (fp32) outputs
+            _, wpt = pack_weight_b16(w4, False, True)
+            dx4 = run(dy2, wpt, 4, None, None, y, None, False, False, out_f32=True)
+            dx = (dx4[:, :K] if K < 4 else dx4).reshape(ctx.x_shape)
+        return dx, dw, db, None, None, None
+
+
+def k4_supported(x, N, relu_in, residual):
+    return x.dtype is torch.float32 and x.shape[-1] in (3, 4) and N % 8 == 0 and 8 <= N <= 256 and not relu_in and residual is None
+
+
+def linear_k4(x, weight, bias, relu_out, w_param, b_param):
+    w2 = weight.squeeze(-1) if weight.dim() == 3 else weight
+    if w_param is not None:
+        return _LinearK4B16Fn.apply(x, w2.detach(), None if bias is None else bias.detach(), bool(relu_out), w_param, b_param)
+    return _LinearK4B16Fn.apply(x, w2, bias, bool(relu_out), None, None)
+
+
 def linear(x, weight, bias, relu_in, relu_out, residual, w_param, b_param, grad_sum, owner, out_f32=False):
     w2 = weight.squeeze(-1) if weight.dim() == 3 else weight
     if w_param is not None:

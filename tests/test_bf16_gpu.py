@@ -149,3 +149,133 @@ def test_bf16_storage_model_vs_fp32_reference(mtype):
             rels.append(abs(float(p.grad.double().norm()) - gn) / gn)
     print(f"gradient-norm deviation from the fp32 reference: median {np.median(rels):.3e}, max {np.max(rels):.3e}")
     assert np.median(rels) <= (0.25 if mtype == "arbitrary" else 0.05)
+
+
+def _close_bf16(a, b, name, atol):
+    """Two bf16 tensors computed with identical fp32 arithmetic up to summation order: at most an ulp apart."""
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = 2 ** -7 * b.abs() + atol
+    assert bool((err <= tol).all()), (name, float((err - tol).max()))
+
+
+@pytest.mark.parametrize("B,n,N,k,d,qb,glob", [(2, 37, 50, 10, 120, 0, False), (3, 1000, 100, 7, 200, 1, True),
+                                                (2, 64, 64, 16, 256, 0, False), (1, 5000, 100, 7, 200, 1, True)])
+def test_attention_glue_bf16_native_vs_cast_reference(B, n, N, k, d, qb, glob):
+    """The bf16-storage instantiation of the attention kernels against the fp32 kernels run on casts of the same bf16
+    inputs (hip_attention.NATIVE_BF16 = False): forward values and every gradient."""
+    from nsdp_amd import hip_attention as ha
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    mk = lambda *s: (torch.randn(*s, generator=g)).to(BF).to(DEV)
+    idx = torch.randint(0, N, (B, n, k), generator=g, dtype=torch.int32).to(DEV)
+    base = dict(q=mk(B, 1 if qb else n, d), kf=mk(B, N, d), vf=mk(B, N, d), pos=mk(B, n, k, d), res=mk(B, n, d),
+                a_g=mk(B, d) if glob else None, v_g=mk(B, d) if glob else None, w=mk(B, n, d))
+    outs = []
+    for native in (True, False):
+        ha.NATIVE_BF16 = native
+        try:
+            t = {kk: (None if v is None else v.clone().requires_grad_(True)) for kk, v in base.items() if kk != "w"}
+            link = ha.pos_grad_link()
+            u = ha.attn_pre(t["q"], t["kf"], t["pos"], idx, link)
+            a = u * 0.5                                      # stands in for the gamma MLP
+            y = ha.attn_post(a, t["vf"], t["pos"], idx, a_g=t["a_g"], v_g=t["v_g"], residual=None if glob else t["res"],
+                             link=link)
+            (y.float() * base["w"].float()).sum().backward()
+            outs.append((u.detach(), y.detach(), {kk: v.grad for kk, v in t.items() if v is not None and v.grad is not None}))
+        finally:
+            ha.NATIVE_BF16 = True
+    (u1, y1, g1), (u0, y0, g0) = outs
+    assert u1.dtype is BF and y1.dtype is BF
+    _close_bf16(u1, u0, "u", 1e-6)
+    _close_bf16(y1, y0, "y", 1e-3)
+    assert set(g1) == set(g0)
+    # dq = sum_j du_j is analytically ~0 when q is per point (the softmax gradient sums to zero over the neighbours): it
+    # consists of bf16 rounding noise of the du_j, so every gradient is judged against the scale of the du-sized ones
+    floor = float(g0["kf"].float().abs().max())
+    for kk in g1:
+        scale = max(float(g0[kk].float().abs().max()), floor) + 1e-6
+        rel = float((g1[kk].float() - g0[kk].float()).abs().max()) / scale
+        assert rel <= 2e-2, (kk, rel)
+
+
+@pytest.mark.parametrize("R,C,addend,relu", [(3200, 256, False, True), (65536, 120, True, False), (1000, 256, True, True)])
+def test_batchnorm_bf16_native_vs_cast_reference(R, C, addend, relu):
+    from nsdp_amd import hip_batchnorm as hbn
+    from nsdp_amd.model import ops
+    g = torch.Generator().manual_seed(R + C)
+    x0 = (torch.randn(R, C, generator=g) * 2 + 3).to(BF).to(DEV)
+    a0 = torch.randn(R, C, generator=g).to(BF).to(DEV) if addend else None
+    w = torch.randn(R, C, generator=g).to(DEV)
+    res = []
+    for native in (True, False):
+        hbn.NATIVE_BF16 = native
+        try:
+            torch.manual_seed(0)
+            bn = torch.nn.BatchNorm1d(C).to(DEV)
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.5, 0.5)
+            x = x0.clone().requires_grad_(True)
+            a = None if a0 is None else a0.clone().requires_grad_(True)
+            y = ops.batch_norm(x, bn, addend=a, relu=relu)
+            (y.float() * w).sum().backward()
+            res.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()))
+        finally:
+            hbn.NATIVE_BF16 = True
+    n1, n0 = res
+    assert n1[0].dtype is BF and n1[1].dtype is BF
+    _close_bf16(n1[0], n0[0], "y", 1e-3)
+    for i, name in ((1, "dx"), (2, "dgamma"), (3, "dbeta"), (4, "running_mean"), (5, "running_var")):
+        scale = float(n0[i].float().abs().max()) + 1e-6
+        assert float((n1[i].float() - n0[i].float()).abs().max()) <= 1.5e-2 * scale, name
+
+
+def test_batchnorm_large_mean_small_std_is_stable():
+    """Shifted sums: a channel with |mean| >> std must not lose its variance to cancellation (fp32 path)."""
+    from nsdp_amd.model import ops
+    torch.manual_seed(1)
+    x = (torch.randn(8192, 8, device=DEV) * 1e-3 + 100.0).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(8).to(DEV)
+    ref = torch.nn.BatchNorm1d(8).to(DEV)
+    y = ops.batch_norm(x, bn)
+    yr = ref(x.detach().double().float())
+    ref64 = (x.detach().double() - x.detach().double().mean(0)) / (x.detach().double().var(0, unbiased=False) + 1e-5).sqrt()
+    assert float((y.double() - ref64).abs().max()) < 2e-2
+    assert float((bn.running_var - (0.9 + 0.1 * x.detach().double().var(0)).float()).abs().max()) < 1e-7
+
+
+def test_batchnorm_momentum_none_is_cumulative_average():
+    from nsdp_amd.model import ops
+    torch.manual_seed(2)
+    bn = torch.nn.BatchNorm1d(16, momentum=None).to(DEV)
+    ref = torch.nn.BatchNorm1d(16, momentum=None).to(DEV)
+    for i in range(3):
+        x = torch.randn(512, 16, device=DEV) + i
+        ops.batch_norm(x, bn)
+        ref(x)
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 3
+
+
+@pytest.mark.parametrize("M,N,K3,relu,mask", [(5000, 200, True, True, True), (70001, 120, True, False, False),
+                                               (4096, 256, False, False, False)])
+def test_k4_bf16_kernels(M, N, K3, relu, mask):
+    from nsdp_amd import hip_linear_bf16 as hb
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, 4, generator=g)
+    if K3:
+        x[:, 3] = 0
+    w = torch.randn(N, 4, generator=g)
+    b = torch.randn(N, generator=g)
+    y = hb.k4_forward(x.to(DEV), w.to(DEV), b.to(DEV), relu)
+    ref = x.double() @ w.double().t() + b.double()
+    ref = F.relu(ref) if relu else ref
+    assert bool(((y.double().cpu() - ref).abs() <= 2 ** -8 * ref.abs() + 1e-5).all())
+    dy = _rnd((M, N), g)
+    mk = y if mask else None
+    dw, db = hb.k4_wgrad(dy.to(DEV), x.to(DEV), mk, False, True)
+    dyd = dy.double() * (y.double().cpu() > 0) if mask else dy.double()
+    rw, rb = dyd.t() @ x.double(), dyd.sum(0)
+    assert float((dw.double().cpu() - rw).abs().max()) <= 1e-5 * (float(rw.abs().max()) + 1) * max(1.0, (M / 4096) ** 0.5)
+    assert float((db.double().cpu() - rb).abs().max()) <= 1e-5 * (float(rb.abs().max()) + 1) * max(1.0, (M / 4096) ** 0.5)
