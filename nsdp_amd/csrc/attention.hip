@@ -579,11 +579,13 @@ inline int launch_regtab_scatter(const T *src, const int32_t *idx, float *table,
   long long wgs = (4LL * nsdp::num_cus() + B - 1) / B;                 // ~4 workgroups per CU in total
   if (wgs * 512 > rows_per_shape) wgs = rows_per_shape / 512 > 0 ? rows_per_shape / 512 : 1;
   long long per = (rows_per_shape + wgs - 1) / wgs;
-  per = (per + 7) / 8 * 8;
+  per = (per + 15) / 16 * 16;
   wgs = (rows_per_shape + per - 1) / per;
   NSDP_TRACE("scatter_rows_regtab<8>");
-  hipLaunchKernelGGL((scatter_rows_regtab_kernel<T, 8>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx, table,
-                     colsum, acc_rows, rows_per_shape, per, N, d, sign, colsum_sign);
+  // (a bf16 row is half the bytes per load instruction: twice the rows in flight per lane)
+  constexpr int kUnroll = sizeof(T) == 2 ? 16 : 8;
+  hipLaunchKernelGGL((scatter_rows_regtab_kernel<T, kUnroll>), dim3(static_cast<unsigned>(wgs), B), dim3(256), 0, st, src, idx,
+                     table, colsum, acc_rows, rows_per_shape, per, N, d, sign, colsum_sign);
   return nsdp::launch_status("scatter_rows_regtab_kernel");
 }
 
