@@ -950,6 +950,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
 namespace nsdp {
 void debug_set_x3(int value);   // gemm_bf16x3.hip
 void debug_set_wg16(int value);  // gemm_bf16.hip
+void debug_set_lin16(int value);
 }
 
 extern "C" {
@@ -961,6 +962,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 5) g_wgrad_vec4 = value;
   if (key == 6) nsdp::debug_set_x3(value);
   if (key == 7) nsdp::debug_set_wg16(value);
+  if (key == 8) nsdp::debug_set_lin16(value);
 }
 
 static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,

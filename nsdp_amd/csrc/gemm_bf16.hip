@@ -140,7 +140,9 @@ struct B16Params {
   long long M;
   int N, K;
   int relu_in, relu_out, out_f32;
+  int dbg;                         // ablation knob nsdp_debug_set(8, v): 1 no MFMA, 2 no stores, 4 no activation loads (timing only)
 };
+int g_lin16_dbg = 0;
 
 // WV = 8 waves per workgroup (two per SIMD, <= 256 registers per lane); a wave owns 16 rows at a time.  Every variant
 // must be free of register spills AND of VGPR -> AGPR copies of the prefetch registers: a destination of an in-flight
@@ -169,6 +171,10 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
     const int blk = q >> 6, kb = blk / NT, nt = blk - kb * NT;
     wl[q] = (kb < KB && nt < ntiles) ? p.Wp[(kb * ntiles + nt) * 64 + (q & 63)] : u32x4{0u, 0u, 0u, 0u};
   }
+  // ... and the bias behind it (read back as two broadcast ds_read_b128 per lane and tile pair: eight scalar global
+  // loads per pair in the epilogue cost 25 % of the kernel)
+  float *bl = reinterpret_cast<float *>(wl + KBM * NT * 64);
+  for (int q = threadIdx.x; q < NT * 16; q += WV * 64) bl[q] = (p.bias && q < N) ? p.bias[q] : 0.f;
   __syncthreads();
 
   const long long tiles = (p.M + 15) >> 4;     // 16-row tiles, handed out wave by wave
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
   for (;;) {
     const long long next = tile + stride;
     const bool more = next < tiles;
-    if (more) issue(next, xn, mn);
+    if (more && !(p.dbg & 4)) issue(next, xn, mn);
 
     f32x4 acc[NT];
 #pragma unroll
@@ -230,21 +236,26 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
     int opaque = 0;
     asm volatile("" : "+s"(opaque));
     const u32x4 *wlane = wl + opaque + lane;
+    if (!(p.dbg & 1)) {
 #pragma unroll
-    for (int kb = 0; kb < KBM; ++kb) {
+      for (int kb = 0; kb < KBM; ++kb) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(wlane[(kb * NT + nt) * 64], xc[kb], acc[nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma_bf16(wlane[(kb * NT + nt) * 64], xc[kb], acc[nt]);
+      }
     }
 
     // epilogue: lane (li, g) holds, for tile pair p, channels 32 p + 8 g .. + 7 of row 16 tile + li
     const long long row = tile * 16 + li;
-    const bool rv = row < p.M;
+    const bool rv = row < p.M && !(p.dbg & 2);
     const long long rowc = rv ? row : (p.M - 1);
     auto finish = [&](float *v, int c0, int cnt) {      // cnt = 8 or 4 consecutive channels from c0 (all < N)
-      if (p.bias) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (c < cnt) v[c] += p.bias[c0 + c];
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bl + c0);
+        v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+        if (cnt == 8) {
+          const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bl + c0 + 4);
+          v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+        }
       }
       if (p.residual) {
         const unsigned short *rr = p.residual + rowc * N + c0;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
         if (c0 < N) {
           float v[8] = {acc[2 * pr][0], acc[2 * pr][1], acc[2 * pr][2], acc[2 * pr][3], 0.f, 0.f, 0.f, 0.f};
           if (p.out_f32 && c0 + 4 > N) {                // N % 4 != 0 (fc_out: N = 3), fp32 output only
-            if (p.bias) for (int c = 0; c < 4; ++c) if (c0 + c < N) v[c] += p.bias[c0 + c];
+            for (int c = 0; c < 4; ++c) v[c] += bl[c0 + c];
             if (p.relu_out) for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
             if (rv) for (int c = 0; c < 4; ++c) if (c0 + c < N) static_cast<float *>(p.Y)[rowc * N + c0 + c] = v[c];
           } else {
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
 
 template <int NT, int KBM>
 int launch_lin(const B16Params &p, hipStream_t st) {
-  const size_t lds = static_cast<size_t>(KBM) * NT * 1024;
+  const size_t lds = static_cast<size_t>(KBM) * NT * 1024 + static_cast<size_t>(NT) * 64;
   const long long cus = nsdp::num_cus();
   auto go = [&](auto kern, const char *name, int wv) -> int {
     const long long wg_tiles = (p.M + wv * 16 - 1) / (wv * 16);
@@ -354,7 +365,7 @@ struct Wg16Params {
 };
 int g_wg16_dbg = 0;
 
-constexpr int kWavesWg = 8;
+constexpr int kWavesWg = 16;      // 4 per SIMD (<= 128 registers): the phases of a slab are latency chains, more waves hide them
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
   unsigned char *rowimg = smem_raw + 2 * img * 16;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wn0 = (wave >> 2) * TN, wk0 = (wave & 3) * TK;      // this wave's output tiles, waves laid out 2 (n) x 4 (k)
+  const int wn0 = (wave >> 2) * TN, wk0 = (wave & 3) * TK;      // this wave's output tiles, waves laid out 4 (n) x 4 (k)
   constexpr int kThreads = kWavesWg * 64;
 
   const long long slab0 = static_cast<long long>(blockIdx.x) * p.slabs_per_wg;
@@ -636,6 +647,7 @@ int launch_wg16(const Wg16Params &p_in, int grid, hipStream_t st) {
 
 namespace nsdp {
 void debug_set_wg16(int value) { g_wg16_dbg = value; }
+void debug_set_lin16(int value) { g_lin16_dbg = value; }
 }  // namespace nsdp
 
 extern "C" {
@@ -683,7 +695,7 @@ int nsdp_linear_bf16(const void *X, const void *Wp, const float *bias, const voi
                "linear_bf16: all operands must be 16-byte aligned");
   B16Params p{static_cast<const unsigned short *>(X), static_cast<const u32x4 *>(Wp), bias,
               static_cast<const unsigned short *>(residual), static_cast<const unsigned short *>(mask),
-              static_cast<const unsigned short *>(out_mask), Y, M, N, K, relu_in, relu_out, out_f32};
+              static_cast<const unsigned short *>(out_mask), Y, M, N, K, relu_in, relu_out, out_f32, g_lin16_dbg};
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kLinearB16, st, 2.0 * M * N * K,
                           2.0 * static_cast<double>(M) * (K * (mask ? 2 : 1) + N * (1 + (residual ? 1 : 0) + (out_mask ? 1 : 0))) +
@@ -721,13 +733,11 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
   nsdp::prof::Scope scope(nsdp::prof::kWgradB16, st, 2.0 * M * N * K,
                           2.0 * static_cast<double>(M) * (N * (mask ? 2 : 1) + K));
   const int nt = (N + 15) / 16, kt = (K + 15) / 16;
-  const int tn = (nt + 1) / 2, tk = (kt + 3) / 4;       // per-wave tile block (waves 2 x 4)
-  // producer chunks (64 column pairs of one row group): 4 row groups x (chunks of dY + chunks of X) over 8 waves
-  const int chunks = 4 * (((N / 2) + 63) / 64 + ((K / 2) + 63) / 64);
+  const int tn = (nt + 3) / 4, tk = (kt + 3) / 4;       // per-wave tile block (waves 4 x 4)
+  // producer chunks (64 column pairs of one row group): 4 row groups x (chunks of dY + chunks of X) <= 16 = one per wave
   int rc;
-  if (tn <= 4 && tk <= 2 && chunks <= 8) rc = launch_wg16<4, 2, 1>(p, pl.grid, st);
-  else if (tn <= 7 && tk <= 4) rc = launch_wg16<7, 4, 2>(p, pl.grid, st);
-  else rc = launch_wg16<8, 4, 2>(p, pl.grid, st);
+  if (tn <= 2 && tk <= 2) rc = launch_wg16<2, 2, 1>(p, pl.grid, st);
+  else rc = launch_wg16<4, 4, 1>(p, pl.grid, st);
   if (rc) return rc;
   const long long nw = static_cast<long long>(N) * K, nb = db ? N : 0;
   hipLaunchKernelGGL(reduce_b16_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0, st, workspace,
