@@ -140,7 +140,7 @@ struct B16Params {
   long long M;
   int N, K;
   int relu_in, relu_out, out_f32;
-  int dbg;                         // ablation knob nsdp_debug_set(8, v): 1 no MFMA, 2 no stores, 4 no activation loads (timing only)
+  int dbg;                         // ablation knob nsdp_debug_set(8, v): 1 no MFMA, 2 no stores (timing only)
 };
 int g_lin16_dbg = 0;
 
@@ -185,24 +185,22 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
   // current tile, next tile (in flight during the MFMAs), and the next tile's mask: the mask is applied the moment
   // both have landed, so only one mask set is ever live
   u32x4 xc[KBM], xn[KBM], mn[MASK ? KBM : 1];
-#pragma unroll
-  for (int kb = 0; kb < KBM; ++kb) {       // k blocks beyond K are never loaded: they stay zero
-    xc[kb] = xn[kb] = u32x4{0u, 0u, 0u, 0u};
-    if constexpr (MASK) mn[kb] = u32x4{0u, 0u, 0u, 0u};
-  }
   auto issue = [&](long long t, u32x4 *x, u32x4 *m) {
     long long r = t * 16 + li;
     r = r < p.M ? r : (p.M - 1);
     const unsigned short *xr = p.X + r * K;
     const unsigned short *mr = MASK ? p.mask + r * K : nullptr;
+    // UNCONDITIONAL: every one of the KBM loads is issued, k blocks beyond K re-read in-row data (their weight fragments
+    // are zero).  A load under `if (kb < KB)` makes its destination a phi of "loaded" and "old value", and the register
+    // allocator then issues the load into a temporary and copies it to the home register straight away -- a copy of a
+    // register whose data has not arrived: the kernel silently computed with the PREVIOUS tile's rows
+    // (tests/test_no_inflight_spills.py scans the ISA for exactly this).
 #pragma unroll
     for (int kb = 0; kb < KBM; ++kb) {
-      if (kb < KB) {
-        int ko = kb * 32 + 8 * g;
-        ko = ko + 8 <= K ? ko : (K - 8);   // past the row end: re-read in-row data (the packed weights are zero there)
-        xload(x[kb], xr + ko);
-        if constexpr (MASK) xload(m[kb], mr + ko);
-      }
+      int ko = kb * 32 + 8 * g;
+      ko = ko + 8 <= K ? ko : (K - 8);   // past the row end: re-read in-row data (the packed weights are zero there)
+      xload(x[kb], xr + ko);
+      if constexpr (MASK) xload(m[kb], mr + ko);
     }
   };
   auto xwait = [&](u32x4 *x, u32x4 *m) {      // ... and the prologue on the operand (mask / ReLU on the raw halves)
@@ -226,7 +224,8 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
   for (;;) {
     const long long next = tile + stride;
     const bool more = next < tiles;
-    if (more && !(p.dbg & 4)) issue(next, xn, mn);
+    // (unconditional as well, for the same reason: the last tile prefetches itself again and drops the result)
+    issue(more ? next : tile, xn, mn);
 
     f32x4 acc[NT];
 #pragma unroll
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
         if (rv) *reinterpret_cast<u32x2 *>(yr) = o;
       }
     };
-    if (more) xwait(xn, mn);     // before the stores go out: vmcnt would otherwise also wait for them
+    xwait(xn, mn);               // before the stores go out: vmcnt would otherwise also wait for them
 #pragma unroll
     for (int pr = 0; pr < (NT + 1) / 2; ++pr) {
       if (2 * pr + 1 < ntiles) {                        // full pair

@@ -33,6 +33,12 @@ LIN = [  # (M, K, N, bias, relu_in, relu_out, residual, mask, out_mask, out_f32)
     (129, 24, 12, True, False, False, True, False, True, False),
     (70000, 128, 128, True, True, True, True, False, False, False),
 ]
+# every kernel variant (n tiles 4 / 8 / 13 / 16 x k blocks <= 4 / <= 8 x mask) with several tiles per wave: a prefetch
+# that delivers the wrong tile's rows shows up here (70 000 rows > 256 workgroups x 128 rows)
+for _n in (64, 128, 200, 256):
+    for _k in (128, 200):
+        for _m in (False, True):
+            LIN.append((70000, _k, _n, True, False, False, False, _m, False, False))
 
 
 @pytest.mark.parametrize("M,K,N,bias,relu_in,relu_out,res,mask,omask,f32", LIN)

@@ -95,3 +95,56 @@ def test_nothing_is_spilled_inside_the_mfma_regions():
             assert not bad, (src, lines[a][:80], bad[:3])
             checked += 1
     assert checked >= 20
+
+
+def _regs(line):
+    """All VGPR numbers an instruction line mentions (vN and v[a:b])."""
+    used = {int(x) for x in re.findall(r"\bv(\d+)\b", line)}
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+        used.update(range(int(a), int(b) + 1))
+    return used
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not available")
+def test_bf16_linear_never_touches_a_register_whose_hand_issued_load_is_in_flight():
+    """csrc/gemm_bf16.hip prefetches the next tile with `asm volatile` global_load_dwordx4 and makes the registers
+    usable with `s_waitcnt vmcnt(0)` asm statements.  Between the two NOTHING may read or write those registers -- not a
+    spill, not a v_mov the register allocator inserts at a loop back edge (that is how a register-ring version of the
+    weight-gradient kernel produced NaNs: copies of registers whose data had not arrived yet), not an AGPR parking."""
+    _, text = _asm(("gemm_bf16.hip", None))
+    lines = text.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*linear_bf16_kernel\w*:", l)]
+    assert len(starts) >= 16
+    for a, b in zip(starts, starts[1:] + [len(lines)]):
+        body = lines[a:b]
+        if any("s_endpgm" in l for l in body):
+            body = body[:max(i for i, l in enumerate(body) if "s_endpgm" in l) + 1]
+        assert not any("scratch_" in l for l in body), lines[a][:80]
+        inflight, in_asm, bad = set(), False, []
+        for l in body:
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith((";", ".")) or t.endswith(":"):
+                continue
+            if in_asm and t.startswith("global_load_dwordx4"):
+                inflight |= _regs(t.split(",")[0])
+                continue
+            if "s_waitcnt" in t and "vmcnt(0)" in t:
+                inflight.clear()
+                continue
+            # sources only: a k block beyond K is zeroed (a write) in the branch that does not load it, and this scan
+            # follows text order, not control flow
+            ops = t.split(None, 1)
+            srcs = ops[1].split(",", 1)[1] if len(ops) > 1 and "," in ops[1] else ""
+            hit = _regs(srcs) & inflight
+            dst = ops[1].split(",", 1)[0] if len(ops) > 1 else ""
+            if not ops[0].startswith(("s_", "global_store", "ds_write", "buffer_store")):
+                inflight -= _regs(dst)          # redefined (the zeroing of an unloaded k block): no longer a load destination
+            if hit:
+                bad.append(t + "   <- in flight: v" + ", v".join(map(str, sorted(hit))))
+        assert not bad, (lines[a][:80], bad[:3])

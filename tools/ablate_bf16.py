@@ -35,8 +35,7 @@ def t(fn, n=10):
 
 L = _lib.lib()
 print(f"linear {M} x {K} -> {N}")
-for dbg, name in [(0, "full"), (1, "no mfma"), (2, "no stores"), (4, "no loads"), (3, "loads only"), (5, "stores only"), (6, "mfma only"),
-                  (7, "loop only")]:
+for dbg, name in [(0, "full"), (1, "no mfma"), (2, "no stores"), (3, "loads only")]:
     L.nsdp_debug_set(8, dbg)
     print(f"  {name:12s} {t(lambda: hb.run(x, wp, N, None, None, None, None, False, False)):8.1f} us")
 L.nsdp_debug_set(8, 0)
