@@ -179,8 +179,6 @@ def main():
                     help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3) | "
                          "forward_eval (BASELINE config 2: eval forward, 8192 queries per shape) | dense_inference "
                          "(BASELINE config 5: eval, 100k queries per shape)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the whole train step (fwd + bwd + Adam) in one hipGraph and replay it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to exercise the multi-rank code path on a single GPU)")
     ap.add_argument("--force-reducer", action="store_true",
@@ -275,24 +273,7 @@ def main():
         torch.cuda.synchronize()
 
     run = infer_step if is_eval else step
-    graph = None
-    if args.graph and not is_eval and world == 1:
-        # whole-step capture: every kernel of the step (HIP library launches on the current stream, Adam's
-        # foreach kernels) goes into one hipGraph; needs a capturable optimizer and static input buffers
-        for g in optimizer.param_groups:
-            g["capturable"] = True
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            static_loss = step()
-        run = lambda: (graph.replay(), static_loss)[1]
+    graph = None     # (whole-step hipGraph replay was dropped: no gain at B = 32 or B = 8)
     # set-up, not part of the contract's W: the first steps of a fresh process also build the weight packs, grow the
     # caching allocator to its steady state and bring the GPU out of its idle power state (a cold first run was
     # measured 25 % slow with W = 3)
@@ -309,7 +290,7 @@ def main():
     # That extra pass also switches the weight-gradient side stream off: with it, an event pair on one stream also
     # spans the time the kernel waits for CUs held by the other stream.
     prof_iso = None
-    dominant = "linear_bf16x3_kernel"
+    dominant = "linear_bf16x3_kernel" if args.dtype == "f32" else "linear_bf16_kernel"
     if graph is None and not is_eval and world == 1:
         from nsdp_amd import hip_linear
         was = hip_linear._OVERLAP_WGRAD
@@ -382,7 +363,8 @@ def main():
             "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2) if args.workload == "forward_train" else None,
             "final_loss": round(final_loss, 6),
             "roofline": profiling.roofline(prof, prof_iso,
-                                           pmc_matches=(args.workload == "forward_train" and args.batch == 32)),
+                                           pmc_matches=(args.workload == "forward_train" and args.batch == 32
+                                                        and args.dtype == "f32")),
             "kernels": profiling.summary(prof_iso if prof_iso else prof),
             "kernels_from": ("2 untimed steps, every launch timed, weight gradients on the main stream" if prof_iso
                              else "timed region"),

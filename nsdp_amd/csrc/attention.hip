@@ -98,6 +98,11 @@ __device__ __forceinline__ void atomic_addq(float *row, int cq, int lpp, Quad v)
   atomicAdd(row + cq, v.x); atomicAdd(row + cq + lpp, v.y);
   atomicAdd(row + cq + 2 * lpp, v.z); atomicAdd(row + cq + 3 * lpp, v.w);
 }
+// Lane -> channel mapping of the two atomic (global scatter) backward kernels: the strided quad above for both storage
+// types.  (Measured for bf16: contiguous quads -- one 8-byte access per tensor and lane instead of four 2-byte ones --
+// make the loads cheaper but turn every fp32 atomic instruction into 64 words at a 16-byte stride: 1.15 ms instead of
+// 0.40 ms on the 2048-point block.  The atomics, not the loads, bound these kernels.)
+template <typename T> struct QuadMap { static constexpr bool kStrided = true; };
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float4 ld4(const bf16_t *p) {           // 4 channels = one 8-byte load
@@ -110,6 +115,40 @@ __device__ __forceinline__ void st4(bf16_t *p, float4 v) {
 }
 __device__ __forceinline__ void atomic_add4(float *p, float4 v) {
   atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+// contiguous-quad accessors (lane owns channels 4cq..4cq+3) for the LDS-table kernels: global traffic is
+// float4, the LDS adds tolerate the 4-way bank conflict (they are two orders of magnitude off the critical path)
+__device__ __forceinline__ Quad ldc(const float *row, int cq) {
+  const float4 v = *reinterpret_cast<const float4 *>(row + 4 * cq);
+  return Quad{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void stc(float *row, int cq, Quad v) {
+  *reinterpret_cast<float4 *>(row + 4 * cq) = make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ Quad ldc(const bf16_t *row, int cq) {
+  const float4 v = ld4(row + 4 * cq);
+  return Quad{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void stc(bf16_t *row, int cq, Quad v) { st4(row + 4 * cq, make_float4(v.x, v.y, v.z, v.w)); }
+__device__ __forceinline__ void atomic_addc(float *row, int cq, Quad v) {
+  atomicAdd(row + 4 * cq, v.x); atomicAdd(row + 4 * cq + 1, v.y);
+  atomicAdd(row + 4 * cq + 2, v.z); atomicAdd(row + 4 * cq + 3, v.w);
+}
+
+template <bool ST, typename P>
+__device__ __forceinline__ Quad ldQ(const P *row, int cq, int lpp) {
+  if constexpr (ST) return ldq(row, cq, lpp);
+  else return ldc(row, cq);
+}
+template <bool ST, typename P>
+__device__ __forceinline__ void stQ(P *row, int cq, int lpp, Quad v) {
+  if constexpr (ST) stq(row, cq, lpp, v);
+  else stc(row, cq, v);
+}
+template <bool ST>
+__device__ __forceinline__ void atQ(float *row, int cq, int lpp, Quad v) {
+  if constexpr (ST) atomic_addq(row, cq, lpp, v);
+  else atomic_addc(row, cq, v);
 }
 
 // u[b,i,j,c] = q[b,i,c] - kf[b,idx[b,i,j],c] + pos[b,i,j,c]
@@ -146,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T 
                                                            const int32_t *__restrict__ idx,
                                                            float *__restrict__ dq, float *__restrict__ dkf,
                                                            T *__restrict__ dpos_acc) {
+  constexpr bool ST = QuadMap<T>::kStrided;
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -163,27 +203,27 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T 
     Quad acc{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
-      const Quad g = ldq(dur + static_cast<long long>(j) * s.d, cq, lpp);
+      const Quad g = ldQ<ST>(dur + static_cast<long long>(j) * s.d, cq, lpp);
       acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-      atomic_addq(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
+      atQ<ST>(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
       if (par) {   // d(pos) += du while the row is in registers (saves the separate add kernel's re-read of du)
         T *pr = par + static_cast<long long>(j) * s.d;
-        const Quad o = ldq(pr, cq, lpp);
-        stq(pr, cq, lpp, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
+        const Quad o = ldQ<ST>(pr, cq, lpp);
+        stQ<ST>(pr, cq, lpp, Quad{o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w});
       }
     }
     if (s.qb) {
       if (b != qb_b) {
-        if (qb_b >= 0) atomic_addq(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
+        if (qb_b >= 0) atQ<ST>(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
         qb_acc = Quad{0.f, 0.f, 0.f, 0.f};
         qb_b = b;
       }
       qb_acc.x += acc.x; qb_acc.y += acc.y; qb_acc.z += acc.z; qb_acc.w += acc.w;
     } else {
-      stq(dq + pt * s.d, cq, lpp, acc);
+      stQ<ST>(dq + pt * s.d, cq, lpp, acc);
     }
   }
-  if (s.qb && qb_b >= 0) atomic_addq(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
+  if (s.qb && qb_b >= 0) atQ<ST>(dq + static_cast<long long>(qb_b) * s.d, cq, lpp, qb_acc);
 }
 
 #define NSDP_ONLINE_STEP(C)                      \
@@ -262,6 +302,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
     const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos,
     float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
+  constexpr bool ST = QuadMap<T>::kStrided;
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -277,41 +318,41 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     float *dvfb = (HAS_V && dvf) ? dvf + static_cast<long long>(b) * s.N * s.d : nullptr;   // null: scatter done elsewhere
     const int32_t *ip = idx + pt * s.k;
     const long long r0 = pt * s.k * s.d;
-    const Quad g = ldq(dy + pt * s.d, cq, lpp);
-    Quad yb = ldq(y + pt * s.d, cq, lpp);
+    const Quad g = ldQ<ST>(dy + pt * s.d, cq, lpp);
+    Quad yb = ldQ<ST>(y + pt * s.d, cq, lpp);
     if (residual) {
-      const Quad r = ldq(residual + pt * s.d, cq, lpp);
+      const Quad r = ldQ<ST>(residual + pt * s.d, cq, lpp);
       yb.x -= r.x; yb.y -= r.y; yb.z -= r.z; yb.w -= r.w;
     }
-    const Quad Lse = ldq(lse + pt * s.d, cq, lpp);
+    const Quad Lse = ldQ<ST>(lse + pt * s.d, cq, lpp);
 #pragma unroll 2
     for (int j = 0; j < s.k; ++j) {
       const long long rj = r0 + static_cast<long long>(j) * s.d;
-      const Quad av = ldq(a + rj, cq, lpp);
-      Quad sv = ldq(pos + rj, cq, lpp);
+      const Quad av = ldQ<ST>(a + rj, cq, lpp);
+      Quad sv = ldQ<ST>(pos + rj, cq, lpp);
       if (HAS_V) {
-        const Quad vv = ldq(vfb + static_cast<long long>(ip[j]) * s.d, cq, lpp);
+        const Quad vv = ldQ<ST>(vfb + static_cast<long long>(ip[j]) * s.d, cq, lpp);
         sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
       }
       const Quad ds{__expf(av.x - Lse.x) * g.x, __expf(av.y - Lse.y) * g.y, __expf(av.z - Lse.z) * g.z,
                     __expf(av.w - Lse.w) * g.w};
-      stq(da + rj, cq, lpp,
+      stQ<ST>(da + rj, cq, lpp,
           Quad{ds.x * (sv.x - yb.x), ds.y * (sv.y - yb.y), ds.z * (sv.z - yb.z), ds.w * (sv.w - yb.w)});
-      stq(dpos + rj, cq, lpp, ds);
-      if (HAS_V && dvfb) atomic_addq(dvfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, ds);
+      stQ<ST>(dpos + rj, cq, lpp, ds);
+      if (HAS_V && dvfb) atQ<ST>(dvfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, ds);
     }
     if (has_g) {
       if (b != gb) {
         if (gb >= 0) {
-          atomic_addq(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
-          atomic_addq(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
+          atQ<ST>(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
+          atQ<ST>(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
         }
         dag = Quad{0.f, 0.f, 0.f, 0.f};
         dvg = dag;
         gb = b;
       }
-      const Quad ag = ldq(a_g + static_cast<long long>(b) * s.d, cq, lpp);
-      const Quad vg = ldq(v_g + static_cast<long long>(b) * s.d, cq, lpp);
+      const Quad ag = ldQ<ST>(a_g + static_cast<long long>(b) * s.d, cq, lpp);
+      const Quad vg = ldQ<ST>(v_g + static_cast<long long>(b) * s.d, cq, lpp);
       const Quad ds{__expf(ag.x - Lse.x) * g.x, __expf(ag.y - Lse.y) * g.y, __expf(ag.z - Lse.z) * g.z,
                     __expf(ag.w - Lse.w) * g.w};
       dag.x += ds.x * (vg.x - yb.x); dag.y += ds.y * (vg.y - yb.y);
@@ -320,8 +361,8 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     }
   }
   if (has_g && gb >= 0) {
-    atomic_addq(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
-    atomic_addq(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
+    atQ<ST>(da_g + static_cast<long long>(gb) * s.d, cq, lpp, dag);
+    atQ<ST>(dv_g + static_cast<long long>(gb) * s.d, cq, lpp, dvg);
   }
 }
 
@@ -334,25 +375,6 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
 // every query of a shape hits (the decoder has 57 k (query, neighbour) pairs per anchor row).
 // ------------------------------------------------------------------------------------------------
 constexpr int kLdsThreads = 512;
-
-// contiguous-quad accessors (lane owns channels 4cq..4cq+3) for the LDS-table kernels: global traffic is
-// float4, the LDS adds tolerate the 4-way bank conflict (they are two orders of magnitude off the critical path)
-__device__ __forceinline__ Quad ldc(const float *row, int cq) {
-  const float4 v = *reinterpret_cast<const float4 *>(row + 4 * cq);
-  return Quad{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void stc(float *row, int cq, Quad v) {
-  *reinterpret_cast<float4 *>(row + 4 * cq) = make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ Quad ldc(const bf16_t *row, int cq) {
-  const float4 v = ld4(row + 4 * cq);
-  return Quad{v.x, v.y, v.z, v.w};
-}
-__device__ __forceinline__ void stc(bf16_t *row, int cq, Quad v) { st4(row + 4 * cq, make_float4(v.x, v.y, v.z, v.w)); }
-__device__ __forceinline__ void atomic_addc(float *row, int cq, Quad v) {
-  atomicAdd(row + 4 * cq, v.x); atomicAdd(row + 4 * cq + 1, v.y);
-  atomicAdd(row + 4 * cq + 2, v.z); atomicAdd(row + 4 * cq + 3, v.w);
-}
 
 struct BlockLane {
   bool active;

@@ -16,7 +16,11 @@ PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def _mfma_peak(name):
-    return PEAK_BF16X3_TFLOPS if "bf16x3" in name else PEAK_F32_MFMA_TFLOPS
+    if "bf16x3" in name:
+        return PEAK_BF16X3_TFLOPS
+    if "bf16" in name:                      # bf16-storage kernels: one bf16 MFMA product per multiply-add
+        return PEAK_BF16_MFMA_TFLOPS
+    return PEAK_F32_MFMA_TFLOPS
 
 _active = False
 
@@ -102,11 +106,13 @@ def roofline(prof, prof_isolated=None, pmc_matches=True):
 
 def _pmc_traffic(name):
     """HBM bytes per launch of `name` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r1_pmc_hbm.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
+    (profiles/r2_pmc_hbm.json, else r1: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the file is absent."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_pmc_hbm.json")
+    prof_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    path = next((os.path.join(prof_dir, f) for f in ("r2_pmc_hbm.json", "r1_pmc_hbm.json")
+                 if os.path.exists(os.path.join(prof_dir, f))), os.path.join(prof_dir, "r2_pmc_hbm.json"))
     try:
         with open(path) as f:
             pmc = json.load(f)
@@ -117,7 +123,7 @@ def _pmc_traffic(name):
         if not n:
             return {"traffic": None}
         total = (2.0 * sum(v[1] for v in fetch) + sum(v[1] for v in write)) * 1024.0
-        return {"traffic": round(total / n), "traffic_unit": "bytes/launch (PMC, profiles/r1_pmc_hbm.json)"}
+        return {"traffic": round(total / n), "traffic_unit": f"bytes/launch (PMC, profiles/{os.path.basename(path)})"}
     except Exception:
         return {"traffic": None}
 

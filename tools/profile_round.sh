@@ -10,6 +10,12 @@ python bench.py > gpurun_out/${tag}_bench_default.json 2> gpurun_out/${tag}_benc
 python bench.py --batch 8 --no-cpu-baseline > gpurun_out/${tag}_bench_b8.json 2>/dev/null
 python bench.py --workload arbitrary_train --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary.json 2>/dev/null
 python bench.py --workload dense_inference --no-cpu-baseline > gpurun_out/${tag}_bench_dense_inference.json 2>/dev/null
+python bench.py --workload forward_eval --no-cpu-baseline > gpurun_out/${tag}_bench_forward_eval.json 2>/dev/null
+python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_bench_forward_bf16.json 2>/dev/null
+python bench.py --dtype bf16 --workload arbitrary_train --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary_bf16.json 2>/dev/null
+python bench.py --dtype bf16 --batch 8 --no-cpu-baseline > gpurun_out/${tag}_bench_b8_bf16.json 2>/dev/null
+# the self-launch path: two ranks on this one GPU over gloo (the RCCL path needs a multi-GPU node: driver-run)
+python bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_2ranks_gloo.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o ${tag} -- \
   python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}.log 2>&1
@@ -22,5 +28,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 NSDP_WGRAD_STREAM=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -o s -- \
   python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1
+NSDP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_bf16 -o ${tag}_bf16 -- \
+  python $R/bench.py --dtype bf16 --workload arbitrary_train --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_bf16.log 2>&1
 ls $R/gpurun_out/prof_${tag} $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/pmc_sq
 tail -c 600 $R/gpurun_out/${tag}_bench_default.json

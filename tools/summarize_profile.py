@@ -26,7 +26,9 @@ def short(name):
 for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
                       ("_iso", "NSDP_WGRAD_STREAM=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                                "(weight gradients on the main stream: every duration is the kernel alone -- the profile "
-                               "that matches bench.py's `roofline`)")):
+                               "that matches bench.py's `roofline`)"),
+                      ("_bf16", "NSDP_WGRAD_STREAM=0 python bench.py --dtype bf16 --workload arbitrary_train --steps 5 "
+                                "--warmup 2 --no-cpu-baseline (BASELINE config 3: FlowArbitrary, bf16 storage)")):
     stats = os.path.join(root, "gpurun_out", f"prof_{tag}{suffix}", f"{tag}{suffix}_kernel_stats.csv")
     if not os.path.exists(stats):
         continue
@@ -36,7 +38,9 @@ for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseli
         f.write(f"# rocprofv3 --kernel-trace --stats ({tag}): {title}\n\n")
         # the decoder's kNN runs exactly once per train step: its call count is the number of steps in the trace
         # (set-up steps + warm-up + timed + the isolated roofline pass of bench.py)
-        nsteps = next((int(r["Calls"]) for r in rows if "fps_reg_kernel" in r["Name"]), 0)
+        nsteps = next((int(r["Calls"]) for r in rows if "fps_reg_kernel<256" in r["Name"]), 0)
+        if suffix == "_bf16":
+            nsteps //= 2          # FlowArbitrary runs two encoders per step
         per = f" = {total/1e6/nsteps:.1f} ms of kernel time per step" if nsteps else ""
         f.write(f"total kernel time {total/1e6:.1f} ms over {nsteps} train steps{per}, B=32 shapes\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
@@ -105,7 +109,9 @@ if os.path.exists(sq_path):
             busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(gui / 8.0 * 1024.0, 1.0)
             f.write(f"| `{k}` | {launches[k]} | {gui/1e6:.1f} | {100*busy:.1f} % | {100*v.get('SQ_WAIT_ANY',0)/wc:.0f} % | "
                     f"{100*v.get('SQ_WAIT_INST_ANY',0)/wc:.0f} % | {100*v.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f} % |\n")
-for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json"):
+for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json",
+             "bench_forward_eval.json", "bench_forward_bf16.json", "bench_arbitrary_bf16.json", "bench_b8_bf16.json",
+             "bench_2ranks_gloo.json"):
     src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
     if os.path.exists(src) and open(src).read().strip():
         open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
