@@ -212,12 +212,12 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
 /* bf16-storage variants of the BatchNorm kernels (x, addend, y, dy, dx bf16; statistics and affine parameters fp32). */
 int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
                        float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
-                       int *sync_counter, long long *num_batches_tracked, void *stream);
+                       long long *num_batches_tracked, void *stream);
 int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
                        const float *beta, long long R, int C, int relu, void *y, void *stream);
 int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, const void *addend, const float *mean,
                           const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
-                          float *dgamma, float *dbeta, float *workspace, int *sync_counter, void *stream);
+                          float *dgamma, float *dbeta, float *workspace, void *stream);
 
 /* K = 4 layers with bf16 storage (first layer of every position-encoding MLP: fp32 relative coordinates zero-padded
  * to 4 columns in, bf16 out; csrc/k4_bf16.hip).  W is the plain [N,4] fp32 matrix.  N % 8 == 0.
@@ -288,13 +288,11 @@ int nsdp_decoder_fused_fwd(const float *xyz_q, const float *anchors, const int32
 size_t nsdp_bn_workspace_bytes(int C);
 /* training statistics: mean[C], invstd[C] = 1/sqrt(biased var + eps); running_mean/var (may be NULL)
  * updated with `momentum` and the unbiased variance, exactly like nn.BatchNorm1d in training mode;
- * *num_batches_tracked (int64, may be NULL) += 1.  ONE launch: the workgroup that finishes last combines the partials
- * ("last workgroup finalizes").  `sync_counter`: a device int the caller zero-initialises ONCE and then only passes
- * along (calls that may run concurrently -- different streams -- need different counters); it is 0 again on return.
+ * *num_batches_tracked (device int64, may be NULL) += 1 (no kernel of its own for the counter).
  * Statistics are accumulated as shifted sums (pivot = row 0), so |mean| >> std does not cancel. */
 int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
-                  int *sync_counter, long long *num_batches_tracked, void *stream);
+                  long long *num_batches_tracked, void *stream);
 /* y = ((x + addend) - mean) * invstd * gamma + beta, then ReLU if relu */
 int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
                   const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream);
@@ -303,8 +301,7 @@ int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const 
  * terms when training != 0, plain gamma*invstd*dy' otherwise (eval: statistics are constants). */
 int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const float *addend,
                      const float *mean, const float *invstd, const float *gamma, long long R, int C,
-                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, int *sync_counter,
-                     void *stream);
+                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Kernel timing with HIP events on the launch stream (used by bench.py for the roofline object)

@@ -56,87 +56,12 @@ __device__ __forceinline__ float4 pivot4(const T *x, const T *addend, int c4) {
   return p;
 }
 
-// Column-wise combination of the per-workgroup partials by the finalizing workgroup: one thread per channel (C <= 1024:
-// up to four channels per thread), every load a coalesced row of the partial matrix, four independent double chains.
-__device__ __forceinline__ void combine_partials(const float *__restrict__ part, int nparts, int C, int c, double &s,
-                                                 double &q) {
-  double s4[4] = {0.0, 0.0, 0.0, 0.0}, q4[4] = {0.0, 0.0, 0.0, 0.0};
-  int p = 0;
-  for (; p + 4 <= nparts; p += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      s4[u] += part[static_cast<long long>(p + u) * 2 * C + c];
-      q4[u] += part[static_cast<long long>(p + u) * 2 * C + C + c];
-    }
-  }
-  for (; p < nparts; ++p) {
-    s4[0] += part[static_cast<long long>(p) * 2 * C + c];
-    q4[0] += part[static_cast<long long>(p) * 2 * C + C + c];
-  }
-  s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-}
-
-// "Last workgroup finalizes": the column-reduction kernels end with an agent-scope release of their partials, a ticket
-// from an atomic counter, and -- in the workgroup that drew the last ticket -- an acquire followed by the finalize that
-// used to be its own launch (70 of the 210 BatchNorm launches of a train step; the step's small layers are launch-bound).
-// The counter is a zero-initialised device int owned by the caller, reset here by the finalizing workgroup.
-__device__ __forceinline__ bool last_workgroup(int *counter) {
-  __shared__ int s_last;
-  __threadfence();                       // release: this workgroup's partials are visible device-wide
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == static_cast<int>(gridDim.x) - 1);
-  __syncthreads();
-  if (!s_last) return false;
-  __threadfence();                       // acquire: drop this CU's L1 copies before reading the others' partials
-  if (threadIdx.x == 0) *counter = 0;    // ready for the next call on this stream
-  return true;
-}
-
-// mean / invstd from the partials + running-statistics update
-// (momentum form of nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance for running_var)
-template <typename T>
-__device__ __forceinline__ void bn_finalize_channel(int c, const T *__restrict__ x, const T *__restrict__ addend,
-                                                    const float *__restrict__ part, int nparts, long long R, int C,
-                                                    float eps, float momentum, float *__restrict__ running_mean,
-                                                    float *__restrict__ running_var, float *__restrict__ mean,
-                                                    float *__restrict__ invstd) {
-  double s, q;
-  combine_partials(part, nparts, C, c, s, q);
-  const float4 pv4 = pivot4(x, addend, c >> 2);
-  const float pv = (c & 3) == 0 ? pv4.x : (c & 3) == 1 ? pv4.y : (c & 3) == 2 ? pv4.z : pv4.w;
-  const double ms = s / static_cast<double>(R);            // mean of the shifted values
-  double var = q / static_cast<double>(R) - ms * ms;
-  if (var < 0.0) var = 0.0;
-  const double m = static_cast<double>(pv) + ms;
-  mean[c] = static_cast<float>(m);
-  invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
-  if (running_mean) {
-    const double unbiased = R > 1 ? var * static_cast<double>(R) / static_cast<double>(R - 1) : var;
-    running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
-    running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
-}
-
-__device__ __forceinline__ void bn_bwd_finalize_channel(int c, const float *__restrict__ part, int nparts, int C,
-                                                        float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  double s, q;
-  combine_partials(part, nparts, C, c, s, q);
-  dbeta[c] = static_cast<float>(s);
-  dgamma[c] = static_cast<float>(q);
-}
-
 // column sums of (v - pivot) and (v - pivot)^2 (v = x [+ addend]) over this workgroup's row chunk -> part[blk][2][C]
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict__ x,
                                                             const T *__restrict__ addend, long long R,
                                                             int C, long long rows_per_blk,
-                                                            float *__restrict__ part, int *__restrict__ counter,
-                                                            float eps, float momentum,
-                                                            float *__restrict__ running_mean,
-                                                            float *__restrict__ running_var, float *__restrict__ mean,
-                                                            float *__restrict__ invstd,
-                                                            long long *__restrict__ num_batches_tracked) {
+                                                            float *__restrict__ part) {
   __shared__ float4 red[2][kThreads];
   const Geo g = geo(C);
   const int sub = threadIdx.x / g.lpr, cq = threadIdx.x - sub * g.lpr;
@@ -171,11 +96,57 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T *__restrict_
     *reinterpret_cast<float4 *>(o + 4 * threadIdx.x) = ts;
     *reinterpret_cast<float4 *>(o + C + 4 * threadIdx.x) = tq;
   }
-  if (!last_workgroup(counter)) return;
-  for (int c = threadIdx.x; c < C; c += kThreads)
-    bn_finalize_channel(c, x, addend, part, static_cast<int>(gridDim.x), R, C, eps, momentum, running_mean, running_var, mean,
-                        invstd);
-  if (num_batches_tracked && threadIdx.x == 0) *num_batches_tracked += 1;
+}
+
+// Column-wise combination of the per-workgroup partials: 16 lanes share one channel (each sums every
+// 16th partial in double, then a 4-step xor shuffle), so the serial chain is nparts/16 long instead of
+// nparts -- these finalize kernels sit on the critical path of 70 tiny launches per step.
+__device__ __forceinline__ void combine_partials(const float *__restrict__ part, int nparts, int C, int c,
+                                                 int sub16, double &s, double &q) {
+  s = 0.0;
+  q = 0.0;
+  if (c < C) {
+    for (int p = sub16; p < nparts; p += 16) {
+      s += part[static_cast<long long>(p) * 2 * C + c];
+      q += part[static_cast<long long>(p) * 2 * C + C + c];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+}
+
+// mean / invstd from the partials + running-statistics update
+// (momentum form of nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance for running_var)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const T *__restrict__ x, const T *__restrict__ addend,
+                                                          const float *__restrict__ part, int nparts, long long R,
+                                                          int C, float eps, float momentum,
+                                                          float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ mean,
+                                                          float *__restrict__ invstd,
+                                                          long long *__restrict__ num_batches_tracked) {
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub16 = threadIdx.x & 15;
+  double s, q;
+  combine_partials(part, nparts, C, c, sub16, s, q);
+  if (c >= C || sub16 != 0) return;
+  const float4 pv4 = pivot4(x, addend, c >> 2);
+  const float pv = (c & 3) == 0 ? pv4.x : (c & 3) == 1 ? pv4.y : (c & 3) == 2 ? pv4.z : pv4.w;
+  const double ms = s / static_cast<double>(R);            // mean of the shifted values
+  double var = q / static_cast<double>(R) - ms * ms;
+  if (var < 0.0) var = 0.0;
+  const double m = static_cast<double>(pv) + ms;
+  mean[c] = static_cast<float>(m);
+  invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+  if (running_mean) {
+    const double unbiased = R > 1 ? var * static_cast<double>(R) / static_cast<double>(R - 1) : var;
+    running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
+    running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
 }
 
 // y = ((x [+ addend]) - mean) * invstd * gamma + beta, optional ReLU
@@ -210,8 +181,7 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const T *__restrict__ dy, const T *__restrict__ y, const T *__restrict__ x,
     const T *__restrict__ addend, const float *__restrict__ mean, const float *__restrict__ invstd,
-    long long R, int C, long long rows_per_blk, float *__restrict__ part, int *__restrict__ counter,
-    float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    long long R, int C, long long rows_per_blk, float *__restrict__ part) {
   __shared__ float4 red[2][kThreads];
   const Geo g = geo(C);
   const int sub = threadIdx.x / g.lpr, cq = threadIdx.x - sub * g.lpr;
@@ -252,8 +222,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     *reinterpret_cast<float4 *>(o + 4 * threadIdx.x) = ts;
     *reinterpret_cast<float4 *>(o + C + 4 * threadIdx.x) = tq;
   }
-  if (!last_workgroup(counter)) return;
-  for (int c = threadIdx.x; c < C; c += kThreads) bn_bwd_finalize_channel(c, part, static_cast<int>(gridDim.x), C, dgamma, dbeta);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float *__restrict__ part, int nparts, int C,
+                                                              float *__restrict__ dgamma,
+                                                              float *__restrict__ dbeta) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int sub16 = threadIdx.x & 15;
+  double s, q;
+  combine_partials(part, nparts, C, c, sub16, s, q);
+  if (c >= C || sub16 != 0) return;
+  dbeta[c] = static_cast<float>(s);
+  dgamma[c] = static_cast<float>(q);
 }
 
 // dx = gamma * invstd * (dy' - dbeta/R - xhat * dgamma/R)   (training)
@@ -317,16 +297,16 @@ inline bool c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 1024; }
 
 template <typename T>
 int bn_stats_t(const T *x, const T *addend, long long R, int C, float eps, float momentum, float *running_mean,
-               float *running_var, float *mean, float *invstd, float *workspace, int *counter, long long *num_batches,
-               void *stream) {
+               float *running_var, float *mean, float *invstd, float *workspace, long long *num_batches, void *stream) {
   NSDP_REQUIRE(R > 0 && c_ok(C), "bn_stats: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
-  NSDP_REQUIRE(x && mean && invstd && workspace && counter, "bn_stats: null pointer");
+  NSDP_REQUIRE(x && mean && invstd && workspace, "bn_stats: null pointer");
   NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats go together");
   hipStream_t st = nsdp::as_stream(stream);
   const Plan p = plan(R, C);
   nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, sizeof(T) * 1.0 * R * C * (addend ? 2 : 1));
-  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk, workspace,
-                     counter, eps, momentum, running_mean, running_var, mean, invstd, num_batches);
+  hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk, workspace);
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 15) / 16), dim3(256), 0, st, x, addend, workspace, p.parts, R, C, eps,
+                     momentum, running_mean, running_var, mean, invstd, num_batches);
   return nsdp::launch_status("bn_stats_kernel");
 }
 
@@ -347,17 +327,17 @@ int bn_apply_t(const T *x, const T *addend, const float *mean, const float *invs
 template <typename T>
 int bn_backward_t(const T *dy, const T *y_relu, const T *x, const T *addend, const float *mean, const float *invstd,
                   const float *gamma, long long R, int C, int training, T *dx, float *dgamma, float *dbeta,
-                  float *workspace, int *counter, void *stream) {
+                  float *workspace, void *stream) {
   NSDP_REQUIRE(R > 0 && c_ok(C), "bn_backward: need R > 0 and C %% 4 == 0, C <= 1024");
-  NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace && counter,
-               "bn_backward: null pointer");
+  NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace, "bn_backward: null pointer");
   hipStream_t st = nsdp::as_stream(stream);
   const Plan p = plan(R, C);
   const long long total4 = R * (C >> 2);
   nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
                           sizeof(T) * 1.0 * R * C * (5.0 + (y_relu ? 2 : 0) + (addend ? 2 : 0)));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean, invstd, R,
-                     C, p.rows_per_blk, workspace, counter, dgamma, dbeta);
+                     C, p.rows_per_blk, workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, p.parts, C, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(total4)), dim3(kThreads), 0, st, dy, y_relu, x, addend, mean,
                      invstd, gamma, dgamma, dbeta, total4, C >> 2, 1.0f / static_cast<float>(R), training, dx);
   return nsdp::launch_status("bn_backward");
@@ -371,8 +351,8 @@ size_t nsdp_bn_workspace_bytes(int C) { return static_cast<size_t>(kMaxParts) * 
 
 int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
-                  int *sync_counter, long long *num_batches_tracked, void *stream) {
-  return bn_stats_t<float>(x, addend, R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace, sync_counter,
+                  long long *num_batches_tracked, void *stream) {
+  return bn_stats_t<float>(x, addend, R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace,
                            num_batches_tracked, stream);
 }
 int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
@@ -381,19 +361,17 @@ int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const 
 }
 int nsdp_bn_backward(const float *dy, const float *y_relu, const float *x, const float *addend,
                      const float *mean, const float *invstd, const float *gamma, long long R, int C,
-                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, int *sync_counter,
-                     void *stream) {
-  return bn_backward_t<float>(dy, y_relu, x, addend, mean, invstd, gamma, R, C, training, dx, dgamma, dbeta, workspace,
-                              sync_counter, stream);
+                     int training, float *dx, float *dgamma, float *dbeta, float *workspace, void *stream) {
+  return bn_backward_t<float>(dy, y_relu, x, addend, mean, invstd, gamma, R, C, training, dx, dgamma, dbeta, workspace, stream);
 }
 
 // bf16-storage variants: x, addend, y, dy, dx are bf16 tensors; statistics / affine parameters / their gradients fp32
 #define B16(p) reinterpret_cast<const bf16_t *>(p)
 int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
                        float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
-                       int *sync_counter, long long *num_batches_tracked, void *stream) {
+                       long long *num_batches_tracked, void *stream) {
   return bn_stats_t<bf16_t>(B16(x), B16(addend), R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace,
-                            sync_counter, num_batches_tracked, stream);
+                            num_batches_tracked, stream);
 }
 int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
                        const float *beta, long long R, int C, int relu, void *y, void *stream) {
@@ -401,9 +379,9 @@ int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, con
 }
 int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, const void *addend, const float *mean,
                           const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
-                          float *dgamma, float *dbeta, float *workspace, int *sync_counter, void *stream) {
+                          float *dgamma, float *dbeta, float *workspace, void *stream) {
   return bn_backward_t<bf16_t>(B16(dy), B16(y_relu), B16(x), B16(addend), mean, invstd, gamma, R, C, training,
-                               reinterpret_cast<bf16_t *>(dx), dgamma, dbeta, workspace, sync_counter, stream);
+                               reinterpret_cast<bf16_t *>(dx), dgamma, dbeta, workspace, stream);
 }
 #undef B16
 

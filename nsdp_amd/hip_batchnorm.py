@@ -29,19 +29,6 @@ _ci = ctypes.c_int
 _cf = ctypes.c_float
 
 
-_counters = {}
-
-
-def _counter(device):
-    """The per-device, zero-initialised sync counter of the "last workgroup finalizes" reductions (self-resetting;
-    BatchNorm calls of one process all run on the main stream of their device)."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    c = _counters.get(key)
-    if c is None:
-        c = _counters[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return c
-
-
 def _ws(C, device):
     L = lib()
     L.nsdp_bn_workspace_bytes.restype = ctypes.c_size_t
@@ -70,8 +57,7 @@ class _BatchNormFn(torch.autograd.Function):
                 invstd = torch.empty(C, dtype=torch.float32, device=dev)
                 check(_fn("nsdp_bn_stats", dt)(_p(x2, dt, "x"), _p(a2, dt, "addend"), _ll(R), _ci(C), _cf(eps), _cf(momentum),
                                                optptr(running_mean), optptr(running_var), fptr(mean), fptr(invstd),
-                                               fptr(_ws(C, dev)), ctypes.c_void_p(_counter(dev).data_ptr()), optptr(nbt),
-                                               stream_ptr()), "nsdp_bn_stats")
+                                               fptr(_ws(C, dev)), optptr(nbt), stream_ptr()), "nsdp_bn_stats")
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)
@@ -99,8 +85,7 @@ class _BatchNormFn(torch.autograd.Function):
         with on_device(dy2):
             check(_fn("nsdp_bn_backward", dt)(_p(dy2, dt, "dy"), _p(y, dt), _p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd),
                                               fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), _p(dx, dt), fptr(dgamma),
-                                              fptr(dbeta), fptr(_ws(C, dev)), ctypes.c_void_p(_counter(dev).data_ptr()),
-                                              stream_ptr()), "nsdp_bn_backward")
+                                              fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
         dx = dx.reshape(ctx.shape)
         return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None, None
 
@@ -111,7 +96,7 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
     counts = bn.training and bn.track_running_stats
     nbt = None
     if counts and bn.momentum is not None and bn.num_batches_tracked.is_cuda:
-        nbt = bn.num_batches_tracked          # incremented by the statistics kernel (35 tiny add kernels per step otherwise)
+        nbt = bn.num_batches_tracked          # incremented by the finalize kernel (35 tiny add kernels per step otherwise)
     elif counts:
         bn.num_batches_tracked.add_(1)
     rm = bn.running_mean if bn.track_running_stats else None
