@@ -35,13 +35,23 @@ def _fn(name, dtype):
 class _PosGrad:
     """Hand-over of d(pos) between the two halves of one attention block.  `pos` feeds the logits (attn_pre) and the
     values (attn_post); in the backward pass attn_post runs first (attn_pre's gradient depends on it through the
-    gamma MLP), parks its d(pos) here and reports no gradient for `pos`; attn_pre then adds d(u) to it inside its
-    kernel and returns the sum.  Without this autograd sums the two with an elementwise add over the largest tensor
-    of the block."""
-    __slots__ = ("dpos",)
+    gamma MLP), parks its d(pos) here and reports no gradient for `pos`.
+
+    With ``grad_sum`` (a hip_linear.InputGradSum shared with the FIRST layer of the gamma MLP, the only consumer of `u`)
+    the sum d(pos) = d(u) + d(pos)|values costs no pass of its own: attn_post's d(pos) becomes the `residual` operand of
+    that layer's dX GEMM, which therefore produces the TOTAL and hands it to attn_pre's backward as "d(u)".  attn_pre
+    then only scatters (one read of the [B,n,k,d] tensor instead of a read-modify-write of a second one) and corrects
+    by linearity:  scatter(d(u)) = scatter(total) - scatter(d(pos)|values) = scatter(total) - dvf,  and the row sums the
+    same way (sum_j d(pos)|values_ij = dy_i for a softmax over the neighbours; sum over a shape = sum_a dvf[a]).
+    Without ``grad_sum`` attn_pre's kernel adds d(u) into the parked tensor (the round-1 form)."""
+    __slots__ = ("dpos", "grad_sum", "dvf", "dy", "fused")
 
     def __init__(self):
         self.dpos = None
+        self.grad_sum = None      # InputGradSum of the gamma MLP's first layer (set by ops.vector_attention)
+        self.dvf = None           # fp32 scatter of attn_post's d(pos) = its dvf
+        self.dy = None            # upstream gradient of attn_post (per-point correction of dq)
+        self.fused = False        # attn_post's backward has run and primed grad_sum.buf
 
 
 class _AttnPre(torch.autograd.Function):
@@ -73,11 +83,22 @@ class _AttnPre(torch.autograd.Function):
         dq = torch.empty((B, 1 if qb else n, d), dtype=torch.float32, device=du.device)
         dkf = torch.empty((B, N, d), dtype=torch.float32, device=du.device)
         acc = None
-        if ctx.link is not None:
-            acc, ctx.link.dpos = ctx.link.dpos, None
+        link = ctx.link
+        fused = link is not None and link.fused
+        if link is not None and not fused:
+            acc, link.dpos = link.dpos, None
         with on_device(du):
             check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
                                                fptr(dq), fptr(dkf), _p(acc, dt, "dpos"), stream_ptr()), "nsdp_attn_pre_bwd")
+        if fused:
+            # `du` is the total d(pos) (see _PosGrad): undo the value path's share in the two small outputs
+            dkf.add_(link.dvf)
+            if qb:
+                dq.sub_(link.dvf.sum(1, keepdim=True))
+            else:
+                dq.sub_(link.dy.reshape(dq.shape))
+            link.dvf = link.dy = None
+            link.fused = False
         if dt is BF16:           # (scatter / reduction outputs are produced in fp32; the tables are small)
             dq, dkf = dq.to(BF16), dkf.to(BF16)
         return dq, dkf, (du if acc is None else acc), None, None
@@ -125,12 +146,18 @@ class _AttnPost(torch.autograd.Function):
                                                 _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B), _ci(n), _ci(N),
                                                 _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(dvf), optptr(da_g),
                                                 optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+        link = ctx.link
+        if link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None:
+            link.grad_sum.buf = dpos.reshape(-1, d)         # residual of the gamma MLP's first dX GEMM
+            link.dvf, link.dy, link.fused = dvf, dy, True
         if dt is BF16:
             dvf = None if dvf is None else dvf.to(BF16)
             da_g = None if da_g is None else da_g.to(BF16)
             dv_g = None if dv_g is None else dv_g.to(BF16)
-        if ctx.link is not None and ctx.needs_input_grad[2]:
-            ctx.link.dpos, dpos = dpos, None          # attn_pre's backward adds d(u) and reports the sum
+        if link is not None and link.fused:
+            dpos = None                               # travels as the dX GEMM's residual; attn_pre reports the total
+        elif link is not None and ctx.needs_input_grad[2]:
+            link.dpos, dpos = dpos, None              # attn_pre's backward adds d(u) and reports the sum
         return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None
 
 
@@ -145,6 +172,11 @@ NATIVE_BF16 = True        # bf16-storage kernels (False: cast around the fp32 on
 
 def _f(t):
     return None if t is None else (t if t.dtype is torch.float32 else t.float())
+
+
+def native(t):
+    """Does this tensor's storage type go to the kernels directly (not through the cast-reference path)?"""
+    return t.dtype is torch.float32 or NATIVE_BF16
 
 
 def attn_pre(q, kf, pos, idx, link=None):

@@ -6,6 +6,8 @@ B*n rows are identical).  Index tensors are int32 ``[B, n, k]`` produced by the 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -117,7 +119,7 @@ def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, resi
                              params=True, grad_sum=grad_sum, out_f32=out_f32)
 
 
-def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
+def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
     """nn.Sequential(Linear, ReLU, Linear) (fc_delta / fc_gamma / fc_middle).
     bf16 storage: the ReLU is the SECOND layer's fused input ReLU (the tensor in between holds the pre-activation): same
     values, but in the backward pass the second layer's dX epilogue applies the ReLU mask once, and neither the first
@@ -125,8 +127,8 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential) -> torch.Tensor:
     fp32 storage keeps the ReLU in the first layer's epilogue: the bf16x3 GEMM's ReLU prologue costs more than the mask
     operand it saves (measured: +1.9 ms of GEMM time per B = 32 step against -1.2 ms of weight-gradient time)."""
     if precision.is_bf16():
-        return linear(linear(x, seq[0]), seq[2], relu_in=True)
-    return linear(linear(x, seq[0], relu=True), seq[2])
+        return linear(linear(x, seq[0], grad_sum=grad_sum), seq[2], relu_in=True)
+    return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum), seq[2])
 
 
 def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = False) -> torch.Tensor:
@@ -142,6 +144,8 @@ def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = Fa
 # ---------------------------------------------------------------------------------------------
 # point-transformer vector attention
 # ---------------------------------------------------------------------------------------------
+FUSE_DPOS = os.environ.get("NSDP_FUSE_DPOS", "1") != "0"     # (A/B knob: 0 = attn_pre_bwd accumulates d(pos) itself)
+
 def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None):
     """sum_j softmax_j[gamma(q_i - kf[idx_ij] + delta(rel_ij))] * (vf[idx_ij] + delta(rel_ij)) (+ residual),
     softmax over the neighbour axis independently per channel (vector attention).
@@ -157,8 +161,11 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         logits = mlp2(pos, fc_gamma)
         out = hip_attention.attn_post(logits, None, pos, idx, residual=residual)
     else:
-        link = hip_attention.pos_grad_link() if pos.requires_grad else None   # d(pos) summed inside attn_pre_bwd
+        link = hip_attention.pos_grad_link() if pos.requires_grad else None
+        if link is not None and FUSE_DPOS and hip_attention.native(pos):
+            # d(pos) = d(u) + d(pos)|values is formed by the gamma MLP's first dX GEMM (residual operand), see _PosGrad
+            link.grad_sum = hip_linear.InputGradSum()
         u = hip_attention.attn_pre(q, kf, pos, idx, link)      # q_i - kf[idx] + pos, gather fused
-        logits = mlp2(u, fc_gamma)
+        logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link)
     return out, pos
