@@ -606,7 +606,7 @@ WgPlan plan_wg16(long long M, int N, int K) {
   WgPlan pl;
   const long long slabs = (M + 31) >> 5;
   long long grid = nsdp::num_cus();
-  if (grid > slabs / 4) grid = slabs / 4 > 0 ? slabs / 4 : 1;       // at least 4 slabs per workgroup (pipeline depth)
+  if (grid > slabs / 4) grid = slabs / 4 > 0 ? slabs / 4 : 1;       // at least 4 slabs per workgroup (2: slower at B = 8)
   pl.slabs_per_wg = static_cast<int>((slabs + grid - 1) / grid);
   pl.grid = static_cast<int>((slabs + pl.slabs_per_wg - 1) / pl.slabs_per_wg);
   pl.ws_floats = static_cast<size_t>(pl.grid) * (static_cast<size_t>(N) * K + N);

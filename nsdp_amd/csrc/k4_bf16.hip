@@ -201,7 +201,8 @@ int nsdp_linear_wgrad_k4_bf16(const void *dY, const float *X, const void *mask, 
   NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_k4_bf16_workspace_bytes(M, N), "linear_wgrad_k4_bf16: workspace too small");
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kWgradB16, st, 8.0 * M * N, static_cast<double>(M) * (16.0 + (mask ? 4.0 : 2.0) * N));
-  const int grid = k4_grid(M, N);
+  int grid = k4_grid(M, N);
+  if (grid > nsdp::num_cus()) grid = nsdp::num_cus();      // one partial per workgroup: keep the final reduce short
   const int slots = 256 / (N >> 3);
   long long per = (M + grid - 1) / grid;
   per = (per + slots - 1) / slots * slots;

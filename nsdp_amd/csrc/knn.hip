@@ -89,10 +89,117 @@ __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ quer
   }
 }
 
+// Several lanes per query.  With one lane per query the kernel is one wave per SIMD at the encoder's sizes (2048
+// queries x 32 shapes = 1024 waves) and the wave-level insertion branch fires in most iterations (any of 64 lanes
+// improving runs the unrolled shift for all): 313 us per launch whatever the batch.  Here S lanes share a query, lane s
+// scans every S-th part of each LDS tile with its own sorted top-K, and the S lists are merged through LDS by
+// (distance, index) -- the same total order, S times the waves, 1/S of the iterations per wave.
+template <int K, int S>
+__global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict__ query_all,
+                                                        const float *__restrict__ source_all, int n, int m, int k,
+                                                        int32_t *__restrict__ idx_all, float *__restrict__ dist_all) {
+  __shared__ float4 tile[kTile];
+  __shared__ float md[256 * K];
+  __shared__ int mi[256 * K];
+  constexpr int kQ = 256 / S;                    // queries per workgroup
+  const int b = blockIdx.y;
+  const float *query = query_all + static_cast<size_t>(b) * n * 3;
+  const float *source = source_all + static_cast<size_t>(b) * m * 3;
+  const int ql = threadIdx.x / S, sub = threadIdx.x - ql * S;   // S consecutive lanes share a query
+  const int i = blockIdx.x * kQ + ql;
+  const bool active = i < n;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active) {
+    qx = query[i * 3 + 0]; qy = query[i * 3 + 1]; qz = query[i * 3 + 2];
+  }
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    bd[t] = FLT_MAX;
+    bi[t] = 0x7fffffff;
+  }
+  for (int base = 0; base < m; base += kTile) {
+    const int cnt = min(kTile, m - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+      const float *p = source + static_cast<size_t>(base + t) * 3;
+      tile[t] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    __syncthreads();
+    const int per = (cnt + S - 1) / S;           // lane `sub` scans tile entries [sub * per, (sub + 1) * per)
+    const int t0 = sub * per, t1 = min(cnt, t0 + per);
+    for (int t = t0; t < t1; ++t) {
+      const float4 sp = tile[t];
+      const float d = nsdp::sq_dist3(qx, qy, qz, sp.x, sp.y, sp.z);
+      if (d < bd[K - 1]) {
+        const int j = base + t;
+#pragma unroll
+        for (int u = K - 1; u > 0; --u) {
+          const bool shift = d < bd[u - 1];
+          const bool here = !shift && d < bd[u];
+          const float nd = shift ? bd[u - 1] : (here ? d : bd[u]);
+          const int ni = shift ? bi[u - 1] : (here ? j : bi[u]);
+          bd[u] = nd;
+          bi[u] = ni;
+        }
+        if (d < bd[0]) {
+          bd[0] = d;
+          bi[0] = j;
+        }
+      }
+    }
+  }
+  // A lane's list is ascending in (distance, index): strict `<` keeps the earlier (lower) index first on ties, and a
+  // lane meets its candidates in increasing index order.  S-way merge by (distance, index) on lane 0 of the query.
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    md[threadIdx.x * K + t] = bd[t];
+    mi[threadIdx.x * K + t] = bi[t];
+  }
+  __syncthreads();
+  if (active && sub == 0) {
+    int head[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) head[u] = 0;
+    int32_t *io = idx_all + (static_cast<size_t>(b) * n + i) * k;
+    float *dout = dist_all ? dist_all + (static_cast<size_t>(b) * n + i) * k : nullptr;
+    for (int t = 0; t < k; ++t) {
+      float best_d = FLT_MAX;
+      int best_i = 0x7fffffff, best_u = 0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int h = head[u];
+        const float dd = h < K ? md[(threadIdx.x + u) * K + h] : FLT_MAX;
+        const int ii = h < K ? mi[(threadIdx.x + u) * K + h] : 0x7fffffff;
+        if (dd < best_d || (dd == best_d && ii < best_i)) {
+          best_d = dd; best_i = ii; best_u = u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < S; ++u) head[u] += (u == best_u) ? 1 : 0;
+      io[t] = best_i;
+      if (dout) dout[t] = best_d;
+    }
+  }
+}
+
 template <int K>
 int launch(const float *q, const float *s, int B, int n, int m, int k, int32_t *idx, float *d2,
            hipStream_t st) {
+  // enough queries to fill the chip with one lane each (the decoder: 8192 queries per shape), or a cloud too small to
+  // split: the one-lane-per-query form
+  const long long waves = (static_cast<long long>(n) + 255) / 256 * 4 * B;
+  if constexpr (K <= 16) {
+    if (m >= 256 && waves < 8LL * nsdp::num_cus()) {
+      dim3 grid(nsdp::ceil_div(n, 64), B);
+      NSDP_TRACE("knn_split<%d,4>", K);
+      hipLaunchKernelGGL((knn_split_kernel<K, 4>), grid, dim3(256), 0, st, q, s, n, m, k, idx, d2);
+      return nsdp::launch_status("knn_split_kernel");
+    }
+  }
   dim3 grid(nsdp::ceil_div(n, 256), B);
+  NSDP_TRACE("knn<%d>", K);
   hipLaunchKernelGGL((knn_kernel<K>), grid, dim3(256), 0, st, q, s, n, m, k, idx, d2);
   return nsdp::launch_status("knn_kernel");
 }
