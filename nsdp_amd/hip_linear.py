@@ -501,22 +501,23 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if precision.is_bf16():
         from . import hip_linear_bf16 as hb
         K, N = x.shape[-1], w2.shape[0]
-        if x.dtype is torch.bfloat16 and 8 <= K <= 256 and K % 8 == 0 and N <= 256 and (out_f32 or N % 4 == 0):
+        if (hb.NATIVE and x.dtype is torch.bfloat16 and 8 <= K <= 256 and K % 8 == 0 and N <= 256
+                and (out_f32 or N % 4 == 0)):
             if residual is not None and residual.dtype is not torch.bfloat16:
                 residual = residual.to(torch.bfloat16)
             return hb.linear(x, weight, bias, relu_in, relu_out, residual, w_param, b_param, grad_sum, owner, out_f32)
-        if not out_f32 and grad_sum is None and hb.k4_supported(x, N, relu_in, residual):
+        if hb.NATIVE and not out_f32 and grad_sum is None and hb.k4_supported(x, N, relu_in, residual):
             return hb.linear_k4(x, weight, bias, relu_out, w_param, b_param)       # fp32 coordinates in, bf16 out
         # the other narrow ends of the network (enc_sdf's 4 / 7 input features): fp32 kernels, result rounded to bf16
-        if grad_sum is not None:
+        if grad_sum is not None and hb.NATIVE:
             raise ValueError("InputGradSum needs a bf16 layer in bf16 storage mode")
         xf = x if x.dtype is torch.float32 else x.float()
         rf = residual if (residual is None or residual.dtype is torch.float32) else residual.float()
         if w_param is not None:
             y = _LinearFn.apply(xf, w2.detach(), None if bias is None else bias.detach(), rf, bool(relu_in),
-                                bool(relu_out), w_param, b_param, None)
+                                bool(relu_out), w_param, b_param, grad_sum)
         else:
-            y = _LinearFn.apply(xf, w2, bias, rf, bool(relu_in), bool(relu_out), None, None, None, owner)
+            y = _LinearFn.apply(xf, w2, bias, rf, bool(relu_in), bool(relu_out), None, None, grad_sum, owner)
         return y if out_f32 else y.to(torch.bfloat16)
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd

@@ -17,6 +17,8 @@ from ._lib import check, fptr, hptr, lib, on_device, opthptr, optptr, stream_ptr
 _ll = ctypes.c_longlong
 _ci = ctypes.c_int
 BF16 = torch.bfloat16
+NATIVE = True     # False: every layer through the fp32 kernels on casts, results rounded to bf16 (the reference semantics
+                  # of bf16 storage that tests compare the native kernels with)
 
 
 def supported(N, K):

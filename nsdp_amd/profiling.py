@@ -134,14 +134,20 @@ def _roofline_one(name, v):
     bytes_per_launch = v["bytes"] / v["launches"]
     intensity = flops_per_launch / max(bytes_per_launch, 1.0)
     peak = _mfma_peak(name)
+    both = {}
+    if flops_per_launch > 0 and bytes_per_launch > 0:
+        # both sides of the roofline, whichever bounds: the 200-wide bf16x3 layers sit AT the ridge (50 flop/B against 52)
+        both = {"frac_hbm": round(bytes_per_launch / (per_launch_ms * 1e6) / PEAK_HBM_GBPS, 4),
+                "frac_mfma": round(flops_per_launch / (per_launch_ms * 1e9) / peak, 4),
+                "mfma_peak_tflops": round(peak, 1), "flop_per_byte": round(intensity, 1)}
     if intensity > peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
         achieved = flops_per_launch / (per_launch_ms * 1e9)
         return {"kernel": name, "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
                 "algorithmic_bytes": round(bytes_per_launch), "launches": v["launches"],
-                "avg_launch_ms": round(per_launch_ms, 4)}
+                "avg_launch_ms": round(per_launch_ms, 4), **both}
     achieved = bytes_per_launch / (per_launch_ms * 1e6)
     return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBPS, 4), "traffic": None,
             "algorithmic_bytes": round(bytes_per_launch), "launches": v["launches"],
-            "avg_launch_ms": round(per_launch_ms, 4)}
+            "avg_launch_ms": round(per_launch_ms, 4), **both}
