@@ -219,6 +219,15 @@ int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, con
                           const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
                           float *dgamma, float *dbeta, float *workspace, void *stream);
 
+/* Scatter as a GEMM (bf16 storage): table[b][a][c] = sum over the rows r of shape b with idx[b][r] == a of src[b][r][c],
+ * computed as one-hot(idx)^T x src on the matrix cores (exact: 1.0 x bf16, fp32 accumulation; no atomics, deterministic).
+ * src (B, rows, d) bf16, idx (B, rows) int32 in [0, N), table (B, N, d) fp32 (overwritten).  N even, <= 128; d % 8 == 0.
+ * Used for the decoder's 100-anchor tables (dvf, dkf); nsdp_attn_post_bwd_bf16 accepts dvf == NULL with vf != NULL for
+ * that (it then only streams). */
+size_t nsdp_scatter_rows_onehot_bf16_workspace_bytes(int B, long long rows, int N, int d);
+int nsdp_scatter_rows_onehot_bf16(const void *src, const int32_t *idx, int B, long long rows, int N, int d, float *table,
+                                  float *workspace, size_t workspace_bytes, void *stream);
+
 /* K = 4 layers with bf16 storage (first layer of every position-encoding MLP: fp32 relative coordinates zero-padded
  * to 4 columns in, bf16 out; csrc/k4_bf16.hip).  W is the plain [N,4] fp32 matrix.  N % 8 == 0.
  * dX of such a layer is an nsdp_linear_bf16 call with 4 outputs. */

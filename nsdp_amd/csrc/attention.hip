@@ -295,14 +295,15 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const T
 //   da_j = w_j dy (s_j - yb);  ds_j = w_j dy  (written to dpos, scattered into dvf)
 //   global token: da_g += sum_i w_g dy (v_g - yb), dv_g += sum_i w_g dy   (register partial sums over the
 //   wave's points, one atomic per lane and shape)
-template <typename T, bool HAS_V>
+// ST: strided-quad lane -> channel mapping (needed when the kernel scatters with atomics); false = contiguous quads (one
+// 8 / 16-byte access per tensor and lane): the pure-stream form used when the caller scatters d(pos) itself
+template <typename T, bool HAS_V, bool ST = true>
 __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     AttnShape s, const T *__restrict__ dy, const T *__restrict__ a, const T *__restrict__ vf,
     const T *__restrict__ pos, const int32_t *__restrict__ idx, const T *__restrict__ a_g,
     const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
     const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos,
     float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
-  constexpr bool ST = QuadMap<T>::kStrided;
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -747,14 +748,15 @@ int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const in
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_post_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(dy && a && pos && idx && y && lse && da && dpos, "attn_post_bwd: null pointer");
-  NSDP_REQUIRE((vf == nullptr) == (dvf == nullptr), "attn_post_bwd: vf and dvf go together");
+  NSDP_REQUIRE(vf != nullptr || dvf == nullptr, "attn_post_bwd: dvf without vf");
+  // (vf without dvf: the caller scatters d(pos) itself -- nsdp_scatter_rows_onehot_bf16 -- and this call is a pure stream)
   NSDP_REQUIRE((a_g == nullptr) == (da_g == nullptr) && (a_g == nullptr) == (v_g == nullptr) &&
                    (a_g == nullptr) == (dv_g == nullptr),
                "attn_post_bwd: global-token pointers go together");
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           kEl * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + (vf ? 2.0 * N : 0)) * d));
   const bool has_v = vf != nullptr;
-  if (lds_table_fits(s) && has_v) {
+  if (lds_table_fits(s) && has_v && dvf) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
     if (const int rc = allow_big_lds(attn_post_bwd_lds_kernel<T, true>, lds, "attn_post_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
@@ -764,6 +766,12 @@ int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const in
     hipLaunchKernelGGL((attn_post_bwd_lds_kernel<T, true>), grid, dim3(kLdsThreads), lds, st, sl, dy, a, vf, pos,
                        idx, a_g, v_g, y, residual, lse, da, dpos, dvf, da_g, dv_g);
     return nsdp::launch_status("attn_post_bwd_lds_kernel");
+  }
+  if (has_v && !dvf) {
+    NSDP_TRACE("attn_post_bwd_stream");
+    hipLaunchKernelGGL((attn_post_bwd_kernel<T, true, false>), attn_grid(s), dim3(256), 0, st, s, dy, a, vf, pos, idx, a_g, v_g,
+                       y, residual, lse, da, dpos, dvf, da_g, dv_g);
+    return nsdp::launch_status("attn_post_bwd_kernel");
   }
   NSDP_TRACE("attn_post_bwd_atomic");
   NSDP_ATTN_LAUNCH_V(attn_post_bwd_kernel, has_v, s, dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, da, dpos,

@@ -382,16 +382,27 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 //  * History: register-staged versions of this kernel were VALU-bound on per-lane 64-bit addresses (2.2 TB/s), and a
 //    register ring with counted waits is unsafe in a loop (the register allocator swaps ring slots with v_mov across
 //    the back edge -- copies of registers whose loads are still in flight).
-template <int TN, int TK, int TASKS, bool MASK>
+// MODE 0: dW = dY^T X.  MODE 1: dY masked by (mask > 0).
+// MODE 2 ("scatter as a GEMM"): the dY operand is the ONE-HOT matrix of a row -> table-row index, generated from the
+// int32 index list (p.dY) in the transposition stage -- table[a][c] = sum_{r: idx[r] = a} X[r][c] comes out of the same
+// MFMA loop, exact (a bf16 1.0 times a bf16 value, fp32 accumulation), with no atomics at all; grid.y = shapes, each with
+// its own p.M rows and its own table.  2 M N K flops for a scatter is extravagant on paper and 0.1 ms in practice.
+template <int TN, int TK, int TASKS, int MODE>
 __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params p) {
+  constexpr bool MASK = MODE == 1, ONEHOT = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int N = p.N, K = p.K;
+  if constexpr (ONEHOT) {                                  // this shape's rows
+    p.X += static_cast<long long>(blockIdx.y) * p.M * K;
+    p.dY = reinterpret_cast<const unsigned short *>(reinterpret_cast<const int *>(p.dY) + static_cast<long long>(blockIdx.y) * p.M);
+  }
   const int nt = (N + 15) >> 4, kt = (K + 15) >> 4;
   const int tiles = nt + kt;
   const int img = tiles * 64;                          // u32x4 per fragment image
   // LDS: [2 fragment images][RING row-major slab images]; a slab image = dY piece region (nt KiB), X (kt KiB), mask (nt KiB)
   const int RING = p.ring;
-  const int pieces = tiles + (MASK ? nt : 0);          // 1 KiB pieces per slab
+  const int pieces = ONEHOT ? kt : tiles + (MASK ? nt : 0);          // 1 KiB pieces per slab (one-hot: X only)
+  const int xoff = ONEHOT ? 0 : (nt << 10);            // X region inside a slab image
   u32x4 *smem = reinterpret_cast<u32x4 *>(smem_raw);
   unsigned char *rowimg = smem_raw + 2 * img * 16;
   const int lane = threadIdx.x & 63;
@@ -414,8 +425,8 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
     for (int i = 0; i < pw; ++i) {
       int q = wave + kWavesWg * i;
       q = q < pieces ? q : (pieces - 1);
-      const bool isx = q >= nt && q < tiles;
-      const int qq = q < nt ? q : (q < tiles ? q - nt : q - tiles);         // piece within its tensor's run
+      const bool isx = ONEHOT || (q >= nt && q < tiles);
+      const int qq = ONEHOT ? q : (q < nt ? q : (q < tiles ? q - nt : q - tiles));   // piece within its tensor's run
       const unsigned char *base = reinterpret_cast<const unsigned char *>(isx ? p.X : (q < nt ? p.dY : p.mask));
       const long long total = isx ? bytes_x : bytes_dy;
       long long off = slab * 32 * (isx ? K : N) * 2 + (static_cast<long long>(qq) << 10) + lane * 16;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
     tstride[t] = (tisx[t] ? K : N) * 2;                // row stride in bytes
     trow[t] = rg * 8;
     tcol[t] = 2 * cc;
-    tsrc[t] = (tisx[t] ? (nt << 10) : 0) + rg * 8 * tstride[t] + 4 * cc;     // byte offset inside a slab image
+    tsrc[t] = (tisx[t] ? xoff : 0) + rg * 8 * tstride[t] + 4 * cc;     // byte offset inside a slab image
     tmsk[t] = (tiles << 10) + rg * 8 * tstride[t] + 4 * cc;
     tdst[t] = ((tisx[t] ? nt : 0) + (tcol[t] >> 4)) * 64 + rg * 16 + (tcol[t] & 15);
   }
@@ -453,14 +464,25 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
     for (int t = 0; t < TASKS; ++t) {
       if (!tlive[t]) continue;                                   // uniform
       unsigned v[8];
+      const long long rbase = slab * 32 + trow[t];
+      if (ONEHOT && !tisx[t]) {                                  // uniform: lanes = pairs of table rows (2 c, 2 c + 1)
+        // the 8 row indices of this task are wave-uniform: scalar loads (lgkmcnt -- a vector load here would make the
+        // compiler wait vmcnt(0), i.e. for the whole DMA ring)
+        const int *ip = reinterpret_cast<const int *>(p.dY) + __builtin_amdgcn_readfirstlane(static_cast<int>(rbase));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[j] = *reinterpret_cast<const unsigned *>(slot + tsrc[t] + j * tstride[t]);
-        if constexpr (MASK) {
-          if (!tisx[t]) v[j] = keep_pos(v[j], *reinterpret_cast<const unsigned *>(slot + tmsk[t] + j * tstride[t]));
+        for (int j = 0; j < 8; ++j) {
+          const int a = rbase + j < p.M ? ip[j] : -1;
+          v[j] = (a == tcol[t] ? 0x00003f80u : 0u) | (a == tcol[t] + 1 ? 0x3f800000u : 0u);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          v[j] = *reinterpret_cast<const unsigned *>(slot + tsrc[t] + j * tstride[t]);
+          if constexpr (MASK) {
+            if (!tisx[t]) v[j] = keep_pos(v[j], *reinterpret_cast<const unsigned *>(slot + tmsk[t] + j * tstride[t]));
+          }
         }
       }
-      const long long rbase = slab * 32 + trow[t];
       if (rbase + 8 > p.M) {                                     // uniform, last slab only: rows past the end are zero
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the trailing dummy copies
   __syncthreads();
   // partial of this workgroup: dW row-major [N][K] then db [N]
-  float *out = p.ws + static_cast<long long>(blockIdx.x) * (static_cast<long long>(N) * K + N);
+  float *out = p.ws + (static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x) * (static_cast<long long>(N) * K + N);
   const int i = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
@@ -598,6 +620,22 @@ __global__ __launch_bounds__(256) void reduce_b16_kernel(const float *__restrict
   else if (db) db[e - nw] = accumulate ? db[e - nw] + s : s;
 }
 
+// out[b][e] = sum over the S partials of shape b (one-hot scatter tables)
+__global__ __launch_bounds__(256) void reduce_tables_kernel(const float *__restrict__ ws, int S, long long stride, long long nw,
+                                                            float *__restrict__ out) {
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  if (e >= nw) return;
+  const float *w = ws + static_cast<long long>(blockIdx.y) * S * stride + e;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 4 <= S; c += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += w[(c + u) * stride];
+  }
+  for (; c < S; ++c) acc[0] += w[c * stride];
+  out[static_cast<long long>(blockIdx.y) * nw + e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 struct WgPlan {
   int grid, slabs_per_wg;
   size_t ws_floats;
@@ -638,8 +676,8 @@ int launch_wg16(const Wg16Params &p_in, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesWg * 64), lds, st, p);
     return nsdp::launch_status("wgrad_bf16_kernel");
   };
-  if (p.mask) return go(wgrad_bf16_kernel<TN, TK, TASKS, true>);
-  return go(wgrad_bf16_kernel<TN, TK, TASKS, false>);
+  if (p.mask) return go(wgrad_bf16_kernel<TN, TK, TASKS, 1>);
+  return go(wgrad_bf16_kernel<TN, TK, TASKS, 0>);
 }
 
 }  // namespace
@@ -742,6 +780,54 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
   hipLaunchKernelGGL(reduce_b16_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0, st, workspace,
                      pl.grid, nw + N, nw, dW, static_cast<long long>(nb), db, accumulate);
   return nsdp::launch_status("reduce_b16_kernel");
+}
+
+static WgPlan plan_onehot(int B, long long rows) {
+  WgPlan pl;
+  const long long slabs = (rows + 31) >> 5;
+  long long grid = (2LL * nsdp::num_cus() + B - 1) / B;            // ~2 workgroups per CU over all shapes
+  if (grid > slabs / 4) grid = slabs / 4 > 0 ? slabs / 4 : 1;
+  pl.slabs_per_wg = static_cast<int>((slabs + grid - 1) / grid);
+  pl.grid = static_cast<int>((slabs + pl.slabs_per_wg - 1) / pl.slabs_per_wg);
+  pl.ws_floats = 0;
+  return pl;
+}
+
+size_t nsdp_scatter_rows_onehot_bf16_workspace_bytes(int B, long long rows, int N, int d) {
+  if (B <= 0 || rows <= 0) return 0;
+  const int Np = (N + 1) & ~1;
+  return static_cast<size_t>(B) * plan_onehot(B, rows).grid * (static_cast<size_t>(Np) * d + Np) * sizeof(float);
+}
+
+int nsdp_scatter_rows_onehot_bf16(const void *src, const int32_t *idx, int B, long long rows, int N, int d, float *table,
+                                  float *workspace, size_t workspace_bytes, void *stream) {
+  if (B <= 0 || rows <= 0 || N <= 0 || d <= 0) return 0;
+  NSDP_REQUIRE(src && idx && table && workspace, "scatter_rows_onehot_bf16: null pointer");
+  NSDP_REQUIRE(N <= 128 && N % 2 == 0 && d % 8 == 0 && d <= 256, "scatter_rows_onehot_bf16: need an even N <= 128 and d %% 8 == 0, d <= 256 (N=%d d=%d)", N, d);
+  NSDP_REQUIRE(B <= 65535, "scatter_rows_onehot_bf16: batch too large");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_scatter_rows_onehot_bf16_workspace_bytes(B, rows, N, d), "scatter_rows_onehot_bf16: workspace too small");
+  const WgPlan pl = plan_onehot(B, rows);
+  Wg16Params p{reinterpret_cast<const unsigned short *>(idx), static_cast<const unsigned short *>(src), nullptr, workspace, rows,
+               N, d, 0, 0, pl.slabs_per_wg, 0, 3};
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0, static_cast<double>(B) * rows * (2.0 * d + 4.0));
+  const int nt = (N + 15) >> 4, kt = (d + 15) >> 4, tiles = nt + kt;
+  int ring = (160 - 2 * tiles) / kt;
+  ring = ring > 6 ? 6 : ring;
+  p.ring = ring;
+  const size_t lds = static_cast<size_t>(2) * tiles * 1024 + static_cast<size_t>(ring) * kt * 1024;
+  auto kern = wgrad_bf16_kernel<2, 4, 1, 2>;              // n tiles <= 8 (4 x 2), k tiles <= 16 (4 x 4), one chunk per wave
+  if (lds > 64 * 1024)
+    NSDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+  NSDP_TRACE("scatter_rows_onehot_bf16");
+  hipLaunchKernelGGL(kern, dim3(pl.grid, B), dim3(kWavesWg * 64), lds, st, p);
+  int rc = nsdp::launch_status("wgrad_bf16_kernel<onehot>");
+  if (rc) return rc;
+  const long long nw = static_cast<long long>(N) * d;
+  hipLaunchKernelGGL(reduce_tables_kernel, dim3(static_cast<unsigned>((nw + 255) / 256), B), dim3(256), 0, st, workspace,
+                     pl.grid, nw + N, nw, table);
+  return nsdp::launch_status("reduce_tables_kernel");
 }
 
 }  // extern "C"

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +31,28 @@ def _p(t, dtype, name="tensor"):
 
 def _fn(name, dtype):
     return getattr(lib(), name + ("_bf16" if dtype is BF16 else ""))
+
+
+ONEHOT_SCATTER = os.environ.get("NSDP_ONEHOT_SCATTER", "1") != "0"   # bf16 storage, decoder (<= 128 table rows): scatter as a GEMM
+
+
+def _onehot_ok(dt, qb_or_decoder, N, d):
+    return ONEHOT_SCATTER and dt is BF16 and qb_or_decoder and N <= 128 and N % 2 == 0 and d % 8 == 0 and d <= 256
+
+
+def onehot_scatter(src, idx, N):
+    """table [B,N,d] fp32 = sum of the rows of src [B,rows,d] (bf16) by idx [B,rows] (nsdp_scatter_rows_onehot_bf16)."""
+    B, rows, d = src.shape
+    L = lib()
+    L.nsdp_scatter_rows_onehot_bf16_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = int(L.nsdp_scatter_rows_onehot_bf16_workspace_bytes(_ci(B), ctypes.c_longlong(rows), _ci(N), _ci(d)))
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=src.device)
+    table = torch.empty((B, N, d), dtype=torch.float32, device=src.device)
+    with on_device(src):
+        check(L.nsdp_scatter_rows_onehot_bf16(_p(src, BF16, "src"), iptr(idx, "idx"), _ci(B), ctypes.c_longlong(rows), _ci(N),
+                                              _ci(d), fptr(table), fptr(ws), ctypes.c_size_t(nbytes), stream_ptr()),
+              "nsdp_scatter_rows_onehot_bf16")
+    return table
 
 
 class _PosGrad:
@@ -87,9 +110,16 @@ class _AttnPre(torch.autograd.Function):
         fused = link is not None and link.fused
         if link is not None and not fused:
             acc, link.dpos = link.dpos, None
-        with on_device(du):
-            check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb),
-                                               fptr(dq), fptr(dkf), _p(acc, dt, "dpos"), stream_ptr()), "nsdp_attn_pre_bwd")
+        if fused and acc is None and _onehot_ok(dt, qb, N, d):
+            # decoder, bf16: -scatter(du) and the per-shape sum of du from one scatter-as-GEMM pass (no atomics)
+            table = onehot_scatter(du.reshape(B, n * k, d), idx.reshape(B, n * k), N)
+            dkf = table.neg_()
+            dq = dkf.sum(1, keepdim=True).neg_()
+        else:
+            with on_device(du):
+                check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
+                                                   _ci(qb), fptr(dq), fptr(dkf), _p(acc, dt, "dpos"), stream_ptr()),
+                      "nsdp_attn_pre_bwd")
         if fused:
             # `du` is the total d(pos) (see _PosGrad): undo the value path's share in the two small outputs
             dkf.add_(link.dvf)
@@ -138,7 +168,8 @@ class _AttnPost(torch.autograd.Function):
         dt = a.dtype
         da = torch.empty_like(a)
         dpos = torch.empty_like(a)
-        dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if vf is not None else None
+        onehot = vf is not None and _onehot_ok(dt, a_g is not None, N, d)
+        dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if (vf is not None and not onehot) else None
         da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         with on_device(dy):
@@ -146,6 +177,8 @@ class _AttnPost(torch.autograd.Function):
                                                 _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B), _ci(n), _ci(N),
                                                 _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(dvf), optptr(da_g),
                                                 optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+        if onehot:     # the kernel only streamed; dvf = scatter(d(pos)) as a GEMM against the one-hot index matrix
+            dvf = onehot_scatter(dpos.reshape(B, n * k, d), idx.reshape(B, n * k), N)
         link = ctx.link
         if link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None:
             link.grad_sum.buf = dpos.reshape(-1, d)         # residual of the gamma MLP's first dX GEMM

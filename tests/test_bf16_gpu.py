@@ -323,3 +323,22 @@ def test_bf16_native_kernels_agree_with_the_cast_reference_in_the_model(mtype):
     assert l2 <= 3e-2, l2
     assert abs(l1 - l0) <= 1e-2 * abs(l0)
     assert np.median(rel) <= 3e-2
+
+
+@pytest.mark.parametrize("B,rows,N,d", [(3, 7001, 100, 200), (2, 57344, 100, 200), (1, 33, 8, 8), (4, 5000, 128, 256)])
+def test_scatter_as_gemm_onehot(B, rows, N, d):
+    """table[b][a] = sum of the rows with idx == a, computed on the matrix cores against the one-hot index matrix."""
+    from nsdp_amd import hip_attention as ha
+    g = torch.Generator().manual_seed(rows)
+    src = torch.randn(B, rows, d, generator=g).to(BF).to(DEV)
+    idx = torch.randint(0, N, (B, rows), generator=g, dtype=torch.int32).to(DEV)
+    if N >= 100:
+        idx[:, :50] = N - 1                      # a hot row and (below) an empty one
+        idx[idx == 3] = 4
+    table = ha.onehot_scatter(src, idx, N)
+    ref = torch.zeros(B, N, d, dtype=torch.float64, device=DEV)
+    ref.scatter_add_(1, idx.long().unsqueeze(-1).expand(B, rows, d), src.double())
+    assert float((table.double() - ref).abs().max()) <= 2e-6 * (float(ref.abs().max()) + 1) * max(1.0, (rows / 4096) ** 0.5)
+    if N >= 100:
+        assert float(table[:, 3].abs().max()) == 0.0
+    assert torch.equal(table, ha.onehot_scatter(src, idx, N))          # deterministic (no atomics)
