@@ -147,8 +147,16 @@ _pending = {}          # (device index, graph task) -> {id(param): [param, grad 
 # its end-of-backward callback, and its leftovers must not be published by (or suppress the callback of) the next pass.
 
 
+# Two private PyTorch entry points carry the side-stream protocol: the id of the running autograd graph task (keys the
+# per-backward state) and the engine's end-of-backward callback queue (publishes the gradients).  If a PyTorch build lacks
+# either, weight gradients simply stay on the main stream and are published inside backward -- slower, never wrong.
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+_engine = getattr(torch.autograd.Variable, "_execution_engine", None)
+_HAVE_ENGINE_HOOKS = _graph_task_id is not None and hasattr(_engine, "queue_callback")
+
+
 def _pass_key(device):
-    return (device.index, torch._C._current_graph_task_id())
+    return (device.index, _graph_task_id())
 
 
 def _side_stream(device):
@@ -183,6 +191,8 @@ def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig):
 
 
 def _use_side_stream(dy2):
+    if not _HAVE_ENGINE_HOOKS:
+        return False
     if _OVERLAP_WGRAD != "auto":
         return _OVERLAP_WGRAD
     key = _pass_key(dy2.device)

@@ -313,3 +313,26 @@ def test_no_grad_forward_reuses_the_weight_pack():
         assert torch.allclose(y2, F.linear(x, lin.weight, lin.bias), rtol=1e-4, atol=1e-4)
     finally:
         hip_linear.pack_weight = orig
+
+
+def test_without_the_private_engine_hooks_gradients_stay_on_the_main_stream():
+    """A PyTorch build without torch._C._current_graph_task_id / the engine's queue_callback: no side stream, gradients
+    published inside backward, same values."""
+    from nsdp_amd import hip_linear
+    lin, x = _layer(3, n=128, k=128)
+    big = torch.randn(140000, 128, device=DEV, requires_grad=True)      # >= _OVERLAP_MIN_ROWS: would take the side stream
+    hip_linear.linear(big, lin.weight, lin.bias, params=True).square().sum().backward()
+    ref_w, ref_b = lin.weight.grad.clone(), lin.bias.grad.clone()
+    lin.zero_grad()
+    was = hip_linear._HAVE_ENGINE_HOOKS
+    hip_linear._HAVE_ENGINE_HOOKS = False
+    try:
+        called = []
+        orig = hip_linear._wgrad_deferred
+        hip_linear._wgrad_deferred = lambda *a, **k: (called.append(1), orig(*a, **k))[1]
+        hip_linear.linear(big, lin.weight, lin.bias, params=True).square().sum().backward()
+        hip_linear._wgrad_deferred = orig
+    finally:
+        hip_linear._HAVE_ENGINE_HOOKS = was
+    assert not called
+    assert torch.allclose(lin.weight.grad, ref_w, rtol=1e-5, atol=1e-3) and torch.allclose(lin.bias.grad, ref_b, rtol=1e-5, atol=1e-3)
