@@ -32,7 +32,9 @@ extern "C" {
 int nsdp_abi_version(void);
 /* Human-readable description of the last non-zero return on this thread. */
 const char *nsdp_last_error(void);
-/* Tuning/debug knob (not part of the reference contract): key 1 = wgrad software pipelining (-1/0/1). */
+/* Tuning / ablation knobs (not part of the reference contract; timing experiments only -- several produce wrong results):
+ * 1 wgrad software pipelining, 3 fp32 GEMM pipeline form, 4 fp32 GEMM ablation bits, 5 float4-operand wgrad, 6 bf16x3 GEMM
+ * ablation bits, 7 bf16 wgrad phases (1 no MFMA, 2 no transposition, 4 no DMA), 8 bf16 linear phases (1 no MFMA, 2 no stores). */
 void nsdp_debug_set(int key, int value);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int nsdp_device_count(void);
