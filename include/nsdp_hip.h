@@ -221,6 +221,17 @@ int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, con
                           const float *invstd, const float *gamma, long long R, int C, int training, void *dx,
                           float *dgamma, float *dbeta, float *workspace, void *stream);
 
+/* Atomics-free scatter through inverse neighbour lists (csrc/segment.hip).  nsdp_knn_invert: idx (B, E) int32 with values
+ * in [0, N) (E = centres x neighbours) -> offsets (B, N + 1), entries (B, E): entries[b][offsets[b][s] .. offsets[b][s+1])
+ * is the ascending list of the flat positions e with idx[b][e] == s.  N <= 8192.  Built once per index set and step.
+ * nsdp_segment_sum_rows: out[b][s][:] = scale * sum over that list of src[b][e][:]  (src (B, E, d) fp32 / bf16, out fp32) --
+ * the scatter-add of the attention backward (dvf, dkf) as a deterministic gather-reduce. */
+int nsdp_knn_invert(const int32_t *idx, int B, int E, int N, int32_t *offsets, int32_t *entries, void *stream);
+int nsdp_segment_sum_rows(const float *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                          float scale, float *out, void *stream);
+int nsdp_segment_sum_rows_bf16(const void *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                               float scale, float *out, void *stream);
+
 /* Scatter as a GEMM (bf16 storage): table[b][a][c] = sum over the rows r of shape b with idx[b][r] == a of src[b][r][c],
  * computed as one-hot(idx)^T x src on the matrix cores (exact: 1.0 x bf16, fp32 accumulation; no atomics, deterministic).
  * src (B, rows, d) bf16, idx (B, rows) int32 in [0, N), table (B, N, d) fp32 (overwritten).  N even, <= 128; d % 8 == 0.

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T 
     for (int j = 0; j < s.k; ++j) {
       const Quad g = ldQ<ST>(dur + static_cast<long long>(j) * s.d, cq, lpp);
       acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
-      atQ<ST>(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
+      if (dkf) atQ<ST>(dkfb + static_cast<long long>(ip[j]) * s.d, cq, lpp, Quad{-g.x, -g.y, -g.z, -g.w});
       if (par) {   // d(pos) += du while the row is in registers (saves the separate add kernel's re-read of du)
         T *pr = par + static_cast<long long>(j) * s.d;
         const Quad o = ldQ<ST>(pr, cq, lpp);
@@ -693,7 +693,12 @@ int attn_pre_bwd_t(const T *du, const int32_t *idx, int B, int n, int N, int k, 
     NSDP_HIP_TRY(hipMemsetAsync(dkf, 0, sizeof(float) * static_cast<size_t>(B) * N * d, st));
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
-  NSDP_REQUIRE(du && idx && dq && dkf, "attn_pre_bwd: null pointer");
+  NSDP_REQUIRE(du && idx && dq, "attn_pre_bwd: null pointer");
+  if (!dkf) {      // the caller scatters itself (inverse neighbour lists): only dq (+ the optional d(pos) accumulation) here
+    NSDP_TRACE("attn_pre_bwd_stream");
+    NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel<T>, s, du, idx, dq, dkf, dpos_acc);
+    return nsdp::launch_status("attn_pre_bwd_kernel");
+  }
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           kEl * (rows(s) * ((dpos_acc ? 3.0 : 1.0) * d + 1.0) + static_cast<double>(B) * (n + 2.0 * N) * d));
   if (q_per_shape && regtab_fits(N, d, static_cast<long long>(n) * k)) {

@@ -40,6 +40,53 @@ def _onehot_ok(dt, qb_or_decoder, N, d):
     return ONEHOT_SCATTER and dt is BF16 and qb_or_decoder and N <= 128 and N % 2 == 0 and d % 8 == 0 and d <= 256
 
 
+# Encoder levels whose source table fits neither LDS nor registers (2048 / 500 source points): scatter through inverse
+# neighbour lists (csrc/segment.hip) instead of global fp32 atomics.  The lists depend on the index tensor only and are
+# cached on it (the two attentions of a set abstraction share one index set; forward builds nothing).
+INVERSE_LISTS = os.environ.get("NSDP_INVERSE_LISTS", "1")         # "0": the global-atomic kernels (A/B knob)
+
+
+def _use_inverse(dt, qb, n, N, d):
+    if qb or N > 8192 or INVERSE_LISTS == "0":
+        return False
+    table_fits_lds = N * d * 4 <= 110 * 1024 and n >= 4 * N            # (lds_table_fits of csrc/attention.hip)
+    if table_fits_lds:
+        return False
+    return True
+
+
+def inverse_lists(idx, N):
+    """(offsets [B,N+1], entries [B,E]) of idx [B,n,k] (nsdp_knn_invert), cached on the index tensor."""
+    cache = idx.__dict__.setdefault("_nsdp_inverse", {}) if hasattr(idx, "__dict__") else {}
+    hit = cache.get(N)
+    if hit is not None:
+        return hit
+    B = idx.shape[0]
+    E = idx.numel() // B
+    offsets = torch.empty((B, N + 1), dtype=torch.int32, device=idx.device)
+    entries = torch.empty((B, E), dtype=torch.int32, device=idx.device)
+    with on_device(idx):
+        check(lib().nsdp_knn_invert(iptr(idx, "idx"), _ci(B), _ci(E), _ci(N), iptr(offsets), iptr(entries), stream_ptr()),
+              "nsdp_knn_invert")
+    cache[N] = (offsets, entries)
+    return offsets, entries
+
+
+def segment_sum(src, idx, N, scale=1.0):
+    """out [B,N,d] fp32 = scale * scatter-add of the rows of src [B,n,k,d] by idx [B,n,k], as a gather-reduce over the
+    inverse lists (deterministic, no atomics)."""
+    B = src.shape[0]
+    d = src.shape[-1]
+    E = idx.numel() // B
+    offsets, entries = inverse_lists(idx, N)
+    out = torch.empty((B, N, d), dtype=torch.float32, device=src.device)
+    dt = src.dtype
+    with on_device(src):
+        check(_fn("nsdp_segment_sum_rows", dt)(_p(src, dt, "src"), iptr(offsets), iptr(entries), _ci(B), _ci(E), _ci(N), _ci(d),
+                                               ctypes.c_float(scale), fptr(out), stream_ptr()), "nsdp_segment_sum_rows")
+    return out
+
+
 def onehot_scatter(src, idx, N):
     """table [B,N,d] fp32 = sum of the rows of src [B,rows,d] (bf16) by idx [B,rows] (nsdp_scatter_rows_onehot_bf16)."""
     B, rows, d = src.shape
@@ -110,7 +157,14 @@ class _AttnPre(torch.autograd.Function):
         fused = link is not None and link.fused
         if link is not None and not fused:
             acc, link.dpos = link.dpos, None
-        if fused and acc is None and _onehot_ok(dt, qb, N, d):
+        if acc is None and _use_inverse(dt, qb, n, N, d):
+            # dq from a pure stream over du, dkf = -scatter(du) as a gather-reduce over the inverse neighbour lists
+            with on_device(du):
+                check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
+                                                   _ci(qb), fptr(dq), ctypes.c_void_p(0), ctypes.c_void_p(0), stream_ptr()),
+                      "nsdp_attn_pre_bwd")
+            dkf = segment_sum(du, idx, N, -1.0)
+        elif fused and acc is None and _onehot_ok(dt, qb, N, d):
             # decoder, bf16: -scatter(du) and the per-shape sum of du from one scatter-as-GEMM pass (no atomics)
             table = onehot_scatter(du.reshape(B, n * k, d), idx.reshape(B, n * k), N)
             dkf = table.neg_()
@@ -169,7 +223,8 @@ class _AttnPost(torch.autograd.Function):
         da = torch.empty_like(a)
         dpos = torch.empty_like(a)
         onehot = vf is not None and _onehot_ok(dt, a_g is not None, N, d)
-        dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if (vf is not None and not onehot) else None
+        inverse = vf is not None and not onehot and a_g is None and _use_inverse(dt, False, n, N, d)
+        dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if (vf is not None and not onehot and not inverse) else None
         da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         with on_device(dy):
@@ -179,6 +234,8 @@ class _AttnPost(torch.autograd.Function):
                                                 optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
         if onehot:     # the kernel only streamed; dvf = scatter(d(pos)) as a GEMM against the one-hot index matrix
             dvf = onehot_scatter(dpos.reshape(B, n * k, d), idx.reshape(B, n * k), N)
+        elif inverse:  # ... or as a gather-reduce over the inverse neighbour lists
+            dvf = segment_sum(dpos, idx, N)
         link = ctx.link
         if link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None:
             link.grad_sum.buf = dpos.reshape(-1, d)         # residual of the gamma MLP's first dX GEMM

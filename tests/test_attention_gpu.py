@@ -122,3 +122,55 @@ def test_pos_gradient_link_matches_autograd_sum(B, n, N, k, d, per_shape):
         # (dq / dkf come from fp32 atomics in both runs: summation order, not the hand-over, sets this tolerance)
         assert float((a_ - e_).abs().max()) <= 2e-5 * (float(e_.abs().max()) + 1.0)
     assert torch.equal(fused[3], plain[3])        # d(pos): the same two addends, added once, in either path
+
+
+@pytest.mark.parametrize("B,n,N,k,d", [(2, 300, 700, 16, 120), (3, 64, 2048, 10, 120), (1, 500, 500, 16, 256)])
+def test_inverse_lists_and_segment_sum(B, n, N, k, d):
+    """nsdp_knn_invert / nsdp_segment_sum_rows: complete, sorted lists; the scatter-add they replace; determinism."""
+    from nsdp_amd import hip_attention as ha
+    g = torch.Generator().manual_seed(n + N)
+    idx = torch.randint(0, N, (B, n, k), generator=g, dtype=torch.int32).to(DEV)
+    idx[:, :, 0] = 5                                     # one hot source, many empty ones
+    off, ent = ha.inverse_lists(idx, N)
+    off_c, ent_c, flat = off.cpu(), ent.cpu(), idx.reshape(B, -1).cpu()
+    for b in range(B):
+        assert off_c[b, 0] == 0 and off_c[b, N] == n * k
+        assert torch.equal(torch.sort(ent_c[b]).values, torch.arange(n * k, dtype=torch.int32))     # a permutation
+        for s_ in (0, 5, N - 1, int(flat[b, 7])):
+            lst = ent_c[b, off_c[b, s_]:off_c[b, s_ + 1]]
+            assert bool((flat[b, lst.long()] == s_).all()) and bool((lst[1:] > lst[:-1]).all())      # right rows, ascending
+        assert torch.equal(torch.bincount(flat[b].long(), minlength=N).int(), (off_c[b, 1:] - off_c[b, :-1]))
+    for dt in (torch.float32, torch.bfloat16):
+        src = torch.randn(B, n, k, d, generator=g).to(dt).to(DEV)
+        out = ha.segment_sum(src, idx, N, -1.0)
+        ref = torch.zeros(B, N, d, dtype=torch.float64, device=DEV)
+        ref.scatter_add_(1, idx.long().reshape(B, n * k, 1).expand(B, n * k, d), -src.double().reshape(B, n * k, d))
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * (float(ref.abs().max()) + 1)
+        assert torch.equal(out, ha.segment_sum(src, idx, N, -1.0))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_backward_through_inverse_lists_matches_the_atomic_kernels(dt):
+    from nsdp_amd import hip_attention as ha
+    B, n, N, k, d = 2, 300, 700, 16, 120
+    g = torch.Generator().manual_seed(11)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dt).to(DEV)
+    idx = torch.randint(0, N, (B, n, k), generator=g, dtype=torch.int32).to(DEV)
+    base = dict(q=mk(B, n, d), kf=mk(B, N, d), vf=mk(B, N, d), pos=mk(B, n, k, d), res=mk(B, n, d))
+    w = mk(B, n, d).float()
+    outs = []
+    was = ha.INVERSE_LISTS
+    for mode in ("1", "0"):
+        ha.INVERSE_LISTS = mode
+        try:
+            t = {kk: v.clone().requires_grad_(True) for kk, v in base.items()}
+            u = ha.attn_pre(t["q"], t["kf"], t["pos"], idx, None)
+            y = ha.attn_post(u * 0.5, t["vf"], t["pos"], idx, residual=t["res"])
+            (y.float() * w).sum().backward()
+            outs.append({kk: v.grad.float() for kk, v in t.items()})
+        finally:
+            ha.INVERSE_LISTS = was
+    floor = float(outs[1]["kf"].abs().max())
+    for kk in outs[0]:
+        scale = max(float(outs[1][kk].abs().max()), floor)
+        assert float((outs[0][kk] - outs[1][kk]).abs().max()) <= (2e-2 if dt is torch.bfloat16 else 1e-4) * scale, kk
