@@ -72,13 +72,13 @@ def inverse_lists(idx, N):
     return offsets, entries
 
 
-def segment_sum(src, idx, N, scale=1.0):
+def segment_sum(src, idx, N, scale=1.0, inv=None):
     """out [B,N,d] fp32 = scale * scatter-add of the rows of src [B,n,k,d] by idx [B,n,k], as a gather-reduce over the
-    inverse lists (deterministic, no atomics)."""
+    inverse lists (deterministic, no atomics).  ``inv``: the lists, when the caller built them already."""
     B = src.shape[0]
     d = src.shape[-1]
     E = idx.numel() // B
-    offsets, entries = inverse_lists(idx, N)
+    offsets, entries = inv if inv is not None else inverse_lists(idx, N)
     out = torch.empty((B, N, d), dtype=torch.float32, device=src.device)
     dt = src.dtype
     with on_device(src):
@@ -128,8 +128,9 @@ class _AttnPre(torch.autograd.Function):
     """u = q[:, :, None] - kf[idx] + pos."""
 
     @staticmethod
-    def forward(ctx, q, kf, pos, idx, link=None):
+    def forward(ctx, q, kf, pos, idx, link=None, inv=None):
         ctx.link = link
+        ctx.inv = inv
         q, kf, pos = _c(q), _c(kf), _c(pos)
         B, n, k, d = pos.shape
         N = kf.shape[1]
@@ -163,7 +164,7 @@ class _AttnPre(torch.autograd.Function):
                 check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
                                                    _ci(qb), fptr(dq), ctypes.c_void_p(0), ctypes.c_void_p(0), stream_ptr()),
                       "nsdp_attn_pre_bwd")
-            dkf = segment_sum(du, idx, N, -1.0)
+            dkf = segment_sum(du, idx, N, -1.0, ctx.inv)
         elif fused and acc is None and _onehot_ok(dt, qb, N, d):
             # decoder, bf16: -scatter(du) and the per-shape sum of du from one scatter-as-GEMM pass (no atomics)
             table = onehot_scatter(du.reshape(B, n * k, d), idx.reshape(B, n * k), N)
@@ -185,15 +186,16 @@ class _AttnPre(torch.autograd.Function):
             link.fused = False
         if dt is BF16:           # (scatter / reduction outputs are produced in fp32; the tables are small)
             dq, dkf = dq.to(BF16), dkf.to(BF16)
-        return dq, dkf, (du if acc is None else acc), None, None
+        return dq, dkf, (du if acc is None else acc), None, None, None
 
 
 class _AttnPost(torch.autograd.Function):
     """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
 
     @staticmethod
-    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None):
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None):
         ctx.link = link
+        ctx.inv = inv
         a, pos = _c(a), _c(pos)
         vf = None if vf is None else _c(vf)
         a_g = None if a_g is None else _c(a_g)
@@ -235,7 +237,7 @@ class _AttnPost(torch.autograd.Function):
         if onehot:     # the kernel only streamed; dvf = scatter(d(pos)) as a GEMM against the one-hot index matrix
             dvf = onehot_scatter(dpos.reshape(B, n * k, d), idx.reshape(B, n * k), N)
         elif inverse:  # ... or as a gather-reduce over the inverse neighbour lists
-            dvf = segment_sum(dpos, idx, N)
+            dvf = segment_sum(dpos, idx, N, 1.0, ctx.inv)
         link = ctx.link
         if link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None:
             link.grad_sum.buf = dpos.reshape(-1, d)         # residual of the gamma MLP's first dX GEMM
@@ -248,7 +250,7 @@ class _AttnPost(torch.autograd.Function):
             dpos = None                               # travels as the dX GEMM's residual; attn_pre reports the total
         elif link is not None and ctx.needs_input_grad[2]:
             link.dpos, dpos = dpos, None              # attn_pre's backward adds d(u) and reports the sum
-        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None
 
 
 def pos_grad_link():
@@ -269,13 +271,22 @@ def native(t):
     return t.dtype is torch.float32 or NATIVE_BF16
 
 
-def attn_pre(q, kf, pos, idx, link=None):
+def backward_lists(idx, n, N, d, qb=False):
+    """The inverse neighbour lists the backward pass of an attention block over this index set will want, or None.
+    Built in the FORWARD pass (once per index set: the cache lives on the index tensor object, which the backward pass
+    no longer sees) and handed to attn_pre / attn_post as ``inv``."""
+    if not torch.is_grad_enabled() or not _use_inverse(None, qb, n, N, d):
+        return None
+    return inverse_lists(idx, N)
+
+
+def attn_pre(q, kf, pos, idx, link=None, inv=None):
     if pos.dtype is torch.bfloat16 and not NATIVE_BF16:
-        return _AttnPre.apply(_f(q), _f(kf), _f(pos), idx, link).to(torch.bfloat16)
-    return _AttnPre.apply(q, kf, pos, idx, link)
+        return _AttnPre.apply(_f(q), _f(kf), _f(pos), idx, link, inv).to(torch.bfloat16)
+    return _AttnPre.apply(q, kf, pos, idx, link, inv)
 
 
-def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None):
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None):
     if a.dtype is torch.bfloat16 and not NATIVE_BF16:
-        return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link).to(torch.bfloat16)
-    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link)
+        return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link, inv).to(torch.bfloat16)
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv)

@@ -61,7 +61,10 @@ class PointTransformerEncoder(nn.Module):
             if i == 0 and self.d_reduced != self.d_transformer:
                 feats = ops.linear(feats, self.fc1)
             feats = self.elementwise[i](feats)
+        final_idx = None      # the final blocks all search the same cloud with the same k: one kNN (and one inverse list) for all
         for blk, mlp in zip(self.final_transformers, self.final_elementwise):
-            feats = mlp(blk(xyz, feats))
+            if final_idx is None and not blk.group_all:
+                final_idx = ops.knn_indices(xyz, xyz, blk.k)
+            feats = mlp(blk(xyz, feats, idx=final_idx))
         lat_vec = feats.max(dim=1)[0]
         return {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}

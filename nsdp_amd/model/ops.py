@@ -165,7 +165,9 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         if link is not None and FUSE_DPOS and hip_attention.native(pos):
             # d(pos) = d(u) + d(pos)|values is formed by the gamma MLP's first dX GEMM (residual operand), see _PosGrad
             link.grad_sum = hip_linear.InputGradSum()
-        u = hip_attention.attn_pre(q, kf, pos, idx, link)      # q_i - kf[idx] + pos, gather fused
+        # (inverse neighbour lists for the scatters of the backward pass: built here, once per index set)
+        inv = hip_attention.backward_lists(idx, pos.shape[1], kf.shape[1], pos.shape[-1], qb=(q.shape[1] == 1 and pos.shape[1] != 1))
+        u = hip_attention.attn_pre(q, kf, pos, idx, link, inv)      # q_i - kf[idx] + pos, gather fused
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
-        out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link)
+        out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv)
     return out, pos
