@@ -48,9 +48,11 @@ class TransformerBlock(nn.Module):
         if self.pos_only:
             res, _ = ops.vector_attention(rel, None, None, None, idx, self.fc_delta, self.fc_gamma)
         else:
-            q = ops.linear(feats, self.w_qs)
-            kf = ops.linear(feats, self.w_ks)
-            vf = ops.linear(feats, self.w_vs)
+            # the three projections read the same tensor: their input gradients are summed inside the dX GEMMs
+            fan = ops.input_grad_sum(feats)
+            q = ops.linear(feats, self.w_qs, grad_sum=fan)
+            kf = ops.linear(feats, self.w_ks, grad_sum=fan)
+            vf = ops.linear(feats, self.w_vs, grad_sum=fan)
             res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats)
         return ops.batch_norm(res, self.bn)
 
@@ -109,15 +111,17 @@ class TransformerSetAbstraction(nn.Module):
         # the reference projects all N points with w_qs and then gathers the centres; gathering first
         # is the same values with N/npoint fewer rows through the GEMM
         q1 = ops.linear(ops.index_points(points, fps_idx), self.w_qs)
-        res1, pos = ops.vector_attention(rel, q1, ops.linear(points, self.w_ks), ops.linear(points, self.w_vs), idx,
-                                         self.fc_delta1, self.fc_gamma1)
+        fan = ops.input_grad_sum(points)          # four projections of `points`: one running sum through their dX GEMMs
+        res1, pos = ops.vector_attention(rel, q1, ops.linear(points, self.w_ks, grad_sum=fan),
+                                         ops.linear(points, self.w_vs, grad_sum=fan), idx, self.fc_delta1, self.fc_gamma1)
         res1 = ops.linear(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1), self.conv2, relu_in=True,
                           residual=res1)
         res1 = ops.batch_norm(res1, self.bnorm0)
 
         q2 = ops.linear(res1, self.w_qs2)
         # second attention re-uses pos; "res1 + res2" is fused as the kernel's residual add
-        res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2), ops.linear(points, self.w_vs2), idx,
+        res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2, grad_sum=fan),
+                                        ops.linear(points, self.w_vs2, grad_sum=fan), idx,
                                         None, self.fc_gamma2, residual=res1, pos=pos)
 
         new_points = ops.batch_norm(res12, self.bnorm1)

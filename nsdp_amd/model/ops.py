@@ -119,6 +119,12 @@ def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, resi
                              params=True, grad_sum=grad_sum, out_f32=out_f32)
 
 
+def input_grad_sum(x: torch.Tensor):
+    """An InputGradSum for the dense layers that read ``x`` (None when no gradient will flow: eval / no_grad).  Contract
+    (hip_linear.InputGradSum): every layer given it takes part in the backward pass."""
+    return hip_linear.InputGradSum() if (torch.is_grad_enabled() and x.requires_grad) else None
+
+
 def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
     """nn.Sequential(Linear, ReLU, Linear) (fc_delta / fc_gamma / fc_middle).
     bf16 storage: the ReLU is the SECOND layer's fused input ReLU (the tensor in between holds the pre-activation): same
