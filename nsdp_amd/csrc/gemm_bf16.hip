@@ -289,7 +289,10 @@ __global__ __launch_bounds__(WV * 64, 1) void linear_bf16_kernel(B16Params p) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = keep_pos(o[c], om[c]);
         }
-        if (rv) *reinterpret_cast<u32x4 *>(yr) = o;
+        if (rv) {
+          if (p.dbg & 4) __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(yr));
+          else *reinterpret_cast<u32x4 *>(yr) = o;
+        }
       } else {
         u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
         if (p.out_mask) {
