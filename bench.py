@@ -320,6 +320,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
+    t_enqueued = time.perf_counter() - t0      # host time to ENQUEUE the K steps (no sync inside a step)
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
@@ -355,6 +356,7 @@ def main():
                        "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1),
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "comm": {"backend": (dist.get_backend() if world > 1 else None),
                      "world_size": (dist.get_world_size() if world > 1 else 1),
                      "grad_bytes_per_step": (reducer.nbytes if reducer is not None else None),

@@ -85,25 +85,39 @@ def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
     return y
 
 
-def _wgrad(dy2, x2, mask, relu_x, want_db):
+def wgrad_out(out, N, K, want_db, device):
+    """(dw, db, accumulate) for a weight-gradient launch: fresh tensors, or -- `out` = (dW [N,K], db [N] or None) of a
+    matching shape -- those buffers with the kernel's accumulate flag (the sum lands in them, no add kernel)."""
+    if out is not None:
+        dw, db = out
+        if (tuple(dw.shape) == (N, K) and dw.dtype is torch.float32 and dw.is_contiguous()
+                and (not want_db or (db is not None and db.dtype is torch.float32 and db.is_contiguous()))):
+            return dw, (db if want_db else None), 1
+    dw = torch.empty((N, K), dtype=torch.float32, device=device)
+    db = torch.empty((N,), dtype=torch.float32, device=device) if want_db else None
+    return dw, db, 0
+
+
+def _wgrad(dy2, x2, mask, relu_x, want_db, out=None):
+    """dW, db.  `out`: accumulate into these buffers instead (returned as they are when the shapes allow it: callers test
+    `dw is out[0]`)."""
     M, N = dy2.shape
     K = x2.shape[1]
     L = lib()
     if _USE_X3 and M >= _X3_MIN_ROWS_WGRAD and L.nsdp_linear_wgrad_bf16x3_supported(_ll(M), _ci(N), _ci(K)):
-        return _wgrad_x3(dy2, x2, mask, relu_x, want_db)
+        return _wgrad_x3(dy2, x2, mask, relu_x, want_db, out)
     L.nsdp_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_linear_wgrad_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
-                                      optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws),
+                                      optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
                                       ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_wgrad_f32")
     return dw, db
 
 
-def _wgrad_x3(dy2, x2, mask, relu_x, want_db):
+def _wgrad_x3(dy2, x2, mask, relu_x, want_db, out=None):
     """_wgrad on the bf16 matrix pipe (3-way split of both operands, nsdp_linear_wgrad_bf16x3_f32)."""
     M, N = dy2.shape
     K = x2.shape[1]
@@ -111,11 +125,10 @@ def _wgrad_x3(dy2, x2, mask, relu_x, want_db):
     L.nsdp_linear_wgrad_bf16x3_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_bf16x3_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
-                                             optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws),
+                                             optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
                                              ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_wgrad_bf16x3_f32")
     return dw, db
 
@@ -176,6 +189,8 @@ def _publish(device, key):
     main.wait_stream(_side_stream(device))
     with torch.no_grad():
         for param, g in todo.values():
+            if g is param.grad:          # the kernels accumulated straight into the existing .grad
+                continue
             g.record_stream(main)
             if param.grad is None:
                 param.grad = g
@@ -183,11 +198,34 @@ def _publish(device, key):
                 param.grad.add_(g)
 
 
-def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig):
-    dw, db = _wgrad(dy2, x2, mask, relu_x, want_db)
+def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig, out=None):
+    dw, db = _wgrad(dy2, x2, mask, relu_x, want_db, out if x2.shape[1] == k_orig else None)
     if dw.shape[1] != k_orig:          # zero-padded reduction dimension (K = 3)
         dw = dw[:, :k_orig].contiguous()
     return dw, db
+
+
+def _grad_targets(w_param, b_param, gw, gb):
+    """The `out` pair for a weight-gradient launch that should add into the buffers gw / gb (None when one is missing)."""
+    if gw is None or (b_param is not None and gb is None) or not gw.is_contiguous():
+        return None
+    return gw.view(gw.shape[0], -1), gb
+
+
+def wgrad_direct(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
+    """Main-stream direct publication: dW / db into `param.grad` (assigned, or accumulated by the kernel itself)."""
+    out = _grad_targets(w_param, b_param, w_param.grad, b_param.grad if b_param is not None else None)
+    if fn is None:
+        gw, gb = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig, out)
+    else:
+        gw, gb = fn(dy2, x2, mask, relu_x, b_param is not None, out)
+    if out is not None and gw is out[0]:
+        return
+    with torch.no_grad():
+        for prm, g in ((w_param, gw), (b_param, gb)):
+            if prm is not None:
+                g = g.view_as(prm)
+                prm.grad = g if prm.grad is None else prm.grad.add_(g)
 
 
 def _use_side_stream(dy2):
@@ -206,7 +244,10 @@ def _use_side_stream(dy2):
 
 
 def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
-    """``fn``: weight-gradient routine (dy2, x2, mask, relu_x, want_db) -> (dw, db) of another storage precision."""
+    """``fn``: weight-gradient routine (dy2, x2, mask, relu_x, want_db, out) -> (dw, db) of another storage precision.
+    The kernels add into what is already there where they can: the pending buffer of a parameter used more than once in the
+    graph (FlowArbitrary runs one encoder three times), or an existing `.grad` (the data-parallel flat-bucket views, gradient
+    accumulation over micro-batches) -- no add kernels, and nothing to publish for those at the end of the pass."""
     dev = dy2.device
     main = torch.cuda.current_stream(dev)
     side = _side_stream(dev)
@@ -217,19 +258,31 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
         slot = _pending[key] = {}
         torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
     with torch.cuda.stream(side):      # everything that touches dw/db before the join stays on `side`
+        ent_w = slot.get(id(w_param))
+        ent_b = slot.get(id(b_param)) if b_param is not None else None
+        if ent_w is None and (b_param is None or ent_b is None):
+            # first use in this pass: an existing .grad becomes the pending buffer itself
+            gw0 = w_param.grad
+            gb0 = b_param.grad if b_param is not None else None
+            if gw0 is not None and (b_param is None or gb0 is not None):
+                ent_w = slot[id(w_param)] = [w_param, gw0]
+                if b_param is not None:
+                    ent_b = slot[id(b_param)] = [b_param, gb0]
+        out = _grad_targets(w_param, b_param, ent_w[1] if ent_w is not None else None, ent_b[1] if ent_b is not None else None)
         if fn is None:
-            dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig)
+            dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig, out)
         else:
-            dw, db = fn(dy2, x2, mask, relu_x, b_param is not None)
-        for param, g in ((w_param, dw), (b_param, db)):
-            if param is None:
-                continue
-            g = g.view_as(param)
-            ent = slot.get(id(param))
-            if ent is None:
-                slot[id(param)] = [param, g]
-            else:
-                ent[1].add_(g)         # parameter used twice in one graph (e.g. fc_gamma in the decoder)
+            dw, db = fn(dy2, x2, mask, relu_x, b_param is not None, out)
+        if out is None or dw is not out[0]:
+            for param, g in ((w_param, dw), (b_param, db)):
+                if param is None:
+                    continue
+                g = g.view_as(param)
+                ent = slot.get(id(param))
+                if ent is None:
+                    slot[id(param)] = [param, g]
+                else:
+                    ent[1].add_(g)     # (shapes the kernels cannot accumulate in place: the padded K = 3 layers)
     for t in (dy2, x2, mask):
         if t is not None:
             t.record_stream(side)
@@ -434,12 +487,7 @@ class _LinearFn(torch.autograd.Function):
             if _use_side_stream(dy2):
                 _wgrad_deferred(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param)   # side stream
             else:
-                gw, gb = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.b_param is not None, ctx.k_orig)
-                with torch.no_grad():
-                    for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
-                        if prm is not None:
-                            g = g.view_as(prm)
-                            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+                wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         if ctx.needs_input_grad[0]:

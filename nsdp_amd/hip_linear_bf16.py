@@ -58,8 +58,8 @@ def run(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, out_f32=Fal
     return y
 
 
-def wgrad(dy2, x2, mask, relu_x, want_db):
-    """dW [N,K], db [N] (fp32) from bf16 dY [M,N], X [M,K] (nsdp_linear_wgrad_bf16)."""
+def wgrad(dy2, x2, mask, relu_x, want_db, out=None):
+    """dW [N,K], db [N] (fp32) from bf16 dY [M,N], X [M,K] (nsdp_linear_wgrad_bf16); `out`: accumulate into these."""
     M, N = dy2.shape
     K = x2.shape[1]
     nt_, kt_ = (N + 15) // 16, (K + 15) // 16
@@ -69,26 +69,25 @@ def wgrad(dy2, x2, mask, relu_x, want_db):
     L.nsdp_linear_wgrad_bf16_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_linear_wgrad_bf16_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
-    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+    dw, db, acc = hip_linear.wgrad_out(out, N, K, want_db, dy2.device)
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_bf16(hptr(dy2, "dy"), hptr(x2, "x"), opthptr(mask, "mask"), _ci(int(relu_x)), fptr(dw),
-                                       optptr(db), _ll(M), _ci(N), _ci(K), _ci(0), fptr(ws), ctypes.c_size_t(nbytes),
+                                       optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws), ctypes.c_size_t(nbytes),
                                        stream_ptr()), "nsdp_linear_wgrad_bf16")
     return dw, db
 
 
-def _wgrad_any(dy2, x2, y_mask, relu_x, want_db):
+def _wgrad_any(dy2, x2, y_mask, relu_x, want_db, out=None):
     """Weight gradient of a bf16-storage layer; shapes outside the bf16 kernel go through the fp32 kernels on casts."""
     N, K = dy2.shape[1], x2.shape[1]
     if dy2.dtype is BF16 and N % 2 == 0 and K % 2 == 0 and N <= 256 and K <= 256 and N >= 8 and K >= 8:
-        return wgrad(dy2, x2, y_mask, relu_x, want_db)
+        return wgrad(dy2, x2, y_mask, relu_x, want_db, out)
     dyf, xf = dy2.float(), x2.float()
     mk = None if y_mask is None else y_mask.float()
     kp = (-K) % 4
     if kp:
         xf = torch.nn.functional.pad(xf, (0, kp))
-    dw, db = hip_linear._wgrad(dyf.contiguous(), xf.contiguous(), mk, relu_x, want_db)
+    dw, db = hip_linear._wgrad(dyf.contiguous(), xf.contiguous(), mk, relu_x, want_db, None if kp else out)
     return (dw[:, :K].contiguous() if kp else dw), db
 
 
@@ -138,12 +137,7 @@ class _LinearB16Fn(torch.autograd.Function):
             if hip_linear._use_side_stream(dy2):
                 hip_linear._wgrad_deferred(dy2, x2, y, ctx.relu_in, K, ctx.w_param, ctx.b_param, fn=_wgrad_any)
             else:
-                gw, gb = _wgrad_any(dy2, x2, y, ctx.relu_in, ctx.b_param is not None)
-                with torch.no_grad():
-                    for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
-                        if prm is not None:
-                            g = g.view_as(prm)
-                            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+                hip_linear.wgrad_direct(dy2, x2, y, ctx.relu_in, K, ctx.w_param, ctx.b_param, fn=_wgrad_any)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad_any(dy2, x2, y, ctx.relu_in, ctx.has_bias)
         if ctx.needs_input_grad[0]:
@@ -212,7 +206,16 @@ class _LinearK4B16Fn(torch.autograd.Function):
         N = w.shape[0]
         x2 = x.reshape(-1, K)
         x2 = torch.nn.functional.pad(x2, (0, 4 - K)) if K < 4 else (x2 if x2.is_contiguous() else x2.contiguous())
-        w4 = torch.nn.functional.pad(w, (0, 4 - K)) if K < 4 else w.contiguous()
+        w4 = None
+        if w_param is not None and K < 4:      # the zero-padded [N,4] weight is a cache of the parameter, like the packs
+            key = hip_linear._pack_key(w_param)
+            hit = w_param.__dict__.get("_nsdp_w4")
+            if hit is not None and hit[0] == key:
+                w4 = hit[1]
+        if w4 is None:
+            w4 = torch.nn.functional.pad(w, (0, 4 - K)) if K < 4 else w.contiguous()
+            if w_param is not None and K < 4:
+                w_param.__dict__["_nsdp_w4"] = (hip_linear._pack_key(w_param), w4)
         y = k4_forward(x2, w4, b, relu_out)
         ctx.k_orig, ctx.n_out, ctx.x_shape, ctx.has_bias = K, N, x.shape, b is not None
         ctx.save_for_backward(x2, y if relu_out else None, w4 if ctx.needs_input_grad[0] else None)
@@ -226,19 +229,14 @@ class _LinearK4B16Fn(torch.autograd.Function):
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dx = dw = db = None
 
-        def wg(dy2_, x2_, mask_, relu_x_, want_db_):
+        def wg(dy2_, x2_, mask_, relu_x_, want_db_, out_=None):      # (padded K: never accumulates in place)
             gw, gb = k4_wgrad(dy2_, x2_, mask_, relu_x_, want_db_)
             return (gw[:, :K].contiguous() if K < 4 else gw), gb
         if ctx.w_param is not None:
             if hip_linear._use_side_stream(dy2):
                 hip_linear._wgrad_deferred(dy2, x2, y, False, K, ctx.w_param, ctx.b_param, fn=wg)
             else:
-                gw, gb = wg(dy2, x2, y, False, ctx.b_param is not None)
-                with torch.no_grad():
-                    for prm, g in ((ctx.w_param, gw), (ctx.b_param, gb)):
-                        if prm is not None:
-                            g = g.view_as(prm)
-                            prm.grad = g if prm.grad is None else prm.grad.add_(g)
+                hip_linear.wgrad_direct(dy2, x2, y, False, K, ctx.w_param, ctx.b_param, fn=wg)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = wg(dy2, x2, y, False, ctx.has_bias)
         if ctx.needs_input_grad[0]:

@@ -336,3 +336,55 @@ def test_without_the_private_engine_hooks_gradients_stay_on_the_main_stream():
         hip_linear._HAVE_ENGINE_HOOKS = was
     assert not called
     assert torch.allclose(lin.weight.grad, ref_w, rtol=1e-5, atol=1e-3) and torch.allclose(lin.bias.grad, ref_b, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("side", ["0", "1"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("k,n,M", [(128, 120, 4096), (200, 200, 40000), (3, 120, 4096)])
+def test_shared_parameters_and_existing_grads_accumulate_in_the_kernel(side, dtype, k, n, M):
+    """A parameter used several times in one graph (FlowArbitrary runs one encoder three times) and an existing `.grad`
+    (flat-bucket views, micro-batch accumulation): the weight-gradient kernels add into the buffer that is already there
+    (their `accumulate` flag), on the side stream and on the main stream, instead of through extra add kernels -- same sums
+    as autograd's, and the `.grad` tensor object (a bucket view) is kept."""
+    from nsdp_amd import hip_linear, precision
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(k, n).to(DEV)
+    xs = [torch.randn(M, k, device=DEV) for _ in range(3)]
+    was = hip_linear._OVERLAP_WGRAD
+    hip_linear._OVERLAP_WGRAD = side == "1"
+    try:
+        ref = torch.autograd.grad(sum(F.linear(x, lin.weight, lin.bias).square().sum() for x in xs), [lin.weight, lin.bias])
+        tol = dict(rtol=2e-2, atol=2e-2 * float(ref[0].abs().max())) if dtype == "bf16" else dict(rtol=1e-4, atol=1e-4 * float(ref[0].abs().max()))
+        with precision.storage(dtype):
+            cast = (lambda t: t.to(torch.bfloat16)) if (dtype == "bf16" and k != 3) else (lambda t: t)
+            # (a) three uses in one graph, .grad empty before
+            sum(hip_linear.linear(cast(x), lin.weight, lin.bias, params=True).float().square().sum() for x in xs).backward()
+            torch.cuda.synchronize()
+            assert torch.allclose(lin.weight.grad, ref[0], **tol) and torch.allclose(lin.bias.grad, ref[1], **tol)
+            # (b) a second pass into the existing .grad (kept as the same tensor objects: flat-bucket views stay views)
+            gw, gb = lin.weight.grad, lin.bias.grad
+            sum(hip_linear.linear(cast(x), lin.weight, lin.bias, params=True).float().square().sum() for x in xs).backward()
+            torch.cuda.synchronize()
+            assert lin.weight.grad is gw and lin.bias.grad is gb
+            assert torch.allclose(gw, 2 * ref[0], **tol) and torch.allclose(gb, 2 * ref[1], **tol)
+    finally:
+        hip_linear._OVERLAP_WGRAD = was
+
+
+def test_in_place_accumulation_launches_no_add_kernels():
+    """The point of the accumulate flag: no ATen add per extra use of a parameter."""
+    from nsdp_amd import hip_linear
+    from torch.profiler import profile, ProfilerActivity
+    torch.manual_seed(6)
+    lin = torch.nn.Linear(128, 128).to(DEV)
+    xs = [torch.randn(4096, 128, device=DEV) for _ in range(3)]
+
+    def run():
+        sum(hip_linear.linear(x, lin.weight, lin.bias, params=True).square().sum() for x in xs).backward()
+    run()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        run()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events()]
+    assert names.count("aten::add_") == 0, names.count("aten::add_")      # (was: one per extra use and parameter)

@@ -15,7 +15,7 @@ python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_bench_forward
 python bench.py --dtype bf16 --workload arbitrary_train --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary_bf16.json 2>/dev/null
 python bench.py --dtype bf16 --batch 8 --no-cpu-baseline > gpurun_out/${tag}_bench_b8_bf16.json 2>/dev/null
 # the self-launch path: two ranks on this one GPU over gloo (the RCCL path needs a multi-GPU node: driver-run)
-python bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_2ranks_gloo.json 2>/dev/null
+python bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${tag}_bench_2ranks_gloo.json
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o ${tag} -- \
   python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}.log 2>&1

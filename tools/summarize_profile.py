@@ -40,7 +40,7 @@ for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseli
         # (set-up steps + warm-up + timed + the isolated roofline pass of bench.py)
         nsteps = next((int(r["Calls"]) for r in rows if "fps_reg_kernel<256" in r["Name"]), 0)
         if suffix == "_bf16":
-            nsteps //= 2          # FlowArbitrary runs two encoders per step
+            nsteps //= 3          # FlowArbitrary runs three encoder passes per step
         per = f" = {total/1e6/nsteps:.1f} ms of kernel time per step" if nsteps else ""
         f.write(f"total kernel time {total/1e6:.1f} ms over {nsteps} train steps{per}, B=32 shapes\n\n")
         f.write("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|\n")
