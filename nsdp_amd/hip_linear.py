@@ -443,12 +443,18 @@ class InputGradSum:
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None):
+    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0):
+        # bw (backward contract of a Linear -> ReLU -> Linear pair whose middle tensor has no other reader):
+        #   1 on the first layer ("premasked"): the incoming gradient already carries this layer's ReLU mask
+        #   2 on the second ("mask_dx"): dX is masked by (x > 0) in the dX kernel's epilogue, i.e. it IS that gradient
+        # -- the mask is then streamed once (as the out_mask of one kernel) instead of twice (masked prologue of the first
+        # layer's dX kernel + mask operand of its weight gradient), and nothing is saved for it.
+        ctx.premasked, ctx.mask_dx = bool(bw & 1) and relu_out, bool(bw & 2)
         ctx.w_param, ctx.b_param = w_param, b_param
         owner = w_param if w_param is not None else owner     # whose __dict__ carries the pack cache
         ctx.grad_sum = None
         if grad_sum is not None and ctx.needs_input_grad[0]:
-            if relu_in or x.shape[-1] % 4:
+            if relu_in or (bw & 2) or x.shape[-1] % 4:
                 raise ValueError("InputGradSum: layers with a fused input ReLU or a padded input width cannot join")
             grad_sum.total += 1
             grad_sum.pending += 1
@@ -473,7 +479,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
-        ctx.save_for_backward(x2, wpt, y if relu_out else None)
+        ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
@@ -498,7 +504,7 @@ class _LinearFn(torch.autograd.Function):
             # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
             link = ctx.grad_sum
             dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
-                      x2 if ctx.relu_in else None, False, False)
+                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
             if link is not None:         # running sum over the layers that share this input
                 link.pending -= 1
@@ -509,7 +515,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -540,11 +546,14 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False):
+           out_f32=False, premasked=False, mask_dx=False):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
-    ``out_f32``: with bf16 storage (nsdp_amd.precision) this layer's output stays fp32 (the network output)."""
+    ``out_f32``: with bf16 storage (nsdp_amd.precision) this layer's output stays fp32 (the network output).
+    ``premasked`` / ``mask_dx`` (fp32 storage): the two halves of the Linear -> ReLU -> Linear backward contract, see
+    _LinearFn.forward -- ``premasked`` on the layer with ``relu_out``, ``mask_dx`` on the ONLY reader of its output."""
+    bw = (1 if premasked else 0) | (2 if mask_dx else 0)
     w_param = b_param = None
     if (params and _PARAM_GRADS_DIRECT and torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf
             and not _observed(weight)):
@@ -557,6 +566,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
+        if bw:
+            raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
         K, N = x.shape[-1], w2.shape[0]
         if (hb.NATIVE and x.dtype is torch.bfloat16 and 8 <= K <= 256 and K % 8 == 0 and N <= 256
@@ -580,5 +591,5 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param, grad_sum)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner)
+                               bool(relu_out), w_param, b_param, grad_sum, None, bw)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw)

@@ -65,5 +65,6 @@ class ResnetBlockFC(nn.Module):
         if precision.is_bf16():        # (see ops.mlp2: the inner ReLU as fc_1's input ReLU -- no mask streams in backward)
             h = ops.linear(x, self.fc_0, relu_in=True)
             return ops.linear(h, self.fc_1, relu_in=True, residual=x_s)
-        h = ops.linear(x, self.fc_0, relu_in=True, relu=True)             # relu(fc_0(relu(x)))
-        return ops.linear(h, self.fc_1, residual=x_s)                     # x_s + fc_1(h), fused epilogue
+        pair = ops.PAIR_MASK and torch.is_grad_enabled()                 # backward mask contract of ops.mlp2
+        h = ops.linear(x, self.fc_0, relu_in=True, relu=True, premasked=pair)      # relu(fc_0(relu(x)))
+        return ops.linear(h, self.fc_1, residual=x_s, mask_dx=pair)       # x_s + fc_1(h), fused epilogue

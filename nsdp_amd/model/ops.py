@@ -111,12 +111,12 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # dense layers
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
-           out_f32: bool = False) -> torch.Tensor:
+           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
-                             params=True, grad_sum=grad_sum, out_f32=out_f32)
+                             params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx)
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -125,15 +125,26 @@ def input_grad_sum(x: torch.Tensor):
     return hip_linear.InputGradSum() if (torch.is_grad_enabled() and x.requires_grad) else None
 
 
+# A/B knob, default off: 1 = the backward ReLU mask of a Linear -> ReLU -> Linear pair is applied once, by the second
+# layer's dX epilogue.  Measured at B = 32: no gain on forward.yaml (47.6 against 47.8 ms on the same box), 2.5 % SLOWER on
+# FlowArbitrary (125.5 against 122.3 ms): the mask read in the bf16x3 epilogue stalls the store phase for longer than the
+# masked prologue / masked weight-gradient variants cost.
+PAIR_MASK = os.environ.get("NSDP_PAIR_MASK", "0") == "1"
+
+
 def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
     """nn.Sequential(Linear, ReLU, Linear) (fc_delta / fc_gamma / fc_middle).
     bf16 storage: the ReLU is the SECOND layer's fused input ReLU (the tensor in between holds the pre-activation): same
     values, but in the backward pass the second layer's dX epilogue applies the ReLU mask once, and neither the first
     layer's dX kernel nor its weight gradient has to stream a mask tensor next to dY (those kernels are pure streams).
-    fp32 storage keeps the ReLU in the first layer's epilogue: the bf16x3 GEMM's ReLU prologue costs more than the mask
-    operand it saves (measured: +1.9 ms of GEMM time per B = 32 step against -1.2 ms of weight-gradient time)."""
+    fp32 storage keeps the ReLU in the first layer's epilogue (the bf16x3 GEMM's ReLU prologue costs more than the mask
+    operand it saves: +1.9 ms of GEMM time per B = 32 step against -1.2 ms of weight-gradient time).  PAIR_MASK (off by
+    default, measured a loss) moves only the BACKWARD mask: the second layer's dX kernel applies (h > 0) in its epilogue
+    (`mask_dx`), so the first layer's dX kernel and weight gradient take an already masked gradient (`premasked`)."""
     if precision.is_bf16():
         return linear(linear(x, seq[0], grad_sum=grad_sum), seq[2], relu_in=True)
+    if PAIR_MASK and torch.is_grad_enabled():
+        return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, premasked=True), seq[2], mask_dx=True)
     return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum), seq[2])
 
 
