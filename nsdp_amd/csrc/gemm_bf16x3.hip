@@ -446,6 +446,327 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Anti-phase" form (experiment, nsdp_debug_set(6, 128)): ONE 8-wave workgroup per CU whose two 4-wave groups run
+// half a tile period apart, so that the epilogue (stores) and tile prologue of one group sit under the MFMA steps of
+// the other -- while both still share ONE weight stream: the workgroup cycles through the k blocks 0 .. KB-1 forever,
+// one block per barrier-delimited slot, and a group that starts its tile at slot s consumes the blocks in the rotated
+// order s mod KB, s+1 mod KB, ... (a dot product does not care).  A tile takes KB compute slots + E slots in which the
+// group only stores / idles (E = 1 or 2, same parity as KB, so that the half period is a whole number of slots).
+// The stores are posted and never waited for by the group that issued them until its next counted vmcnt wait (gfx9 retires
+// vector memory operations in order): weight pieces are staged by the group that is past the first slot of its tile.
+template <int NT, int PRE>
+__global__ __launch_bounds__(512, 1) void linear_bf16x3_ap_kernel(X3Params p, int E) {
+  static_assert(PRE != 1, "the masked prologue keeps the register path");
+  constexpr int MT = 2, WV = 8;
+  __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][NT * 3 * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 xbuf[2][WV][MT * 2 * 64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wave >> 2, wq = wave & 3;
+  const int li = lane & 15, g = lane >> 4;
+  const int K = p.K, N = p.N;
+  const int KB = (K + 31) >> 5;
+  const int ntiles = (N + 15) >> 4;
+  const int P = KB + E, D = grp ? (P >> 1) : 0, Do = grp ? 0 : (P >> 1);
+  constexpr long long kRowsGt = 4 * MT * 16;                    // rows of one group tile
+  const long long gtiles = (p.M + kRowsGt - 1) / kRowsGt;
+  const long long gstride = 2LL * gridDim.x;
+  auto count = [&](long long first) -> int { return first < gtiles ? static_cast<int>((gtiles - first + gstride - 1) / gstride) : 0; };
+  const int ntl0 = count(2LL * blockIdx.x);
+  const int ntl = count(2LL * blockIdx.x + grp), ntlo = count(2LL * blockIdx.x + (grp ^ 1));
+  const int S_total = (P >> 1) + ntl0 * P;                      // every wave runs exactly this many slots (barriers)
+  long long gt = 2LL * blockIdx.x + grp;
+
+  // activation addresses = wave-uniform tile base (SGPRs) + a 32-bit lane offset: row (clamped into the tensor: rows >= M
+  // are computed and never stored) times the row pitch
+  auto tile_base = [&](long long t) -> const char * {
+    return reinterpret_cast<const char *>(p.X + (t < gtiles ? t : gtiles - 1) * kRowsGt * K);
+  };
+  auto tile_rows = [&](long long t) -> int {
+    const long long left = p.M - (t < gtiles ? t : gtiles - 1) * kRowsGt;
+    return left < kRowsGt ? static_cast<int>(left) : static_cast<int>(kRowsGt);
+  };
+
+  const char *wbase = static_cast<const char *>(p.Wp);      // uniform base + 32-bit lane offset: no per-lane pointer to keep
+  const unsigned lane16 = lane * 16u;
+  const int pieces = ntiles * 3;
+  auto stage = [&](int kb, unsigned buf, int first, int step) {
+    for (int q = first; q < pieces; q += step)
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + ((static_cast<long long>(kb) * pieces + q) << 10) + lane16),
+                                       (lds_ptr_t)(&wbuf[buf][q * 64]), 16, 0, 0);
+  };
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wbuf[0][lane])));
+  constexpr unsigned kBufBytes = NT * 3 * 1024;
+
+  auto xissue = [&](const char *base, int rows, int kb, unsigned xb) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int r = wq * (MT * 16) + mt * 16 + li;
+      r = r < rows ? r : rows - 1;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        int ko = kb * 32 + 16 * hf + 4 * g;
+        ko = ko < K ? ko : (K - 4);
+        const unsigned off = static_cast<unsigned>(r * K + ko) * 4u;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(base + off), (lds_ptr_t)(&xbuf[xb][wave][(mt * 2 + hf) * 64]), 16, 0, 0);
+      }
+    }
+  };
+  struct Planes {
+    u32x4 h[MT], m[MT], l[MT];
+  };
+  auto convert_pair = [&](Planes &pl, int mt, int pr, unsigned xb) {
+    f32x4 v = __builtin_bit_cast(f32x4, xbuf[xb][wave][(mt * 2 + (pr >> 1)) * 64 + lane]);
+    if (PRE == 2) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(v[c], 0.f, __builtin_inff());
+    }
+    unsigned h, m, l;
+    split_pair(v[2 * (pr & 1)], v[2 * (pr & 1) + 1], h, m, l);
+    pl.h[mt][pr] = h; pl.m[mt][pr] = m; pl.l[mt][pr] = l;
+  };
+  auto wrap = [&](int v) { return v >= KB ? v - KB : v; };
+
+  // global slot state (identical in every wave) and the other group's position in its period
+  int s = 0;
+  int kwn = KB > 1 ? 1 : 0;      // (s + 1) mod KB: the weight block staged during slot s
+  int ol = -Do;                  // other group's local slot index (negative: not started)
+  int oi = 0;                    // ... modulo P once started
+  auto other_comp_i = [&]() -> int { return (ol >= 0 && ol < ntlo * P && oi < KB) ? oi : -1; };
+  auto advance = [&]() {
+    ++s;
+    if (++kwn == KB) kwn = 0;
+    ++ol;
+    if (ol > 0) { ++oi; if (oi == P) oi = 0; }
+  };
+  // a slot in which this group does not compute: `staging` only when no group computes at all (then all 8 waves stage)
+  auto passive_slot = [&]() {
+    const bool other_computes = other_comp_i() >= 0;
+    if (!other_computes && s + 1 < S_total && !(p.dbg & 1)) {
+      stage(kwn, (s + 1) & 1u, wave, WV);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    advance();
+  };
+
+  // prologue: weight block 0 by everybody; this group's first tile: blocks ks, ks+1 in flight, the first one split
+  Planes cur, nxt;
+  stage(0, 0u, wave, WV);
+  int ks = D % KB;               // rotated start of the tile
+  const char *xa = tile_base(gt), *xn = tile_base(gt + gstride);
+  int ra = tile_rows(gt), rn = tile_rows(gt + gstride);
+  if (ntl > 0) {
+    xissue(xa, ra, ks, 0u);
+    xissue(xa, ra, wrap(ks + 1), 1u);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ntl > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) convert_pair(cur, mt, pr, 0u);
+  }
+  __syncthreads();
+  if (blockIdx.x & 7) {           // stagger the workgroups so that their store bursts do not coincide
+    for (int i = 0; i < static_cast<int>(blockIdx.x & 7) * KB; ++i) __builtin_amdgcn_s_sleep(10);
+  }
+  for (int i = 0; i < D; ++i) passive_slot();
+
+  constexpr int kConvSteps = NT > 4 ? 4 : NT - 1;
+  constexpr int kConvFirst = NT - kConvSteps;
+  constexpr int kPairs = MT * 4;
+  constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
+  constexpr int kValuPerMfma = (kPerStep * (PRE == 2 ? 10 : 9) + 6 * MT - 1) / (6 * MT);
+  unsigned cs = 0;               // this wave's compute-slot count: X buffer parity
+
+  for (int n = 0; n < ntl; ++n) {
+    const long long row0 = (gt * 4 + wq) * (MT * 16);
+    const bool next_tile = n + 1 < ntl;
+    const int ks_next = (ks + P) % KB;
+    int li_t = li, g_t = g;
+    asm volatile("" : "+v"(li_t), "+v"(g_t));
+    f32x4 acc[MT][NT];
+    if (p.residual) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        long long row = row0 + mt * 16 + li_t;
+        row = row < p.M ? row : (p.M - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          int col = nt * 16 + 4 * g_t;
+          col = col + 4 <= N ? col : (N - 4);
+          const float4 v = *reinterpret_cast<const float4 *>(p.residual + row * N + col);
+          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int i = 0; i < KB; ++i, ++cs) {
+      const unsigned wb = s & 1u, xb = cs & 1u;
+      // who stages the next weight block: the group(s) past the first slot of their tile; the first-slot group only if alone
+      const int oc = other_comp_i();
+      const bool me_stage = i >= 1 || oc < 1;
+      const bool other_stage = oc >= 1 || (oc == 0 && i < 1);
+      if (me_stage && s + 1 < S_total && !(p.dbg & 1)) {
+        if (other_stage) stage(kwn, wb ^ 1u, wave, WV);
+        else stage(kwn, wb ^ 1u, wq, 4);
+      }
+      bool x_issued = false;
+      if (i + 2 < KB) { xissue(xa, ra, wrap(ks + i + 2), xb); x_issued = true; }
+      else if (next_tile) { xissue(xn, rn, wrap(ks_next + (i + 2 - KB)), xb); x_issued = true; }
+      auto xwait_older = [&]() {
+        if (x_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
+      const unsigned wl_addr = lds0 + wb * kBufBytes;
+      u32x4 wh, wm, wl;
+      lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
+      lds_wait(wh, wm, wl);
+      static_for<0, NT>([&](auto I) {
+        constexpr int nt = decltype(I)::value;
+        u32x4 nh, nm, nl;
+        if constexpr (nt + 1 < NT) {
+          lds_read<(nt + 1) * 3072>(nh, wl_addr); lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
+          lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
+        }
+        if constexpr (nt == kConvFirst) xwait_older();
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
+#pragma unroll
+          for (int q = 0; q < kPerStep; ++q) {
+            constexpr int base = (nt - kConvFirst) * kPerStep;
+            if (base + q < kPairs) convert_pair(nxt, (base + q) >> 2, (base + q) & 3, xb ^ 1u);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.l[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wl, cur.h[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wm, cur.m[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.m[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wm, cur.h[mt], acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mfma_bf16(wh, cur.h[mt], acc[mt][nt]);
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
+#pragma unroll
+          for (int q = 0; q < 6 * MT; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);
+          }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+a"(acc[mt][nt]));
+        if constexpr (nt >= kConvFirst && nt < kConvFirst + kConvSteps) {
+#pragma unroll
+          for (int q = 0; q < kPerStep; ++q) {
+            constexpr int base = (nt - kConvFirst) * kPerStep;
+            if (base + q < kPairs) {
+              const int mt = (base + q) >> 2, pr = (base + q) & 3;
+              asm volatile("" : "+v"(nxt.h[mt][pr]), "+v"(nxt.m[mt][pr]), "+v"(nxt.l[mt][pr]));
+            }
+          }
+        }
+        if constexpr (nt + 1 < NT) {
+          lds_wait(nh, nm, nl);
+          wh = nh; wm = nm; wl = nl;
+        }
+      });
+      xwait_older();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      cur = nxt;
+      advance();
+    }
+
+    // epilogue: posted stores, nothing waits for them here
+    if (row0 < p.M && !(p.dbg & 8)) {
+      const bool full_rows = row0 + MT * 16 <= p.M;
+      int li_e = li, g_e = g;
+      asm volatile("" : "+v"(li_e), "+v"(g_e));
+      float4 bias4[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bias4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + 4 * g_e;
+          bias4[nt] = *reinterpret_cast<const float4 *>(p.bias + (col + 4 <= N ? col : (N - 4)));
+        }
+      }
+      auto otile = [&](int nt, auto has_omask, auto guarded) {
+        const int col = nt * 16 + 4 * g_e;
+        const bool cv = col + 4 <= N;
+        const int colc = cv ? col : (N - 4);
+        const float4 bv = bias4[nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const long long row = row0 + mt * 16 + li_e;
+          const bool rv = !decltype(guarded)::value || row < p.M;
+          const long long rowc = rv ? row : (p.M - 1);
+          float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+          if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (decltype(has_omask)::value) {
+            const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
+            v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f;
+          }
+          const f32x4 vv = {v.x, v.y, v.z, v.w};
+          if (decltype(guarded)::value) {
+            if (cv && rv) *reinterpret_cast<f32x4 *>(p.Y + rowc * N + colc) = vv;
+          } else {
+            *reinterpret_cast<f32x4 *>(p.Y + row * N + col) = vv;
+          }
+        }
+      };
+      auto epilogue = [&](auto has_omask) {
+        const int full_tiles = N >> 4;
+        if (full_rows) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            if (nt < full_tiles) otile(nt, has_omask, std::false_type{});
+            else if (nt * 16 < N) otile(nt, has_omask, std::true_type{});
+          }
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            if (nt * 16 < N) otile(nt, has_omask, std::true_type{});
+        }
+      };
+      if (p.out_mask) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+    }
+    for (int e = 0; e < E; ++e) passive_slot();
+    gt += gstride;
+    ks = ks_next;
+    xa = xn; ra = rn;
+    xn = tile_base(gt + gstride); rn = tile_rows(gt + gstride);
+  }
+  while (s < S_total) passive_slot();
+}
+
+template <int NT, int PRE>
+void launch_x3_ap(const X3Params &p, hipStream_t st) {
+  const int KB = (p.K + 31) >> 5;
+  int E = (KB & 1) ? 1 : 2;
+  if ((p.dbg >> 8) & 3) E = ((p.dbg >> 8) & 3) + ((((p.dbg >> 8) & 3) ^ KB) & 1);       // override, parity fixed up
+  const long long gtiles = (p.M + 127) / 128;
+  const long long wgs = (gtiles + 1) / 2;
+  const unsigned grid = static_cast<unsigned>(wgs < nsdp::num_cus() ? wgs : nsdp::num_cus());
+  NSDP_TRACE("linear_bf16x3_ap<%d,%d> E=%d", NT, PRE, E);
+  hipLaunchKernelGGL((linear_bf16x3_ap_kernel<NT, PRE>), dim3(grid), dim3(512), 0, st, p, E);
+}
+
 // bf16x3 packs.  Wp  [ceil(K/32)][ceil(N/16)][3 planes][64 lanes][8 bf16]:
 //   element j of lane 16 g + li of (kb, tn) = plane_p( W[16 tn + li][32 kb + kperm(g, j)] ),
 //   kperm(g, j) = 16 (j / 4) + 4 g + j % 4: the k permutation of the activation loads (above)
@@ -495,7 +816,10 @@ int launch_x3(const X3Params &p, hipStream_t st) {
     if (pre == 0) launch_x3_pre<2, 13, 0, 4, true>(p, st, 2);
     else launch_x3_pre<2, 13, 2, 4, true>(p, st, 2);
   } else if (two_waves) {
-    if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8>(p, st);
+    if (g_x3_dbg & 128) {
+      if (pre == 0) launch_x3_ap<13, 0>(p, st);
+      else launch_x3_ap<13, 2>(p, st);
+    } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8>(p, st);
     else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
   } else {
     constexpr int MT0 = NT >= 16 ? 3 : 4;

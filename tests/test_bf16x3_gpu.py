@@ -149,3 +149,29 @@ def test_autograd_routes_large_layers_through_bf16x3_and_matches_fp32_path():
     for a, e in zip(*outs):
         s = float(e.abs().max())
         assert float((a - e).abs().max()) <= 4e-6 * s
+
+
+@pytest.mark.parametrize("M,K,N,res,relu_in,relu_out", [(524288 + 129 * 7, 200, 200, False, False, True),
+                                                        (600001, 64, 144, True, True, False)])
+def test_linear_bf16x3_antiphase_variant_matches_fp64(M, K, N, res, relu_in, relu_out):
+    """The experimental anti-phase form of the 8-wave kernel (nsdp_debug_set(6, 128): two 4-wave groups half a tile apart
+    on one rotating weight stream, csrc/gemm_bf16x3.hip) computes the same layer: fp32-level error against fp64 on sampled
+    rows (ragged last tile included), and within rounding of the standard form (the k blocks are summed in rotated order)."""
+    from nsdp_amd import _lib, hip_linear
+    g = torch.Generator(device="cpu").manual_seed(M + K)
+    x, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
+    r = _rand(g, M, N) if res else None
+    wp = hip_linear.pack_weight_x3(w)[0]
+    y_std = hip_linear._fwd_x3(x, wp, N, b, r, None, None, relu_in, relu_out)
+    _lib.lib().nsdp_debug_set(6, 128)
+    try:
+        y_ap = hip_linear._fwd_x3(x, wp, N, b, r, None, None, relu_in, relu_out)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().nsdp_debug_set(6, 0)
+    idx = torch.cat([torch.arange(0, 256, device=DEV), torch.arange(M - 256, M, device=DEV),
+                     torch.randint(0, M, (4096,), device=DEV)])
+    ref = _ref64(x[idx], w, b, None if r is None else r[idx], None, None, relu_in, relu_out)
+    scale = float(ref.abs().max())
+    assert float((y_ap[idx].double() - ref).abs().max()) / scale <= 1.5e-6
+    assert float((y_ap - y_std).abs().max()) / scale <= 3e-6
