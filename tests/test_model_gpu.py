@@ -253,6 +253,37 @@ def test_dense_inference_step_matches_oracle():
     assert abs(loss - float(((ref_v - verts) ** 2).sum(-1).mean() / 2)) < 1e-5
 
 
+def test_config5_dense_inference_b4_100k_queries_matches_oracle():
+    """BASELINE config 5 at its full size: 4 shapes x 100 000 query points through the fused decoder kernel.  A query's
+    output depends on the encoder's latent and on that query alone, so the CPU oracle is run on a 3000-query sample per shape
+    (both ends of the 100 k, where a ragged last tile would show) and compared with the same rows of the full run; the
+    layer-by-layer path is compared on all 400 k rows."""
+    from nsdp_amd import hip_decoder
+    cfg = model_cfg("forward", [2048, 500, 100])
+    nq = 100000
+    data = synth.make_batch(555, 4, 2048, nq)
+    model, _, state = build_product(cfg, 555, DEV)
+    model.eval()
+    dd = to_dev(data, DEV)
+    with torch.no_grad():
+        out = run_forward(model, cfg, dd)
+        hip_decoder.ENABLED = False
+        try:
+            out_layered = run_forward(model, cfg, dd)
+        finally:
+            hip_decoder.ENABLED = True
+        pick = np.concatenate([np.arange(0, 1500), np.arange(nq - 1500, nq)])
+        q = data["space_samples_src"][:, pick].copy()
+        sd = tdnet_ref.to_torch_state(state)
+        torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+        ref = tdnet_ref.model_forward(sd, cfg["model"], {"surface_samples_inputs": torch.from_numpy(data["surface_samples_inputs"]),
+                                                          "q": torch.from_numpy(q)}, queries_key="q").numpy()
+    assert out.shape == (4, nq, 3)
+    assert l2_err(out[:, pick].cpu().numpy(), ref) <= TOL_L2
+    assert l2_err(out_layered[:, pick].cpu().numpy(), ref) <= TOL_L2
+    assert l2_err(out.cpu().numpy(), out_layered.cpu().numpy()) <= TOL_L2
+
+
 def test_flat_bucket_gradients_equal_plain_gradients_on_gpu():
     """GradAllReducer's .grad views (the data-parallel path) must receive exactly what plain autograd
     produces, including through the hand-written backward kernels."""
