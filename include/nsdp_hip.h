@@ -156,16 +156,6 @@ int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, v
 int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,
                            const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
                            int relu_in, int relu_out, void *stream);
-/* The same layer with its ReLU masks as BITS instead of fp32 tensors (1 bit instead of 32 per masked value):
- *   relu_bits_out (needs relu_out): the kernel also writes bits of (Y > 0), nsdp_relu_bits_bytes(M, N) bytes, 32-byte aligned.
- *   mask_bits: pre(X) = X where the bit is set (alternative to `mask`; not with relu_in) -- the bits a producer wrote for
- *   the [M, K] tensor the mask belongs to (backward: dX = (dY * relu'(Y)) W reads dY [M, N] as its X and Y's bits as mask_bits).
- * Layout: 64-bit words, word ((rb * ceil(N/16) + nt) * 4 + j), bit (16 g + i)  <=>  element [16 rb + i][16 nt + 4 g + j] > 0
- * -- one wave ballot over the kernel's accumulator lane layout; rows >= M / columns >= N hold unspecified bits. */
-long long nsdp_relu_bits_bytes(long long M, int N);
-int nsdp_linear_bf16x3_bits_f32(const float *X, const void *Wp, const float *bias, const float *residual,
-                                const float *mask, const void *mask_bits, const float *out_mask, float *Y,
-                                void *relu_bits_out, long long M, int N, int K, int relu_in, int relu_out, void *stream);
 
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.

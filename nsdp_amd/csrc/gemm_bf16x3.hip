@@ -58,12 +58,6 @@ struct X3Params {
   long long M;
   int N, K;
   int relu_in, relu_out;
-  // ReLU masks as bits (64-bit words, one per (16-row block rb, 16-column tile nt, j = 0..3): bit 16 g + li <=>
-  // element [16 rb + li][16 nt + 4 g + j] > 0 -- exactly what one ballot over this kernel's accumulator / operand lane
-  // layout yields, so the producer writes it with 4 ballots per output tile and the consumer applies it with one
-  // v_cndmask per value, its condition an SGPR pair fetched by scalar loads: 1 bit instead of 32 per masked value)
-  const unsigned long long *mask_bits;   // prologue: X *= bit (layout over [M, K])
-  unsigned long long *bits_out;          // epilogue: bits of (Y > 0) (layout over [M, N]); with relu_out
   int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores -- wrong results,
             // timing only
 };
@@ -110,9 +104,7 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
 // 256 registers per lane -- the second wave of a SIMD issues MFMAs while the first splits, stores or waits)
 // XREG: raw activations through registers even without a mask (frees the 32 KiB X staging: at 13 n tiles two 4-wave
 // workgroups then fit into one CU's LDS)
-// BOUT: the epilogue also writes the ReLU mask of the tile as bits (p.bits_out); its own instantiations, because the four
-// ballots and their store cost the tightest unmasked variants the registers they keep their loads in flight with
-template <int MT, int NT, int PRE, int WV, bool XREG = false, bool BOUT = false>
+template <int MT, int NT, int PRE, int WV, bool XREG = false>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
@@ -184,31 +176,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       }
     }
   };
-  // PRE == 3: the mask words of the k block being split next, [mt][half][j] (wave-uniform: scalar loads)
-  constexpr bool kBits = PRE == 3;
-  unsigned long long mw[kBits ? MT : 1][2][4];
-  auto load_bits = [&](long long t, int kb) {
-    if constexpr (kBits) {
-      const long long mask_rbs = (p.M + 15) >> 4;
-      const int mask_nts = (K + 15) >> 4;
-      const long long rb0 = (t * WV + wave) * MT;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        long long rb = rb0 + mt;
-        rb = rb < mask_rbs ? rb : (mask_rbs - 1);
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          int nt = 2 * kb + hf;
-          nt = nt < mask_nts ? nt : (mask_nts - 1);      // past K: any bits do (the packed weights are zero there)
-          // constant address space: the words were written by an earlier launch, and only an SMEM load leaves them in SGPRs
-          typedef const __attribute__((address_space(4))) unsigned long long *const_u64_ptr;
-          const const_u64_ptr w = (const_u64_ptr)(reinterpret_cast<uintptr_t>(p.mask_bits + (rb * mask_nts + nt) * 4));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) mw[mt][hf][j] = w[j];
-        }
-      }
-    }
-  };
   struct Planes {
     u32x4 h[MT], m[MT], l[MT];
   };
@@ -227,11 +194,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     if (PRE == 2) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(v[c], 0.f, __builtin_inff());   // max(v, 0), one VALU op
-    }
-    if constexpr (PRE == 3) {     // keep where this lane's bit of the (wave-uniform) mask word is set
-#pragma unroll
-      for (int c = 2 * (pr & 1); c < 2 * (pr & 1) + 2; ++c)
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(v[c]) : "v"(v[c]), "s"(mw[mt][pr >> 1][c]));
     }
     unsigned h, m, l;
     split_pair(v[2 * (pr & 1)], v[2 * (pr & 1) + 1], h, m, l);
@@ -252,7 +214,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   stage(0, 0);
   xissue(xa, ma, 0, 0u);
   if constexpr (kXLds) xissue(xa, ma, 1, 1u);
-  load_bits(tile, 0);
   xwait();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -325,9 +286,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
       const unsigned wl_addr = lds0 + buf * kBufBytes;
-      // mask words of the block split during this iteration (the next block of this tile, or the next tile's first)
-      if (kb + 1 < KB) load_bits(tile, kb + 1);
-      else load_bits(tile + stride, 0);
       u32x4 wh, wm, wl;
       lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
       lds_wait(wh, wm, wl);
@@ -439,13 +397,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           const long long rowc = rv ? row : (p.M - 1);
           float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
           if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          if constexpr (BOUT) {     // the ReLU mask of this tile as four ballots, stored by lanes 0..3
-            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v.x > 0.f), b1 = __builtin_amdgcn_ballot_w64(v.y > 0.f);
-            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(v.z > 0.f), b3 = __builtin_amdgcn_ballot_w64(v.w > 0.f);
-            const long long rb = (row0 >> 4) + mt;
-            if (rb < ((p.M + 15) >> 4) && lane < 4)
-              p.bits_out[(rb * ((N + 15) >> 4) + nt) * 4 + lane] = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
-          }
           if (decltype(has_omask)::value) {
             const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
             v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f;
@@ -827,7 +778,7 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   nsdp::pack::x3_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
-template <int MT, int NT, int PRE, int WV, bool XREG = false, bool BOUT = false>
+template <int MT, int NT, int PRE, int WV, bool XREG = false>
 void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
@@ -836,13 +787,13 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long slots = static_cast<long long>(nsdp::num_cus()) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
   NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu);
-  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, BOUT>), dim3(grid), dim3(WV * 64), 0, st, p);
+  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
 // (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
 template <int NT>
 int launch_x3(const X3Params &p, hipStream_t st) {
-  const int pre = p.mask ? 1 : p.mask_bits ? 3 : (p.relu_in ? 2 : 0);
+  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   // measured per class: up to 13 n tiles two waves per SIMD with 2 row tiles each win (1.36 -> 1.20 ms on the
@@ -851,39 +802,30 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   // Up to 8 n tiles the two waves per SIMD come from TWO 4-wave workgroups per CU (2 x 80 KiB of LDS, exactly the
   // CU's 160 KiB): they share no barrier, so one's epilogue stores overlap the other's MFMA steps (2-10 % faster than
   // one 8-wave workgroup, bit-identical results).  13 n tiles would need 2 x 110 KiB.
-  // The bit-mask prologue (pre == 3) costs one VALU op per value and no registers in flight: it takes the forms of the
-  // unmasked kernel.
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
-  auto plain = [&](auto PRE, auto BO) {      // pre in {0, 2, 3}; BO: write the ReLU mask bits (forward launches: pre 0 / 2)
-    constexpr int kPre = decltype(PRE)::value;
-    constexpr bool kBo = decltype(BO)::value;
-    if (NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), kPre, 4, false, kBo>(p, st, 2);
-    else if (NT == 13 && two_waves && p.M <= (1 << 19) && !kBo) {
-      // 13 n tiles, up to ~0.5 M rows: the same two-workgroups-per-CU form, made to fit (2 x 78 KiB) by taking the raw
-      // activations through registers instead of the 32 KiB LDS staging: 8-19 % faster there, on par at 1.8 M rows
-      // (not with the mask bits: that form has no register to spare)
-      launch_x3_pre<2, 13, kPre, 4, true>(p, st, 2);
-    } else if (two_waves) {
-      if constexpr (kPre != 3 && !kBo) {
-        if (g_x3_dbg & 128) { launch_x3_ap<13, kPre>(p, st); return; }
-      }
-      launch_x3_pre<2, (NT > 8 ? NT : 13), kPre, 8, false, kBo>(p, st);
-    } else {
-      // (the bit-mask prologue keeps MT x 8 mask words in SGPRs: two row tiles, or they spill)
-      constexpr int MT0 = kPre == 3 ? 2 : NT >= 16 ? 3 : 4;
-      launch_x3_pre<MT0, NT, kPre, 4, false, kBo>(p, st);
-    }
-  };
   // (the masked prologue as well, up to 8 n tiles: 10-25 % over one 4-wave workgroup with more row tiles)
   if (pre == 1 && NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), 1, 4, true>(p, st, 2);
   else if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
-  else if (pre == 3) plain(std::integral_constant<int, 3>{}, std::false_type{});
-  else if (p.bits_out) {
-    if (pre == 0) plain(std::integral_constant<int, 0>{}, std::true_type{});
-    else plain(std::integral_constant<int, 2>{}, std::true_type{});
-  } else if (pre == 0) plain(std::integral_constant<int, 0>{}, std::false_type{});
-  else plain(std::integral_constant<int, 2>{}, std::false_type{});
+  else if (NT <= 8 && two_waves) {
+    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4>(p, st, 2);
+    else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 4>(p, st, 2);
+  } else if (NT == 13 && two_waves && p.M <= (1 << 19)) {
+    // 13 n tiles, up to ~0.5 M rows: the same two-workgroups-per-CU form, made to fit (2 x 78 KiB) by taking the raw
+    // activations through registers instead of the 32 KiB LDS staging: 8-19 % faster there, on par at 1.8 M rows
+    if (pre == 0) launch_x3_pre<2, 13, 0, 4, true>(p, st, 2);
+    else launch_x3_pre<2, 13, 2, 4, true>(p, st, 2);
+  } else if (two_waves) {
+    if (g_x3_dbg & 128) {
+      if (pre == 0) launch_x3_ap<13, 0>(p, st);
+      else launch_x3_ap<13, 2>(p, st);
+    } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8>(p, st);
+    else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
+  } else {
+    constexpr int MT0 = NT >= 16 ? 3 : 4;
+    if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
+    else launch_x3_pre<MT0, NT, 2, 4>(p, st);
+  }
   return nsdp::launch_status("linear_bf16x3_kernel");
 }
 
@@ -920,20 +862,10 @@ int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, v
   return nsdp::launch_status("pack_bf16x3_kernel");
 }
 
-long long nsdp_relu_bits_bytes(long long M, int N) {
-  return M <= 0 || N <= 0 ? 0 : ((M + 15) >> 4) * ((N + 15) >> 4) * 32;
-}
-
-int nsdp_linear_bf16x3_bits_f32(const float *X, const void *Wp, const float *bias, const float *residual,
-                                const float *mask, const void *mask_bits, const float *out_mask, float *Y,
-                                void *relu_bits_out, long long M, int N, int K, int relu_in, int relu_out, void *stream) {
+int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,
+                           const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
+                           int relu_in, int relu_out, void *stream) {
   if (M <= 0 || N <= 0) return 0;
-  NSDP_REQUIRE(!(mask && mask_bits), "linear_bf16x3: mask and mask_bits are alternatives");
-  NSDP_REQUIRE(!(mask_bits && relu_in), "linear_bf16x3: mask_bits with relu_in is not supported");
-  NSDP_REQUIRE(!relu_bits_out || (relu_out && !mask && !mask_bits),
-               "linear_bf16x3: relu_bits_out needs relu_out and no input mask");
-  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(mask_bits) | reinterpret_cast<uintptr_t>(relu_bits_out)) & 31) == 0,
-               "linear_bf16x3: bit masks must be 32-byte aligned");
   NSDP_REQUIRE(X && Wp && Y, "linear_bf16x3: null pointer");
   NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
   NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3: N=%d must be a multiple of 4 and <= 256", N);
@@ -941,21 +873,13 @@ int nsdp_linear_bf16x3_bits_f32(const float *X, const void *Wp, const float *bia
                  reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) |
                  reinterpret_cast<uintptr_t>(mask) | reinterpret_cast<uintptr_t>(out_mask)) & 15) == 0,
                "linear_bf16x3: all operands must be 16-byte aligned");
-  X3Params p{X, Wp, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out,
-             static_cast<const unsigned long long *>(mask_bits), static_cast<unsigned long long *>(relu_bits_out), g_x3_dbg};
+  X3Params p{X, Wp, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out, g_x3_dbg};
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
   if (nt <= 4) return launch_x3<4>(p, st);
   if (nt <= 8) return launch_x3<8>(p, st);
   if (nt <= 13) return launch_x3<13>(p, st);
   return launch_x3<16>(p, st);
-}
-
-int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,
-                           const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
-                           int relu_in, int relu_out, void *stream) {
-  return nsdp_linear_bf16x3_bits_f32(X, Wp, bias, residual, mask, nullptr, out_mask, Y, nullptr, M, N, K, relu_in, relu_out,
-                                     stream);
 }
 
 }  // extern "C"

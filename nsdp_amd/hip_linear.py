@@ -73,25 +73,15 @@ def pack_weight_x3(w, fwd=True, transposed=False):
     return wp, wpt
 
 
-def relu_bits(M, N, device):
-    """Buffer for the ReLU mask of an [M, N] output as bits (layout: include/nsdp_hip.h, nsdp_linear_bf16x3_bits_f32)."""
-    L = lib()
-    L.nsdp_relu_bits_bytes.restype = ctypes.c_longlong
-    return torch.empty(int(L.nsdp_relu_bits_bytes(_ll(M), _ci(N))) // 8, dtype=torch.int64, device=device)
-
-
-def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, mask_bits=None, bits_out=None):
-    """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack.
-    ``mask_bits``: the prologue mask as bits (instead of ``mask``); ``bits_out``: receives the bits of (y > 0)."""
+def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
+    """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack."""
     M, K = x2.shape
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
     with on_device(x2):
-        check(lib().nsdp_linear_bf16x3_bits_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
-                                                optptr(mask), ctypes.c_void_p(mask_bits.data_ptr() if mask_bits is not None else 0),
-                                                optptr(out_mask), fptr(y),
-                                                ctypes.c_void_p(bits_out.data_ptr() if bits_out is not None else 0),
-                                                _ll(M), _ci(N), _ci(K), _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),
-              "nsdp_linear_bf16x3_bits_f32")
+        check(lib().nsdp_linear_bf16x3_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
+                                           optptr(mask), optptr(out_mask), fptr(y), _ll(M), _ci(N), _ci(K),
+                                           _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),
+              "nsdp_linear_bf16x3_f32")
     return y
 
 
@@ -306,7 +296,6 @@ def _pad_cols(t, mult=4):
 # Large layers run on the bf16 matrix pipe with the error-compensated 3-way split (nsdp_linear_bf16x3_f32, fp32
 # rounding-level accuracy, see csrc/gemm_bf16x3.hip); NSDP_BF16X3=0 keeps every layer on the exact-fp32 MFMA path.
 _USE_X3 = os.environ.get("NSDP_BF16X3", "1") != "0"
-RELU_BITS = os.environ.get("NSDP_RELU_BITS", "1") != "0"      # (A/B knob: 0 = the dX kernels read fp32 masks)
 _X3_MIN_ROWS = 32768
 _X3_MIN_ROWS_WGRAD = 2048      # the split-row wgrad kernel already wins at a few thousand rows
 
@@ -432,11 +421,9 @@ def _packs(w, owner, kind, want_t):
     return ent
 
 
-def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, mask_bits=None, bits_out=None):
-    if kind == "x3":
-        return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, mask_bits, bits_out)
-    assert mask_bits is None and bits_out is None
-    return _fwd_wp(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out)
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out):
+    fn = _fwd_x3 if kind == "x3" else _fwd_wp
+    return fn(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out)
 
 
 class InputGradSum:
@@ -488,22 +475,16 @@ class _LinearFn(torch.autograd.Function):
         kind_t = "x3" if _x3_ok(M, Kp, N) else "wp"                    # dX: Kp outputs, N is the reduction dim
         wp = _packs(w, owner, kind, want_t and kind_t == kind)[0]
         wpt = _packs(w, owner, kind_t, True)[1] if want_t else None
-        # ReLU mask for the backward pass as bits, when both the producer (this launch) and the consumer (the dX launch)
-        # are the bf16x3 kernel: the dX kernel then reads 1 bit instead of an fp32 value per element and takes its fast
-        # unmasked forms (the weight gradient still reads y)
-        bits = None
-        if RELU_BITS and relu_out and not ctx.premasked and kind == "x3" and kind_t == "x3" and want_t and N % 4 == 0:
-            bits = relu_bits(M, N, x2.device)
-        y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, None, bits)
+        y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
-        ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None, bits)
+        ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, wpt, y, bits = ctx.saved_tensors
+        x2, wpt, y = ctx.saved_tensors
         N = ctx.n_out
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
@@ -522,10 +503,8 @@ class _LinearFn(torch.autograd.Function):
                 mk = _pad_cols(y) if y is not None else None
             # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
             link = ctx.grad_sum
-            if bits is not None:
-                mk = None
             dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
-                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False, bits)
+                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
             if link is not None:         # running sum over the layers that share this input
                 link.pending -= 1

@@ -175,77 +175,3 @@ def test_linear_bf16x3_antiphase_variant_matches_fp64(M, K, N, res, relu_in, rel
     scale = float(ref.abs().max())
     assert float((y_ap[idx].double() - ref).abs().max()) / scale <= 1.5e-6
     assert float((y_ap - y_std).abs().max()) / scale <= 3e-6
-
-
-def _expected_relu_bits(y):
-    """The bit layout of nsdp_linear_bf16x3_bits_f32 restated with tensor ops: word ((rb * NT + nt) * 4 + j), bit 16 g + i
-    <=> y[16 rb + i][16 nt + 4 g + j] > 0, as (lo, hi) 32-bit halves (rows / columns past the tensor: masked out)."""
-    M, N = y.shape
-    RB, NT = (M + 15) // 16, (N + 15) // 16
-    pos = torch.zeros(RB * 16, NT * 16, dtype=torch.bool, device=y.device)
-    pos[:M, :N] = y > 0
-    valid = torch.zeros_like(pos)
-    valid[:M, :N] = True
-    def words(t):
-        t = t.reshape(RB, 16, NT, 4, 4).permute(0, 2, 4, 3, 1).to(torch.int64)       # [rb, nt, j, g, i]
-        w = (t * (2 ** torch.arange(16, device=y.device, dtype=torch.int64))).sum(-1)   # 16 bits per g
-        return w[..., 0] | (w[..., 1] << 16), w[..., 2] | (w[..., 3] << 16)            # lo: g = 0, 1; hi: g = 2, 3
-    return words(pos), words(valid)
-
-
-@pytest.mark.parametrize("M,K,N,relu_in,omask", [(40000, 200, 200, False, False), (33333, 128, 128, True, True),
-                                                 (70001, 256, 256, False, False), (524288 + 4099, 200, 200, False, False),
-                                                 (36000, 120, 256, False, True)])
-def test_relu_mask_as_bits_producer_and_consumer(M, K, N, relu_in, omask):
-    """ReLU masks as bits: the forward launch writes them next to Y (four ballots per tile), the dX launch applies them in
-    its prologue (one v_cndmask per value on scalar-loaded words) -- the bits equal (Y > 0) in the documented layout, and dX
-    is bit-identical to the launch that reads Y as an fp32 mask, in every kernel form (two workgroups per CU, 8 waves, one
-    wave per SIMD; with the fused input-ReLU mask on the way out)."""
-    from nsdp_amd import hip_linear
-    g = torch.Generator(device="cpu").manual_seed(M + K + N)
-    x, w, b = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, N)
-    dy = _rand(g, M, N)
-    wp, wpt = hip_linear.pack_weight_x3(w, True, True)
-    bits = hip_linear.relu_bits(M, N, DEV)
-    bits.fill_(0x5555555555555555)
-    y = hip_linear._fwd_x3(x, wp, N, b, None, None, None, relu_in, True, None, bits)
-    y_ref = hip_linear._fwd_x3(x, wp, N, b, None, None, None, relu_in, True)
-    assert torch.equal(y, y_ref)
-    (lo, hi), (vlo, vhi) = _expected_relu_bits(y)
-    got = bits.reshape(lo.shape)
-    assert torch.equal(got & 0xFFFFFFFF & vlo, lo) and torch.equal((got >> 32) & 0xFFFFFFFF & vhi, hi)
-    om = x if omask else None          # (backward of a layer with a fused input ReLU: dX is masked by (x > 0) on the way out)
-    dx_bits = hip_linear._fwd_x3(dy, wpt, K, None, None, None, om, False, False, bits)
-    dx_mask = hip_linear._fwd_x3(dy, wpt, K, None, None, y, om, False, False)
-    assert torch.equal(dx_bits, dx_mask)
-    ref = ((dy.double() * (y > 0)) @ w.double())
-    if omask:
-        ref = ref * (x > 0)
-    assert float((dx_bits.double() - ref).abs().max()) / float(ref.abs().max()) <= 1.5e-6
-
-
-def test_relu_bits_in_autograd_match_the_fp32_mask_path():
-    """hip_linear.linear with relu_out at a size that takes the bf16x3 kernels: gradients with NSDP_RELU_BITS on and off are
-    bit-identical (the mask is the same mask), and the traced dX kernel is an unmasked form."""
-    from nsdp_amd import _lib, hip_linear
-    torch.manual_seed(11)
-    lin = torch.nn.Linear(200, 200).to(DEV)
-    x0 = torch.randn(70000, 200, device=DEV)
-    res = []
-    for on in (True, False):
-        hip_linear.RELU_BITS = on
-        try:
-            x = x0.clone().requires_grad_(True)
-            lin.zero_grad()
-            _lib.lib().nsdp_trace_enable(1)
-            hip_linear.linear(x, lin.weight, lin.bias, relu_out=True, params=True).square().sum().backward()
-            torch.cuda.synchronize()
-            buf = __import__("ctypes").create_string_buffer(1 << 16)
-            _lib.lib().nsdp_trace_read(buf, len(buf))
-            _lib.lib().nsdp_trace_enable(0)
-            res.append((x.grad.clone(), lin.weight.grad.clone(), buf.value.decode()))
-        finally:
-            hip_linear.RELU_BITS = True
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    assert ",3," in res[0][2] and ",1," not in res[0][2].replace("wgrad", ""), res[0][2]
-    assert ",1," in res[1][2]
