@@ -80,8 +80,9 @@ def test_nothing_is_spilled_inside_the_mfma_regions():
         assert starts, src
         for a, b in zip(starts, starts[1:] + [len(lines)]):
             body = lines[a:b]
-            if any("s_endpgm" in l for l in body):
-                body = body[:max(i for i, l in enumerate(body) if "s_endpgm" in l) + 1]
+            ends = [i for i, l in enumerate(body) if l.startswith(".Lfunc_end")]     # (kernels the regex skips may follow)
+            if ends:
+                body = body[:ends[0]]
             mf = [i for i, l in enumerate(body) if "v_mfma" in l]
             region = body[mf[0]:mf[-1]]
             bad = []
@@ -117,8 +118,9 @@ def test_bf16_linear_never_touches_a_register_whose_hand_issued_load_is_in_fligh
     assert len(starts) >= 16
     for a, b in zip(starts, starts[1:] + [len(lines)]):
         body = lines[a:b]
-        if any("s_endpgm" in l for l in body):
-            body = body[:max(i for i, l in enumerate(body) if "s_endpgm" in l) + 1]
+        ends = [i for i, l in enumerate(body) if l.startswith(".Lfunc_end")]
+        if ends:
+            body = body[:ends[0]]
         assert not any("scratch_" in l for l in body), lines[a][:80]
         inflight, in_asm, bad = set(), False, []
         for l in body:
