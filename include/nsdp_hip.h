@@ -165,6 +165,13 @@ size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K);
 int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
                           float *db, long long M, int N, int K, int accumulate, float *workspace,
                           size_t workspace_bytes, void *stream);
+/* K = 4 layers with a fused output ReLU (the first layer of a position-encoding MLP: 16-byte input rows, [M, N] output):
+ * the same gradients with the ReLU mask RECOMPUTED from X [M,4], W [N,4] (row-major, zero-padded K = 3) and bias [N] (or
+ * NULL) -- relu'(X W^T + bias), bit for bit the decision of nsdp_linear_f32's K = 4 kernel -- instead of read back from
+ * the [M, N] output: half the bytes.  Workspace as nsdp_linear_wgrad_f32 with K = 4. */
+int nsdp_linear_wgrad_k4_remask_f32(const float *dY, const float *X, const float *W, const float *bias, float *dW,
+                                    float *db, long long M, int N, int accumulate, float *workspace,
+                                    size_t workspace_bytes, void *stream);
 
 /* nsdp_linear_wgrad_f32 on the bf16 matrix pipe (error-compensated 3-way split of both operands, fp32 rounding-level
  * accuracy, csrc/wgrad_bf16x3.hip).  Same contract; shapes must satisfy nsdp_linear_wgrad_bf16x3_supported

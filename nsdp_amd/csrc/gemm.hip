@@ -473,6 +473,12 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 // float -- a pure output stream.  N/4 lanes per row, each with the 4 x 4 weights and the bias of its four channels in
 // registers, one 16-byte load of the row's coordinates and one float4 store per row.  WP selects where a weight
 // row lives (fragment-major pack: row n of the only k block is float4 number (n / 16) * 64 + n % 16).
+// pre-activation of a K = 4 layer: ONE expression for the forward kernel and for the weight-gradient kernel that
+// recomputes the layer's ReLU mask from its 16-byte input rows instead of reading the [M, N] output back
+__device__ __forceinline__ float k4_preact(float4 xv, float4 w, float b) {
+  return b + (xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w);
+}
+
 template <bool WP>
 __global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
   const int N = p.N;
@@ -502,10 +508,10 @@ __global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
       float4 xv = x[u];
       if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
       float4 y;
-      y.x = b.x + (xv.x * w[0].x + xv.y * w[0].y + xv.z * w[0].z + xv.w * w[0].w);
-      y.y = b.y + (xv.x * w[1].x + xv.y * w[1].y + xv.z * w[1].z + xv.w * w[1].w);
-      y.z = b.z + (xv.x * w[2].x + xv.y * w[2].y + xv.z * w[2].z + xv.w * w[2].w);
-      y.w = b.w + (xv.x * w[3].x + xv.y * w[3].y + xv.z * w[3].z + xv.w * w[3].w);
+      y.x = k4_preact(xv, w[0], b.x);
+      y.y = k4_preact(xv, w[1], b.y);
+      y.z = k4_preact(xv, w[2], b.z);
+      y.w = k4_preact(xv, w[3], b.w);
       if (p.relu_out) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
       if (rr < p.M) *reinterpret_cast<float4 *>(p.Y + rr * N + 4 * cq) = y;
     }
@@ -558,6 +564,7 @@ struct WgradParams {
   int N, K;
   long long rows_per_chunk;  // multiple of 16
   int want_db;
+  const float *W0 = nullptr, *b0 = nullptr;   // K = 4 only: recompute the ReLU mask (W0 row-major [N][4], b0 [N] or null)
 };
 
 // kWgN = n-tiles per wave (the workgroup's 4 waves cover 4*kWgN n-tiles >= N/16), TK = k-tiles per wave
@@ -844,7 +851,9 @@ void dispatch_wgrad_k(const WgradParams &p, unsigned chunks, int ktiles, hipStre
 // their column sums; the row slots of a workgroup are combined through LDS in fixed order and written as one partial
 // in the layout of reduce_partials_kernel.  The MFMA kernel it replaces here ran at 2.9 TB/s with a quarter of its
 // tile rows padding.
-template <bool MASK>
+// MASK: 0 none, 1 dY *= (mask > 0) with mask [M, N] read from memory, 2 the same mask RECOMPUTED from the layer's input
+// rows (already loaded: they are the X operand) and its weights: relu'(x W0^T + b0), bit for bit the forward kernel's
+template <int MASK>
 __global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
   __shared__ float red[256][21];       // 16 products + 4 column sums per thread (padded: conflict-free columns)
   const int N = p.N;
@@ -862,6 +871,12 @@ __global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) a[c][k] = 0.f;
   }
+  float4 w0[4], b0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MASK == 2 && active) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w0[c] = *reinterpret_cast<const float4 *>(p.W0 + static_cast<long long>(4 * cq + c) * 4);
+    if (p.b0) b0 = *reinterpret_cast<const float4 *>(p.b0 + 4 * cq);
+  }
   if (active) {
     constexpr int U = 4;
     for (long long r = r0 + sub; r < r1; r += static_cast<long long>(U) * slots) {
@@ -871,14 +886,14 @@ __global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
         long long rr = r + static_cast<long long>(u) * slots;
         rr = rr < r1 ? rr : (r1 - 1);                  // clamped re-read, zeroed below
         dy[u] = *reinterpret_cast<const float4 *>(p.dY + rr * N + 4 * cq);
-        if (MASK) mk[u] = *reinterpret_cast<const float4 *>(p.mask + rr * N + 4 * cq);
+        if (MASK == 1) mk[u] = *reinterpret_cast<const float4 *>(p.mask + rr * N + 4 * cq);
         x[u] = *reinterpret_cast<const float4 *>(p.X + rr * 4);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool rv = r + static_cast<long long>(u) * slots < r1;
         float d[4] = {dy[u].x, dy[u].y, dy[u].z, dy[u].w};
-        if (MASK) {
+        if (MASK == 1) {
           d[0] = mk[u].x > 0.f ? d[0] : 0.f; d[1] = mk[u].y > 0.f ? d[1] : 0.f;
           d[2] = mk[u].z > 0.f ? d[2] : 0.f; d[3] = mk[u].w > 0.f ? d[3] : 0.f;
         }
@@ -886,6 +901,11 @@ __global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
         if (p.relu_x) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) xv[k] = fmaxf(xv[k], 0.f);
+        }
+        if (MASK == 2) {
+          const float4 xq = make_float4(xv[0], xv[1], xv[2], xv[3]);
+          d[0] = k4_preact(xq, w0[0], b0.x) > 0.f ? d[0] : 0.f; d[1] = k4_preact(xq, w0[1], b0.y) > 0.f ? d[1] : 0.f;
+          d[2] = k4_preact(xq, w0[2], b0.z) > 0.f ? d[2] : 0.f; d[3] = k4_preact(xq, w0[3], b0.w) > 0.f ? d[3] : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -1092,9 +1112,9 @@ size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K) {
   return static_cast<size_t>(pl.slots) * (static_cast<size_t>(N) * K + N) * sizeof(float);
 }
 
-int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
-                          float *db, long long M, int N, int K, int accumulate, float *workspace,
-                          size_t workspace_bytes, void *stream) {
+static int wgrad_f32_impl(const float *dY, const float *X, const float *mask, const float *remask_W,
+                          const float *remask_bias, int relu_x, float *dW, float *db, long long M, int N, int K,
+                          int accumulate, float *workspace, size_t workspace_bytes, void *stream) {
   if (N <= 0 || K <= 0) return 0;
   NSDP_REQUIRE(dW, "linear_wgrad: null output");
   NSDP_REQUIRE(N <= 256, "linear_wgrad: N=%d > 256 is not supported", N);
@@ -1117,10 +1137,19 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
     nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K,
                             4.0 * (static_cast<double>(M) * (K + N)));
     const unsigned gx = static_cast<unsigned>(chunks);
-    if (K == 4 && N % 4 == 0 && N >= 16 && pl.slots == chunks && pl.grid_y == 1 &&
-        ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0) {
-      if (mask) hipLaunchKernelGGL((linear_wgrad_k4_kernel<true>), dim3(gx), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((linear_wgrad_k4_kernel<false>), dim3(gx), dim3(256), 0, st, p);
+    const bool k4 = K == 4 && N % 4 == 0 && N >= 16 && pl.slots == chunks && pl.grid_y == 1 &&
+        ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0;
+    if (remask_W) {
+      NSDP_REQUIRE(k4 && !mask, "linear_wgrad_k4_remask: K = 4, N %% 4 == 0, N >= 16, 16-byte aligned operands (N=%d K=%d)", N, K);
+      NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(remask_W) | reinterpret_cast<uintptr_t>(remask_bias)) & 15) == 0,
+                   "linear_wgrad_k4_remask: weights / bias must be 16-byte aligned");
+      p.W0 = remask_W;
+      p.b0 = remask_bias;
+    }
+    if (k4) {
+      if (p.W0) hipLaunchKernelGGL((linear_wgrad_k4_kernel<2>), dim3(gx), dim3(256), 0, st, p);
+      else if (mask) hipLaunchKernelGGL((linear_wgrad_k4_kernel<1>), dim3(gx), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((linear_wgrad_k4_kernel<0>), dim3(gx), dim3(256), 0, st, p);
     } else if (pl.vec4) {
       const dim3 grid(gx, 1);
       if (pl.threads == 512)
@@ -1140,6 +1169,20 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
                      st, workspace, static_cast<int>(pl.slots), nw + N, nw, dW, static_cast<long long>(N), db,
                      accumulate);
   return nsdp::launch_status("reduce_partials_kernel");
+}
+
+int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                          float *db, long long M, int N, int K, int accumulate, float *workspace,
+                          size_t workspace_bytes, void *stream) {
+  return wgrad_f32_impl(dY, X, mask, nullptr, nullptr, relu_x, dW, db, M, N, K, accumulate, workspace, workspace_bytes,
+                        stream);
+}
+
+int nsdp_linear_wgrad_k4_remask_f32(const float *dY, const float *X, const float *W, const float *bias, float *dW,
+                                    float *db, long long M, int N, int accumulate, float *workspace,
+                                    size_t workspace_bytes, void *stream) {
+  NSDP_REQUIRE(W, "linear_wgrad_k4_remask: null weights");
+  return wgrad_f32_impl(dY, X, nullptr, W, bias, 0, dW, db, M, N, 4, accumulate, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

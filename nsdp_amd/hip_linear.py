@@ -205,6 +205,41 @@ def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig, out=None):
     return dw, db
 
 
+REMASK_K4 = os.environ.get("NSDP_REMASK_K4", "1") != "0"      # (A/B knob: 0 = the K = 4 weight gradient reads the fp32 mask)
+
+
+def _padded_w4(w_param):
+    """Row-major [N, 4] copy of a K = 3 / 4 weight (zero-padded), cached on the parameter like the packs."""
+    key = _pack_key(w_param)
+    hit = w_param.__dict__.get("_nsdp_w4")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = w_param.detach()
+    w = w.squeeze(-1) if w.dim() == 3 else w
+    w4 = (F.pad(w, (0, 4 - w.shape[1])) if w.shape[1] < 4 else w).contiguous()
+    w_param.__dict__["_nsdp_w4"] = (key, w4)
+    return w4
+
+
+def _wgrad_k4_remask(w4, bias, k_orig):
+    """Weight-gradient routine of a K = 4 layer with a fused output ReLU whose mask is recomputed from the 16-byte input
+    rows (nsdp_linear_wgrad_k4_remask_f32) instead of read back from the [M, N] output."""
+    def fn(dy2, x2, mask, relu_x, want_db, out=None):
+        M, N = dy2.shape
+        L = lib()
+        L.nsdp_linear_wgrad_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.nsdp_linear_wgrad_workspace_bytes(_ll(M), _ci(N), _ci(4)))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+        dw = torch.empty((N, 4), dtype=torch.float32, device=dy2.device)
+        db = torch.empty((N,), dtype=torch.float32, device=dy2.device) if want_db else None
+        with on_device(dy2):
+            check(L.nsdp_linear_wgrad_k4_remask_f32(fptr(dy2, "dy"), fptr(x2, "x"), fptr(w4, "weight"), optptr(bias), fptr(dw),
+                                                    optptr(db), _ll(M), _ci(N), _ci(0), fptr(ws), ctypes.c_size_t(nbytes),
+                                                    stream_ptr()), "nsdp_linear_wgrad_k4_remask_f32")
+        return (dw[:, :k_orig].contiguous() if k_orig < 4 else dw), db
+    return fn
+
+
 def _grad_targets(w_param, b_param, gw, gb):
     """The `out` pair for a weight-gradient launch that should add into the buffers gw / gb (None when one is missing)."""
     if gw is None or (b_param is not None and gb is None) or not gw.is_contiguous():
@@ -490,10 +525,16 @@ class _LinearFn(torch.autograd.Function):
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dx = dw = db = dres = None
         if ctx.w_param is not None:
+            fn = None
+            if (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
+                    and x2.shape[0] >= 4096):
+                # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates
+                fn = _wgrad_k4_remask(_padded_w4(ctx.w_param), None if ctx.b_param is None else ctx.b_param.detach(),
+                                      ctx.k_orig)
             if _use_side_stream(dy2):
-                _wgrad_deferred(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param)   # side stream
+                _wgrad_deferred(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)   # side stream
             else:
-                wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param)
+                wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         if ctx.needs_input_grad[0]:

@@ -390,3 +390,30 @@ def test_in_place_accumulation_launches_no_add_kernels():
         torch.cuda.synchronize()
     names = [e.name for e in prof.events()]
     assert names.count("aten::add_") == 0, names.count("aten::add_")      # (was: one per extra use and parameter)
+
+
+@pytest.mark.parametrize("k,n,M,bias", [(3, 200, 70000, True), (4, 120, 40001, True), (3, 256, 8192, False)])
+def test_k4_weight_gradient_with_recomputed_relu_mask(k, n, M, bias):
+    """First layer of a position-encoding MLP (K = 3 / 4, fused output ReLU): the weight-gradient kernel recomputes the ReLU
+    mask from the coordinates (nsdp_linear_wgrad_k4_remask_f32) instead of reading the [M, N] output back -- bit-identical to
+    the masked-read path (same mask decisions, same summation), and right against autograd."""
+    from nsdp_amd import hip_linear
+    torch.manual_seed(M)
+    lin = torch.nn.Linear(k, n, bias=bias).to(DEV)
+    x = torch.randn(M, k, device=DEV)
+    t = torch.randn(M, n, device=DEV)
+    ref = torch.autograd.grad((F.relu(F.linear(x, lin.weight, lin.bias)) * t).sum(), list(lin.parameters()))
+    got = []
+    for on in (True, False):
+        hip_linear.REMASK_K4 = on
+        try:
+            lin.zero_grad()
+            (hip_linear.linear(x, lin.weight, lin.bias, relu_out=True, params=True) * t).sum().backward()
+            torch.cuda.synchronize()
+            got.append([p.grad.clone() for p in lin.parameters()])
+        finally:
+            hip_linear.REMASK_K4 = True
+    for a, b in zip(*got):
+        assert torch.equal(a, b)
+    for a, r in zip(got[0], ref):
+        assert torch.allclose(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
