@@ -24,9 +24,9 @@ orig_fwd, orig_wgrad = hip_linear._run, hip_linear._wgrad
 def rec_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
     calls[("nt-" + kind, x2.shape[0], N, x2.shape[1], b is not None, residual is not None, mask is not None, out_mask is not None, bool(relu_in), bool(relu_out))] += 1
     return orig_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out)
-def rec_wgrad(dy2, x2, mask, relu_x, want_db):
+def rec_wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     calls[("wgrad", dy2.shape[0], dy2.shape[1], x2.shape[1], mask is not None, bool(relu_x), bool(want_db))] += 1
-    return orig_wgrad(dy2, x2, mask, relu_x, want_db)
+    return orig_wgrad(dy2, x2, mask, relu_x, want_db, out)
 hip_linear._run, hip_linear._wgrad = rec_fwd, rec_wgrad
 for _ in range(2):
     calls.clear()
