@@ -1,0 +1,43 @@
+"""bench.py end to end on the GPU at a small batch: the one JSON line and its contract fields."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", *flags],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("flags", [(), ("--dtype", "bf16"), ("--workload", "forward_eval")])
+def test_bench_line_contract(flags):
+    d = _run("--no-cpu-baseline", *flags)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "query-points/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == ("bf16" if "bf16" in flags else "f32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    # value = units processed / time: 2 shapes x 8192 query points per step
+    assert abs(d["value"] - 2 * 8192 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and 0.0 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_bench_cpu_baseline_leg():
+    d = _run()
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "query-points/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
