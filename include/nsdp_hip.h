@@ -214,6 +214,9 @@ int nsdp_linear_bf16(const void *X, const void *Wp, const float *bias, const voi
                      const void *out_mask, void *Y, long long M, int N, int K, int relu_in, int relu_out, int out_f32,
                      void *stream);
 size_t nsdp_linear_wgrad_bf16_workspace_bytes(long long M, int N, int K);
+/* 1 when nsdp_linear_wgrad_bf16 can take `mask` for this shape (its LDS ring holds the mask rows as well); 0: the caller
+ * multiplies the mask into dY first (the call then returns NSDP_ENOSUP with a mask). */
+int nsdp_linear_wgrad_bf16_takes_mask(long long M, int N, int K);
 int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
                            long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                            void *stream);

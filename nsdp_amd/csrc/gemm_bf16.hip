@@ -421,10 +421,10 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
   // ---- DMA: piece q of a slab = 1 KiB number q of its (dY | X | mask) runs; wave w takes pieces w, w + 8, ...
   const int pw = (pieces + kWavesWg - 1) / kWavesWg;            // per wave and slab, surplus = re-copies of the last piece
   const long long bytes_dy = p.M * N * 2, bytes_x = p.M * K * 2;
-  auto dma = [&](long long slab) {
+  auto dma = [&](long long slab, int ring_idx) {   // (ring indices are carried along: a 64-bit modulo per slab is not free)
     if (p.dbg & 4) return;
     slab = slab < slab1 ? slab : (slab1 - 1);                    // past the end: dummy re-copy (keeps the count static)
-    unsigned char *slot = rowimg + static_cast<int>((slab - slab0) % RING) * (pieces << 10);
+    unsigned char *slot = rowimg + ring_idx * (pieces << 10);
     for (int i = 0; i < pw; ++i) {
       int q = wave + kWavesWg * i;
       q = q < pieces ? q : (pieces - 1);
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
     tmsk[t] = (tiles << 10) + rg * 8 * tstride[t] + 4 * cc;
     tdst[t] = ((tisx[t] ? nt : 0) + (tcol[t] >> 4)) * 64 + rg * 16 + (tcol[t] & 15);
   }
-  auto transpose = [&](long long slab, int parity) {
-    const unsigned char *slot = rowimg + static_cast<int>((slab - slab0) % RING) * (pieces << 10);
+  auto transpose = [&](long long slab, int parity, int ring_idx) {
+    const unsigned char *slot = rowimg + ring_idx * (pieces << 10);
     u32x4 *dst = smem + parity * img;
 #pragma unroll
     for (int t = 0; t < TASKS; ++t) {
@@ -542,18 +542,22 @@ __global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_kernel(Wg16Params
   for (int q = threadIdx.x; q < 2 * img; q += kThreads) smem[q] = u32x4{0u, 0u, 0u, 0u};
 
   if (slab0 < slab1) {
-    for (int d = 0; d < RING - 1; ++d) dma(slab0 + d);
+    for (int d = 0; d < RING - 1; ++d) dma(slab0 + d, d);
     dma_wait(RING - 2);           // slab0 here (this wave's pieces) ...
     barrier();                    // ... and everybody's; the zero fill is complete as well
-    if (!(p.dbg & 2)) transpose(slab0, 0);
-    dma(slab0 + RING - 1);
+    if (!(p.dbg & 2)) transpose(slab0, 0, 0);
+    dma(slab0 + RING - 1, RING - 1);
     dma_wait(RING - 2);           // slab0 + 1
     barrier();
+    int ri = 0, par = 0;          // ring slot of slab s, fragment image of slab s
     for (long long s = slab0; s < slab1; ++s) {
+      const int rn = ri + 1 == RING ? 0 : ri + 1;
       // slab s + 1: row-major image (complete since the last barrier) -> the other fragment image (free since then too)
-      if (s + 1 < slab1 && !(p.dbg & 2)) transpose(s + 1, static_cast<int>((s + 1 - slab0) & 1));
-      dma(s + RING);              // into the ring slot of slab s, whose row image was consumed one iteration ago
-      const u32x4 *step = smem + static_cast<int>((s - slab0) & 1) * img + lane;
+      if (s + 1 < slab1 && !(p.dbg & 2)) transpose(s + 1, par ^ 1, rn);
+      dma(s + RING, ri);          // into the ring slot of slab s, whose row image was consumed one iteration ago
+      const u32x4 *step = smem + par * img + lane;
+      ri = rn;
+      par ^= 1;
       // the k-side fragments of this wave (TK of them) stay in registers, the n-side ones stream through
       u32x4 bf[TK];
 #pragma unroll
@@ -639,6 +643,249 @@ __global__ __launch_bounds__(256) void reduce_tables_kernel(const float *__restr
   out[static_cast<long long>(blockIdx.y) * nw + e] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, transpose-read form: the MFMA operands come straight out of the row-major slab images
+// ------------------------------------------------------------------------------------------------
+// gfx950's ds_read_b64_tr_b16 hands lane i of a 16-lane group COLUMN i of the 4 x 16 block whose rows the group's lanes
+// point at (lane i: row i / 4, columns 4 (i % 4) .. + 3; any row pitch) -- exactly half an MFMA operand of dY^T or X^T
+// (lane (i, g): column i, rows 8 g .. 8 g + 7 = two such reads).  So the slab images the DMA ring holds ARE the operand
+// store: no transposition pass, no fragment images, the whole LDS is ring (up to 6 slabs in flight).  A slab image is
+// [32 rows][pitch]: the DMA's source addresses are chosen per lane so that every row starts `pitch` bytes after the last
+// one, pitch = row bytes + 16 * pad = 32 (mod 64) (a 512-byte pitch would put all rows on the same banks).  Needs N % 8 == 0 and K % 8 == 0 (16-byte DMA granules); other shapes keep the kernel above.
+struct Wg16TrParams {
+  const unsigned char *dY, *X, *mask;    // bf16 [M,N], [M,K], [M,N]
+  float *ws;
+  long long M;
+  int N, K, relu_x, want_db;
+  int slabs_per_wg, dbg, ring;
+  int pitch_a, pitch_b;                  // bytes per image row (dY / mask, X)
+  int slot_bytes, pieces;                // bytes of one ring slot (multiple of 1 KiB), DMA pieces per slab
+};
+
+template <int I, int NN, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < NN) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, NN>(f);
+  }
+}
+
+template <int OFF>
+__device__ __forceinline__ void tr_read(unsigned long long &dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+// SR: a slab (one barrier, one ring slot) is SR x 32 rows = SR MFMA steps: narrow layers move too few bytes per 32 rows
+// to pay for a barrier each
+template <int TN, int TK, bool MASK, int SR>
+__global__ __launch_bounds__(kWavesWg * 64, 1) void wgrad_bf16_tr_kernel(Wg16TrParams p) {
+  constexpr int kRows = 32 * SR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int N = p.N, K = p.K;
+  const int nt = (N + 15) >> 4, kt = (K + 15) >> 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int wn0 = (wave >> 2) * TN, wk0 = (wave & 3) * TK;
+  const int RING = p.ring;
+  // images inside a slot start at KiB boundaries, so that a DMA piece (1 KiB) belongs to ONE tensor: uniform base pointer
+  const int off_b = (kRows * p.pitch_a + 1023) & ~1023, off_m = off_b + ((kRows * p.pitch_b + 1023) & ~1023);
+
+  const long long slab0 = static_cast<long long>(blockIdx.x) * p.slabs_per_wg;
+  long long slab1 = slab0 + p.slabs_per_wg;
+  const long long slabs_all = (p.M + kRows - 1) / kRows;
+  slab1 = slab1 < slabs_all ? slab1 : slabs_all;
+
+  // ---- DMA: this wave's pieces (1 KiB of a slot each): per lane the tensor, the byte offset inside a slab and the
+  //      slab stride of its 16-byte granule; granules in the padding re-read granule 0 of dY (never used)
+  constexpr int kPwMax = 3;
+  // this wave's pieces: wave, wave + 16, ... (its own count: every wave waits for exactly what it issued)
+  const int pw = (p.pieces - wave + kWavesWg - 1) / kWavesWg;     // 0 .. kPwMax (host)
+  // per piece: the tensor (uniform) and, per lane, the byte offset of its 16-byte granule inside a slab (low 24 bits) and
+  // its image row (high bits; 255 = a granule of the padding, which re-reads granule 0)
+  unsigned goff[kPwMax];
+#pragma unroll
+  for (int u = 0; u < kPwMax; ++u) {
+    const int q = wave + kWavesWg * u < p.pieces ? wave + kWavesWg * u : p.pieces - 1;
+    const int o = (q << 10) + lane * 16;
+    const bool isb = (q << 10) >= off_b && (q << 10) < off_m;       // (uniform)
+    const int width = (isb ? K : N) * 2, pitch = isb ? p.pitch_b : p.pitch_a;
+    const int rel = o - (isb ? off_b : ((q << 10) >= off_m ? off_m : 0));
+    const int r = rel / pitch, w = rel - r * pitch;
+    const bool real = r < kRows && w < width;
+    goff[u] = real ? (static_cast<unsigned>(r * width + w) | (static_cast<unsigned>(r) << 24)) : (255u << 24);
+  }
+  auto dma = [&](long long slab, int ring_idx) {     // (the ring index is carried along: a 64-bit modulo per slab is not free)
+    if (p.dbg & 4) return;
+    slab = slab < slab1 ? slab : (slab1 - 1);                      // past the end: re-copy (keeps the count static)
+    unsigned char *slot = smem_raw + ring_idx * p.slot_bytes;
+    const long long left = p.M - slab * kRows;                     // (uniform) < kRows: the matrix's last, partial slab
+    const int rows_here = left < kRows ? static_cast<int>(left) : kRows;
+#pragma unroll
+    for (int u = 0; u < kPwMax; ++u) {
+      if (u >= pw) break;
+      const int q = wave + kWavesWg * u;
+      const bool isb = (q << 10) >= off_b && (q << 10) < off_m;
+      const unsigned char *tensor = isb ? p.X : (MASK && (q << 10) >= off_m ? p.mask : p.dY);
+      const long long stride = 2LL * kRows * (isb ? K : N);
+      // rows past M: the same granule of the slab before (in-tensor bytes; zeroed in the operand registers)
+      const unsigned char *sbase = tensor + slab * stride;          // (uniform)
+      unsigned off = goff[u] & 0xffffffu;
+      const int row = static_cast<int>(goff[u] >> 24);
+      const unsigned char *src = sbase + off;
+      if (rows_here < kRows && row >= rows_here && row < kRows) src -= stride;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(slot + (q << 10)), 16, 0, 0);
+    }
+  };
+  auto dma_wait = [&](int younger) {
+    const int n = younger * pw;
+#define NSDP_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+      NSDP_VMCNT_CASE(0) NSDP_VMCNT_CASE(1) NSDP_VMCNT_CASE(2) NSDP_VMCNT_CASE(3) NSDP_VMCNT_CASE(4) NSDP_VMCNT_CASE(5)
+      NSDP_VMCNT_CASE(6) NSDP_VMCNT_CASE(7) NSDP_VMCNT_CASE(8) NSDP_VMCNT_CASE(9) NSDP_VMCNT_CASE(10) NSDP_VMCNT_CASE(11)
+      NSDP_VMCNT_CASE(12) NSDP_VMCNT_CASE(13) NSDP_VMCNT_CASE(14) NSDP_VMCNT_CASE(15) NSDP_VMCNT_CASE(16)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;     // (host contract: (ring - 2) * pw <= 16)
+    }
+#undef NSDP_VMCNT_CASE
+  };
+  auto barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // bias gradient = column sums of dY: the waves of k group 0 add up the eight rows their dY operand holds per column (fp32
+  // adds of exact bf16 values; one register per n tile -- an MFMA against ones would need four)
+  f32x4 acc[TN][TK];
+  float dbs[TN];
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    dbs[a] = 0.f;
+#pragma unroll
+    for (int b = 0; b < TK; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool dbwave = p.want_db && (wave & 3) == 0;
+  // operand addresses of this lane inside a slot: row 8 g + i / 4 (+ 4 for the second half), columns 16 t + 4 (i % 4)
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)smem_raw));
+  // (which 8 of the slab's 32 rows a lane group contracts over is free as long as both operands agree: group g takes rows
+  // 4 g .. 4 g + 3 and 16 + 4 g .. + 3, so that one read instruction covers 16 CONSECUTIVE rows -- with a pitch of 32 bytes
+  // modulo 64 the eight rows of a 32-lane pass then tile the 64 banks exactly)
+  const unsigned a_lo = (4 * g + (i >> 2)) * p.pitch_a + 8 * (i & 3) + 32 * wn0;
+  const unsigned b_lo = off_b + (4 * g + (i >> 2)) * p.pitch_b + 8 * (i & 3) + 32 * wk0;
+
+  if (slab0 < slab1) {
+    for (int d = 0; d < RING - 1; ++d) dma(slab0 + d, d);
+    dma_wait(RING - 2);
+    barrier();
+    int ri = 0;                   // ring slot of slab s
+    for (long long s = slab0; s < slab1; ++s) {
+      dma(s + RING - 1, ri == 0 ? RING - 1 : ri - 1);      // into the slot of slab s - 1, read by everybody before the last barrier
+      const unsigned slot = lds0 + static_cast<unsigned>(ri) * p.slot_bytes;
+      ri = ri + 1 == RING ? 0 : ri + 1;
+#pragma unroll
+      for (int sr = 0; sr < SR; ++sr) {
+      const unsigned aa = slot + a_lo + sr * 32 * p.pitch_a, ab = aa + 16 * p.pitch_a;
+      const unsigned ba = slot + b_lo + sr * 32 * p.pitch_b, bb = ba + 16 * p.pitch_b;
+      // X operands of this wave up front, then one n tile at a time
+      unsigned long long rb[TK][2];
+      static_for<0, TK>([&](auto B) {
+        constexpr int b = decltype(B)::value;
+        tr_read<32 * b>(rb[b][0], ba); tr_read<32 * b>(rb[b][1], bb);
+      });
+#pragma unroll
+      for (int b = 0; b < TK; ++b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[b][0]), "+v"(rb[b][1]));
+      const long long rl = p.M - s * kRows - sr * 32;             // < 32 only in the matrix's last slab (uniform)
+      const int rows_left = rl < 32 ? (rl < 0 ? 0 : static_cast<int>(rl)) : 32;
+      u32x4 bf[TK];
+#pragma unroll
+      for (int b = 0; b < TK; ++b) {
+        bf[b] = u32x4{static_cast<unsigned>(rb[b][0]), static_cast<unsigned>(rb[b][0] >> 32),
+                      static_cast<unsigned>(rb[b][1]), static_cast<unsigned>(rb[b][1] >> 32)};
+        if (p.relu_x) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) bf[b][c] = relu2(bf[b][c]);
+        }
+      }
+      static_for<0, TN>([&](auto A) {
+        constexpr int a = decltype(A)::value;
+        if (wn0 + a < nt && !(p.dbg & 1)) {      // (uniform)
+          unsigned long long ra[2], rm[2];
+          tr_read<32 * a>(ra[0], aa); tr_read<32 * a>(ra[1], ab);
+          if constexpr (MASK) { tr_read<32 * a>(rm[0], aa + off_m); tr_read<32 * a>(rm[1], ab + off_m); }
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]));
+          u32x4 af = {static_cast<unsigned>(ra[0]), static_cast<unsigned>(ra[0] >> 32),
+                      static_cast<unsigned>(ra[1]), static_cast<unsigned>(ra[1] >> 32)};
+          if constexpr (MASK) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rm[0]), "+v"(rm[1]));
+            const u32x4 mf = {static_cast<unsigned>(rm[0]), static_cast<unsigned>(rm[0] >> 32),
+                              static_cast<unsigned>(rm[1]), static_cast<unsigned>(rm[1] >> 32)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) af[c] = keep_pos(af[c], mf[c]);
+          }
+          if (rows_left < 32) {       // dword c of the operand = rows 16 (c / 2) + 4 g + 2 (c % 2), + 1
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int r = 16 * (c >> 1) + 4 * g + 2 * (c & 1);
+              af[c] = r + 1 < rows_left ? af[c] : (r < rows_left ? (af[c] & 0xffffu) : 0u);
+            }
+          }
+#pragma unroll
+          for (int b = 0; b < TK; ++b)
+            if (wk0 + b < kt) acc[a][b] = mfma_bf16(af, bf[b], acc[a][b]);
+          if (dbwave) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              t += __builtin_bit_cast(float, af[c] << 16) + __builtin_bit_cast(float, af[c] & 0xffff0000u);
+            dbs[a] += t;
+          }
+        }
+      });
+      }
+      dma_wait(RING - 2);         // slab s + 1 (outstanding: s + 1 .. s + RING - 1)
+      barrier();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float *out = p.ws + static_cast<long long>(blockIdx.x) * (static_cast<long long>(N) * K + N);
+#pragma unroll
+  for (int a = 0; a < TN; ++a) {
+    const int tn = wn0 + a;
+    if (tn >= nt) continue;
+#pragma unroll
+    for (int b = 0; b < TK; ++b) {
+      const int tkk = wk0 + b;
+      if (tkk >= kt) continue;
+      const int k = tkk * 16 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tn * 16 + 4 * g + r;
+        if (n < N && k < K) out[static_cast<long long>(n) * K + k] = acc[a][b][r];
+      }
+    }
+  }
+  if (dbwave) {      // lane (i, g) holds column i's sum over the rows 8 g .. 8 g + 7 of every slab: add the four groups
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      float t = dbs[a];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      const int n = (wn0 + a) * 16 + i;
+      if (g == 0 && wn0 + a < nt && n < N) out[static_cast<long long>(N) * K + n] = t;
+    }
+  }
+}
+
+// row pitch of a slab image: row bytes + 16-byte granules of padding until pitch = 32 (mod 64) bytes: consecutive rows then
+// start 8 dword banks apart, and the 8 (16) consecutive rows one transpose read of 32 (64) lanes touches, 32 bytes each,
+// tile the 64 banks
+static int tr_pitch(int width_elems) {
+  int pitch = (width_elems * 2 + 15) / 16 * 16;      // (callers pass widths that are multiples of 8: whole granules)
+  while (pitch % 64 != 32) pitch += 16;
+  return pitch;
+}
+
 struct WgPlan {
   int grid, slabs_per_wg;
   size_t ws_floats;
@@ -652,6 +899,61 @@ WgPlan plan_wg16(long long M, int N, int K) {
   pl.grid = static_cast<int>((slabs + pl.slabs_per_wg - 1) / pl.slabs_per_wg);
   pl.ws_floats = static_cast<size_t>(pl.grid) * (static_cast<size_t>(N) * K + N);
   return pl;
+}
+
+// geometry of the transpose-read kernel for a shape: rows per slab (0: the shape stays on the transposing kernel)
+struct TrGeom {
+  int sr, pitch_a, pitch_b, slot_bytes, pieces, ring;
+};
+static TrGeom tr_geometry(long long M, int N, int K, bool mask) {
+  TrGeom t{0, 0, 0, 0, 0, 0};
+  if (N % 8 || K % 8 || (g_wg16_dbg & 8)) return t;
+  t.pitch_a = tr_pitch(N);
+  t.pitch_b = tr_pitch(K);
+  // (two MFMA steps per barrier for the narrow layers -- SR = 2 -- measured slower in the step: 29.5 against 29.1 ms)
+  for (int sr = 1; sr >= 1; --sr) {
+    if (M < 2LL * 32 * sr) continue;
+    const int img_a = (32 * sr * t.pitch_a + 1023) / 1024 * 1024, img_b = (32 * sr * t.pitch_b + 1023) / 1024 * 1024;
+    const int slot = img_a * (mask ? 2 : 1) + img_b, pieces = slot / 1024, pw = (pieces + kWavesWg - 1) / kWavesWg;
+    int ring = (160 * 1024) / slot;
+    ring = ring > 6 ? 6 : ring;
+    while (ring > 3 && (ring - 2) * pw > 16) --ring;
+    if (ring < 3 || pw > 3) continue;
+    t.sr = sr; t.slot_bytes = slot; t.pieces = pieces; t.ring = ring;
+    return t;
+  }
+  return t;
+}
+
+WgPlan plan_wg16_any(long long M, int N, int K, bool mask) {      // partials are per workgroup: the plan follows the kernel
+  const TrGeom t = tr_geometry(M, N, K, mask);
+  if (t.sr == 0) return plan_wg16(M, N, K);
+  WgPlan pl;
+  const long long slabs = (M + 32 * t.sr - 1) / (32 * t.sr);
+  long long grid = nsdp::num_cus();
+  if (grid > slabs / 4) grid = slabs / 4 > 0 ? slabs / 4 : 1;
+  pl.slabs_per_wg = static_cast<int>((slabs + grid - 1) / grid);
+  pl.grid = static_cast<int>((slabs + pl.slabs_per_wg - 1) / pl.slabs_per_wg);
+  pl.ws_floats = static_cast<size_t>(pl.grid) * (static_cast<size_t>(N) * K + N);
+  return pl;
+}
+
+template <int TN, int TK>
+int launch_wg16_tr(const Wg16Params &q, const TrGeom &t, int grid, hipStream_t st) {
+  Wg16TrParams p{reinterpret_cast<const unsigned char *>(q.dY), reinterpret_cast<const unsigned char *>(q.X),
+                 reinterpret_cast<const unsigned char *>(q.mask), q.ws, q.M, q.N, q.K, q.relu_x, q.want_db, q.slabs_per_wg,
+                 q.dbg, t.ring, t.pitch_a, t.pitch_b, t.slot_bytes, t.pieces};
+  const size_t lds = static_cast<size_t>(t.ring) * t.slot_bytes;
+  auto go = [&](auto kern) -> int {
+    if (lds > 64 * 1024)
+      NSDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+    NSDP_TRACE("wgrad_bf16_tr<%d,%d,%s,%d>", TN, TK, p.mask ? "mask" : "plain", t.sr);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWavesWg * 64), lds, st, p);
+    return nsdp::launch_status("wgrad_bf16_tr_kernel");
+  };
+  if (p.mask) return go(wgrad_bf16_tr_kernel<TN, TK, true, 1>);
+  return go(wgrad_bf16_tr_kernel<TN, TK, false, 1>);
 }
 
 template <int TN, int TK, int TASKS>
@@ -753,9 +1055,18 @@ int nsdp_linear_bf16(const void *X, const void *Wp, const float *bias, const voi
   return launch_lin<16, 8>(p, st);
 }
 
+int nsdp_linear_wgrad_bf16_takes_mask(long long M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  const int nt = (N + 15) / 16, kt = (K + 15) / 16;
+  if (tr_geometry(M, N, K, true).sr) return 1;          // transpose-read kernel: three images per ring slot
+  return (160 - 2 * (nt + kt)) / (2 * nt + kt) >= 3;    // transposing kernel: 2 fragment images + >= 3 row images (KiB)
+}
+
 size_t nsdp_linear_wgrad_bf16_workspace_bytes(long long M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return plan_wg16(M, N, K).ws_floats * sizeof(float);
+  // (with or without a mask: the larger of the two plans, the caller need not know)
+  const size_t a = plan_wg16_any(M, N, K, false).ws_floats, b = plan_wg16_any(M, N, K, true).ws_floats;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
@@ -764,7 +1075,8 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   NSDP_REQUIRE(dY && X && dW && workspace, "linear_wgrad_bf16: null pointer");
   NSDP_REQUIRE(N % 2 == 0 && K % 2 == 0 && N <= 256 && K <= 256, "linear_wgrad_bf16: N=%d, K=%d must be even and <= 256", N, K);
-  const WgPlan pl = plan_wg16(M, N, K);
+  const TrGeom geom = tr_geometry(M, N, K, mask != nullptr);
+  const WgPlan pl = plan_wg16_any(M, N, K, mask != nullptr);
   NSDP_REQUIRE(workspace_bytes >= pl.ws_floats * sizeof(float), "linear_wgrad_bf16: workspace too small");
   Wg16Params p{static_cast<const unsigned short *>(dY), static_cast<const unsigned short *>(X),
                static_cast<const unsigned short *>(mask), workspace, M, N, K, relu_x, db != nullptr, pl.slabs_per_wg,
@@ -776,7 +1088,10 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
   const int tn = (nt + 3) / 4, tk = (kt + 3) / 4;       // per-wave tile block (waves 4 x 4)
   // producer chunks (64 column pairs of one row group): 4 row groups x (chunks of dY + chunks of X) <= 16 = one per wave
   int rc;
-  if (tn <= 2 && tk <= 2) rc = launch_wg16<2, 2, 1>(p, pl.grid, st);
+  if (geom.sr) {      // operands by transpose reads straight from the slab images
+    if (tn <= 2 && tk <= 2) rc = launch_wg16_tr<2, 2>(p, geom, pl.grid, st);
+    else rc = launch_wg16_tr<4, 4>(p, geom, pl.grid, st);
+  } else if (tn <= 2 && tk <= 2) rc = launch_wg16<2, 2, 1>(p, pl.grid, st);
   else rc = launch_wg16<4, 4, 1>(p, pl.grid, st);
   if (rc) return rc;
   const long long nw = static_cast<long long>(N) * K, nb = db ? N : 0;

@@ -62,10 +62,9 @@ def wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     """dW [N,K], db [N] (fp32) from bf16 dY [M,N], X [M,K] (nsdp_linear_wgrad_bf16); `out`: accumulate into these."""
     M, N = dy2.shape
     K = x2.shape[1]
-    nt_, kt_ = (N + 15) // 16, (K + 15) // 16
-    if mask is not None and (160 - 2 * (nt_ + kt_)) // (2 * nt_ + kt_) < 3:          # KiB of LDS: 2 fragment + >= 3 row images
-        dy2, mask = dy2 * (mask > 0), None                                       # (only 256 x 256 with a mask)
     L = lib()
+    if mask is not None and not L.nsdp_linear_wgrad_bf16_takes_mask(_ll(M), _ci(N), _ci(K)):
+        dy2, mask = dy2 * (mask > 0), None            # (the mask rows do not fit into the kernel's LDS ring as well)
     L.nsdp_linear_wgrad_bf16_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_linear_wgrad_bf16_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)

@@ -78,16 +78,29 @@ def test_linear_bf16_forward_kernel(M, K, N, bias, relu_in, relu_out, res, mask,
 
 WG = [(4096, 120, 120, False, False, True), (5000, 200, 200, True, False, True), (4099, 256, 256, False, True, True),
       (33, 128, 200, True, True, False), (70001, 200, 128, False, False, True), (262144, 128, 128, True, True, True),
-      (3200, 256, 120, False, False, True), (31, 8, 8, False, False, True)]
+      (3200, 256, 120, False, False, True), (31, 8, 8, False, False, True),
+      # (the transpose-read kernel: ragged last slab, a mask at 256 x 256 -- three images per ring slot --, one slab more
+      # than a workgroup's share, widths that are multiples of 8 but not of 16; and the shapes that stay on the
+      # transposing kernel: widths that are not multiples of 8, fewer than 64 rows)
+      (4097, 256, 256, True, True, True), (65, 200, 200, True, False, True), (40000 + 17, 72, 248, False, True, True),
+      (9000, 250, 122, True, False, True), (63, 64, 64, False, False, True)]
 
 
+@pytest.mark.parametrize("old_kernel", [False, True])
 @pytest.mark.parametrize("M,N,K,mask,relu_x,want_db", WG)
-def test_linear_bf16_wgrad_kernel(M, N, K, mask, relu_x, want_db):
-    from nsdp_amd import hip_linear_bf16 as hb
+def test_linear_bf16_wgrad_kernel(M, N, K, mask, relu_x, want_db, old_kernel):
+    """Both weight-gradient kernels of the bf16 path (operands by hardware transpose reads from the row-major slab images;
+    explicit transposition into fragment images: nsdp_debug_set(7, 8)) against fp64 on the same bf16 inputs."""
+    from nsdp_amd import _lib, hip_linear_bf16 as hb
     g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
     dy, x = _rnd((M, N), g), _rnd((M, K), g)
     mk = _rnd((M, N), g).clamp_min(0) if mask else None
-    dw, db = hb.wgrad(dy.to(DEV), x.to(DEV), None if mk is None else mk.to(DEV), relu_x, want_db)
+    _lib.lib().nsdp_debug_set(7, 8 if old_kernel else 0)
+    try:
+        dw, db = hb.wgrad(dy.to(DEV), x.to(DEV), None if mk is None else mk.to(DEV), relu_x, want_db)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().nsdp_debug_set(7, 0)
     dyd = dy.double() * (mk > 0) if mask else dy.double()
     xd = F.relu(x.double()) if relu_x else x.double()
     ref = dyd.t() @ xd
