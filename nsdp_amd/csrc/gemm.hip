@@ -971,6 +971,7 @@ namespace nsdp {
 void debug_set_x3(int value);   // gemm_bf16x3.hip
 void debug_set_wg16(int value);  // gemm_bf16.hip
 void debug_set_lin16(int value);
+void debug_set_wg3(int value);   // wgrad_bf16x3.hip
 }
 
 extern "C" {
@@ -983,6 +984,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 6) nsdp::debug_set_x3(value);
   if (key == 7) nsdp::debug_set_wg16(value);
   if (key == 8) nsdp::debug_set_lin16(value);
+  if (key == 9) nsdp::debug_set_wg3(value);
 }
 
 static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,

@@ -441,6 +441,314 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_kernel(WgX3Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row-wise form: the producer loads float4s of ROWS (1 KiB contiguous per wave instruction, a quarter of the load
+// instructions of the column-wise form above, whose 8-rows-of-one-column slots exist only because the split planes had to
+// land in MFMA fragment order), splits them and writes the three planes as ROW-MAJOR bf16 images; the consumer fetches its
+// operands with ds_read_b64_tr_b16 (lane i of a 16-lane group gets column i of the 4 x 16 block the group addresses --
+// half an operand of dY^T / X^T).  A lane group contracts over rows 4 g .. + 3 and 16 + 4 g .. + 3 (both operands agree), the
+// image pitch is 32 (mod 64) bytes: one read's rows tile the LDS banks.  Same partial layout, same reduce kernel.
+constexpr int tr_pitch_bytes(int cols) {
+  int pitch = cols * 2;
+  while (pitch % 64 != 32) pitch += 16;
+  return pitch;
+}
+__device__ __forceinline__ void gload4(f32x4 &dst, const float *uniform_base, unsigned byte_off) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform_base));
+}
+template <int OFF>
+__device__ __forceinline__ void tr_read(unsigned long long &dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+struct Frag3 {
+  unsigned long long h[2], m[2], l[2];
+};
+__device__ __forceinline__ void frag_wait(Frag3 &f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.h[0]), "+v"(f.h[1]), "+v"(f.m[0]), "+v"(f.m[1]), "+v"(f.l[0]), "+v"(f.l[1]));
+}
+__device__ __forceinline__ u32x4 frag_vec(const unsigned long long (&q)[2]) {
+  return u32x4{static_cast<unsigned>(q[0]), static_cast<unsigned>(q[0] >> 32), static_cast<unsigned>(q[1]),
+               static_cast<unsigned>(q[1] >> 32)};
+}
+
+template <int NTA, int KTB, bool MASK, bool TAIL>
+__global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
+  constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
+  constexpr int kColsA = NTA * 16, kColsB = KTB * 16, kC4A = NTA * 4, kC4B = KTB * 4;
+  constexpr int kPitchA = tr_pitch_bytes(kColsA), kPitchB = tr_pitch_bytes(kColsB);
+  constexpr int kPlaneA = 32 * kPitchA, kPlaneB = 32 * kPitchB;
+  constexpr unsigned kBufBytes = 3 * (kPlaneA + kPlaneB);            // [A h, m, l][B h, m, l], row-major images
+  constexpr int RA = (32 * kC4A + 255) / 256, RB = (32 * kC4B + 255) / 256;   // float4 slots per lane
+  __shared__ __attribute__((aligned(16))) unsigned char planes[2 * kBufBytes];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 1, wb = wave & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int N = p.N, K = p.K;
+  const int k_off = static_cast<int>(blockIdx.y) * kColsB;
+  const int Kpart = K - k_off < kColsB ? K - k_off : kColsB;
+  const float *const dYp = sgpr_ptr(p.dY), *const Xp = sgpr_ptr(p.X), *const Mp = sgpr_ptr(p.mask);
+  const long long Mrows = p.M;
+  const long long mb0 = static_cast<long long>(blockIdx.x) * p.blocks_per_wg;
+  const long long mb_all = (p.M + 31) >> 5;
+  long long mb1 = mb0 + p.blocks_per_wg;
+  mb1 = mb1 < mb_all ? mb1 : mb_all;
+  const int nblk = static_cast<int>(mb1 - mb0);
+
+  // ---- producer slots: s = tid + 256 r -> row s / c4s, float4 column s % c4s (surplus slots alias slot s - 256) ----
+  unsigned offA[RA], offB[RB];       // byte offset of the slot's float4 in dY / X for the block loaded next
+  unsigned ldsA[RA], ldsB[RB];       // byte offset inside a plane image
+  int rowA[RA], rowB[RB];            // image row (TAIL)
+  const unsigned strideA = static_cast<unsigned>(N) * 4u, strideB = static_cast<unsigned>(K) * 4u;
+#pragma unroll
+  for (int r = 0; r < RA; ++r) {
+    int s = tid + 256 * r;
+    s = s < 32 * kC4A ? s : s - 256;
+    const int row = s / kC4A, c4 = s % kC4A;
+    const int col = 4 * c4 + 4 <= N ? 4 * c4 : N - 4;      // padding columns re-read the last real ones (never reduced)
+    rowA[r] = row;
+    offA[r] = static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
+    ldsA[r] = static_cast<unsigned>(row * kPitchA + c4 * 8);
+  }
+#pragma unroll
+  for (int r = 0; r < RB; ++r) {
+    int s = tid + 256 * r;
+    s = s < 32 * kC4B ? s : s - 256;
+    const int row = s / kC4B, c4 = s % kC4B;
+    const int col = k_off + (4 * c4 + 4 <= Kpart ? 4 * c4 : Kpart - 4);
+    rowB[r] = row;
+    offB[r] = static_cast<unsigned>(((mb0 * 32 + row) * K + col) * 4);
+    ldsB[r] = static_cast<unsigned>(3 * kPlaneA + row * kPitchB + c4 * 8);
+  }
+  const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&planes[0])));
+
+  f32x4 rawA[RA], rawM[MASK ? RA : 1], rawB[RB];
+  f32x4 dbsum[RA];
+#pragma unroll
+  for (int r = 0; r < RA; ++r) dbsum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto issue_a = [&](int r, long long mb) {
+    unsigned off = offA[r];
+    if (TAIL && mb * 32 + 32 > Mrows) {           // rows past M: re-read row M - 1 (zeroed in the split)
+      const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
+      if (rowA[r] > last_row) off -= static_cast<unsigned>(rowA[r] - last_row) * strideA;
+    }
+    gload4(rawA[r], dYp, off);
+    if (MASK) gload4(rawM[r], Mp, off);
+  };
+  auto issue_b = [&](int r, long long mb) {
+    unsigned off = offB[r];
+    if (TAIL && mb * 32 + 32 > Mrows) {
+      const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
+      if (rowB[r] > last_row) off -= static_cast<unsigned>(rowB[r] - last_row) * strideB;
+    }
+    gload4(rawB[r], Xp, off);
+  };
+  auto issue = [&](long long mb) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) issue_a(r, mb);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) issue_b(r, mb);
+  };
+  auto advance = [&]() {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) offA[r] += 32u * strideA;
+#pragma unroll
+    for (int r = 0; r < RB; ++r) offB[r] += 32u * strideB;
+  };
+  auto gwait = [&]() {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA[r]));
+      if (MASK) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawM[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawB[r]));
+  };
+  auto write3 = [&](const f32x4 &v, unsigned byte_off, int plane_bytes) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(v[0], v[1], h0, m0, l0);
+    split_pair(v[2], v[3], h1, m1, l1);
+    unsigned char *dst = &planes[0] + byte_off;
+    *reinterpret_cast<unsigned long long *>(dst) = (static_cast<unsigned long long>(h1) << 32) | h0;
+    *reinterpret_cast<unsigned long long *>(dst + plane_bytes) = (static_cast<unsigned long long>(m1) << 32) | m0;
+    *reinterpret_cast<unsigned long long *>(dst + 2 * plane_bytes) = (static_cast<unsigned long long>(l1) << 32) | l0;
+  };
+  auto produce_a = [&](int r, unsigned buf_off, int rows_left, bool real) {
+    f32x4 v = rawA[r];
+    if (MASK) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = rawM[r][c] > 0.f ? v[c] : 0.f;
+    }
+    if (TAIL) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = rowA[r] < rows_left ? v[c] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbsum[r][c] += real ? v[c] : 0.f;     // (the split after the last block works on stale registers)
+    write3(v, buf_off + ldsA[r], kPlaneA);
+  };
+  const float relu_floor = p.relu_x ? 0.f : -__builtin_inff();
+  auto produce_b = [&](int r, unsigned buf_off) {
+    f32x4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(rawB[r][c], relu_floor, __builtin_inff());
+    write3(v, buf_off + ldsB[r], kPlaneB);
+  };
+  auto rows_in = [&](long long mb) {
+    const long long left = p.M - mb * 32;
+    return static_cast<int>(left < 32 ? left : 32);
+  };
+
+  f32x4 acc[TA][TB];
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(mb0);
+  gwait();
+  {
+    const int rl = rows_in(mb0);
+#pragma unroll
+    for (int r = 0; r < RA; ++r) produce_a(r, 0u, rl, true);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) produce_b(r, 0u);
+  }
+  advance();
+  if (nblk > 1) issue(mb0 + 1);
+  advance();
+  gwait();
+  __syncthreads();
+
+  // operand addresses: row 4 g + i / 4 (+ 16 for the second half), columns 16 t + 4 (i % 4) of the wave's first tile
+  const unsigned fragA = lds_base + static_cast<unsigned>((4 * g + (i >> 2)) * kPitchA + 8 * (i & 3) + wa * TA * 32);
+  const unsigned fragB = lds_base + static_cast<unsigned>(3 * kPlaneA + (4 * g + (i >> 2)) * kPitchB + 8 * (i & 3) + wb * TB * 32);
+  auto read_a = [&](auto T, Frag3 &f, unsigned base) {
+    constexpr int t = decltype(T)::value;
+    tr_read<t * 32>(f.h[0], base); tr_read<t * 32 + 16 * kPitchA>(f.h[1], base);
+    tr_read<t * 32 + kPlaneA>(f.m[0], base); tr_read<t * 32 + kPlaneA + 16 * kPitchA>(f.m[1], base);
+    tr_read<t * 32 + 2 * kPlaneA>(f.l[0], base); tr_read<t * 32 + 2 * kPlaneA + 16 * kPitchA>(f.l[1], base);
+  };
+  auto read_b = [&](auto T, Frag3 &f, unsigned base) {
+    constexpr int t = decltype(T)::value;
+    tr_read<t * 32>(f.h[0], base); tr_read<t * 32 + 16 * kPitchB>(f.h[1], base);
+    tr_read<t * 32 + kPlaneB>(f.m[0], base); tr_read<t * 32 + kPlaneB + 16 * kPitchB>(f.m[1], base);
+    tr_read<t * 32 + 2 * kPlaneB>(f.l[0], base); tr_read<t * 32 + 2 * kPlaneB + 16 * kPitchB>(f.l[1], base);
+  };
+  constexpr int kSlots = RA + RB;
+  constexpr int kAH = 4;
+  constexpr int kPasses = (TA + kAH - 1) / kAH;
+  constexpr int kSteps = kPasses * TB;
+  constexpr int kPerStep = (kSlots + kSteps - 1) / kSteps;             // producer slots per consumer step
+
+  for (int ib = 0; ib < nblk; ++ib) {
+    const unsigned buf = static_cast<unsigned>(ib & 1) * kBufBytes, nbuf = kBufBytes - buf;
+    const int rl_next = rows_in(mb0 + ib + 1 < mb_all ? mb0 + ib + 1 : mb_all - 1);
+    static_for<0, kPasses>([&](auto P) {
+      constexpr int pass = decltype(P)::value;
+      constexpr int kShort = TA % kAH;
+      constexpr int a0 = (kShort == 0) ? pass * kAH : (pass == 0 ? 0 : kShort + (pass - 1) * kAH);
+      constexpr int na = (kShort != 0 && pass == 0) ? kShort : kAH;
+      static_assert(a0 + na <= TA, "pass geometry");
+      Frag3 fa[na];
+      static_for<0, na>([&](auto I) {
+        constexpr int a = decltype(I)::value;
+        read_a(std::integral_constant<int, a0 + a>{}, fa[a], fragA + buf);
+      });
+      Frag3 fb;
+      read_b(std::integral_constant<int, 0>{}, fb, fragB + buf);
+      u32x4 ah[na], am[na], al[na];
+      static_for<0, na>([&](auto I) {
+        constexpr int a = decltype(I)::value;
+        frag_wait(fa[a]);
+        ah[a] = frag_vec(fa[a].h); am[a] = frag_vec(fa[a].m); al[a] = frag_vec(fa[a].l);
+      });
+      frag_wait(fb);
+      u32x4 bh = frag_vec(fb.h), bm = frag_vec(fb.m), bl = frag_vec(fb.l);
+      static_for<0, TB>([&](auto I) {
+        constexpr int b = decltype(I)::value;
+        constexpr int st = pass * TB + b;
+        Frag3 nb;
+        if constexpr (b + 1 < TB) read_b(std::integral_constant<int, b + 1>{}, nb, fragB + buf);
+        // the next block's split: kPerStep producer slots per step, in the same basic block as the step's MFMAs
+        static_for<0, kPerStep>([&](auto Q) {
+          constexpr int slot = st * kPerStep + decltype(Q)::value;
+          if constexpr (slot < RA) produce_a(slot, nbuf, rl_next, ib + 1 < nblk);
+          else if constexpr (slot < kSlots) produce_b(slot - RA, nbuf);
+        });
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(al[a], bh, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bl, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bm, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bh, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bm, acc[a0 + a][b]);
+#pragma unroll
+        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bh, acc[a0 + a][b]);
+        if constexpr (st * kPerStep < kSlots) {
+#pragma unroll
+          for (int q = 0; q < 6 * na; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2 * kPerStep, 0);
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < na; ++a) asm volatile("" : "+a"(acc[a0 + a][b]));
+        // a slot's raw registers are free as soon as it is split: the loads of the block after next follow
+        static_for<0, kPerStep>([&](auto Q) {
+          constexpr int slot = st * kPerStep + decltype(Q)::value;
+          if constexpr (slot < RA) {
+            if (ib + 2 < nblk) issue_a(slot, mb0 + ib + 2);
+          } else if constexpr (slot < kSlots) {
+            if (ib + 2 < nblk) issue_b(slot - RA, mb0 + ib + 2);
+          }
+        });
+        if constexpr (st == kSteps - 1) advance();
+        if constexpr (b + 1 < TB) {
+          frag_wait(nb);
+          bh = frag_vec(nb.h); bm = frag_vec(nb.m); bl = frag_vec(nb.l);
+        }
+      });
+    });
+    gwait();
+    __syncthreads();
+  }
+
+  float *wsp = p.ws + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) *
+                         (static_cast<size_t>(NTA) * KTB * 256 + NTA * 16);
+#pragma unroll
+  for (int a = 0; a < TA; ++a)
+#pragma unroll
+    for (int b = 0; b < TB; ++b) {
+      const int ta = wa * TA + a, tb = wb * TB + b;
+      if (ta < NTA && tb < KTB) {
+        const f32x4 v = acc[a][b];
+        *reinterpret_cast<float4 *>(wsp + (static_cast<size_t>(ta) * KTB + tb) * 256 + lane * 4) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  if (p.want_db && blockIdx.y == 0) {
+    // every slot (row, float4 column) has exactly one owner: park the per-slot sums in LDS ([32 rows][kColsA]) and add a
+    // column's 32 rows in fixed order (deterministic)
+    float *dbl = reinterpret_cast<float *>(&planes[0]);       // all plane reads are behind the last barrier
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int s = tid + 256 * r;
+      if (s < 32 * kC4A) *reinterpret_cast<f32x4 *>(dbl + (s / kC4A) * kColsA + 4 * (s % kC4A)) = dbsum[r];
+    }
+    __syncthreads();
+    for (int c = tid; c < kColsA; c += 256) {
+      float t = 0.f;
+      for (int r = 0; r < 32; ++r) t += dbl[r * kColsA + c];
+      wsp[static_cast<size_t>(NTA) * KTB * 256 + c] = t;
+    }
+  }
+}
+
 // dW[n][k] = sum over the S partials of element (n, k): accumulator (tile n/16, tile k/16), lane 16 (n%16)/4 + k%16,
 // register (n%16)%4  (C/D layout of the MFMA: row = 4 (lane >> 4) + reg, column = lane & 15).
 // 32 elements x 8 partial ranges per workgroup: a thread sums one eighth of the partials of one element (S/8
@@ -513,10 +821,23 @@ X3Plan plan_x3(long long M, int N, int K) {
   return pl;
 }
 
+int g_wg3_rows = 1;     // nsdp_debug_set(9, v): 1 = row-wise producer + transpose reads (default), 0 = column-wise form
+
 template <int NTA, int KTB>
 void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
   const dim3 g(grid, p.kparts);
   const bool tail = (p.M & 31) != 0;
+  if (g_wg3_rows) {
+    NSDP_TRACE("wgrad_bf16x3<%d,%d,%s,%s>", NTA, KTB, p.mask ? "mask" : "plain", tail ? "tail" : "notail");
+    if (p.mask) {
+      if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, true>), g, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, false>), g, dim3(256), 0, st, p);
+    } else {
+      if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, true>), g, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false>), g, dim3(256), 0, st, p);
+    }
+    return;
+  }
   if (p.mask) {
     NSDP_TRACE("wgrad_bf16x3<%d,%d,mask,%s>", NTA, KTB, tail ? "tail" : "notail");
     if (tail) hipLaunchKernelGGL((wgrad_bf16x3_kernel<NTA, KTB, true, true>), g, dim3(256), 0, st, p);
@@ -529,6 +850,10 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
 }
 
 }  // namespace
+
+namespace nsdp {
+void debug_set_wg3(int value) { g_wg3_rows = value; }
+}  // namespace nsdp
 
 extern "C" {
 
