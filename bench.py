@@ -365,8 +365,8 @@ def main():
             "model_tflops": round(value * FLOP_PER_QUERY_FWD_BWD / 1e12, 2) if args.workload == "forward_train" else None,
             "final_loss": round(final_loss, 6),
             "roofline": profiling.roofline(prof, prof_iso,
-                                           pmc_matches=(args.workload == "forward_train" and args.batch == 32
-                                                        and args.dtype == "f32")),
+                                           pmc_matches=(args.workload == "forward_train" and args.batch == 32),
+                                           pmc_suffix=("" if args.dtype == "f32" else "_bf16")),
             "kernels": profiling.summary(prof_iso if prof_iso else prof),
             "kernels_from": ("2 untimed steps, every launch timed, weight gradients on the main stream" if prof_iso
                              else "timed region"),

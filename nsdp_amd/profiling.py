@@ -80,7 +80,7 @@ def summary(prof):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def roofline(prof, prof_isolated=None, pmc_matches=True):
+def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix=""):
     """Roofline object of the dominant hand-written kernel class.
 
     Two measurements exist for every kernel, both taken live with HIP events on the launch stream: inside the timed
@@ -97,22 +97,23 @@ def roofline(prof, prof_isolated=None, pmc_matches=True):
     out = _roofline_one(name, v)
     out["measured"] = "isolated pass (no cross-stream overlap)" if prof_isolated else "timed region"
     # the committed PMC passes are of the default workload (B = 32 forward.yaml train step) only
-    out.update(_pmc_traffic(name) if pmc_matches else {"traffic": None})
+    out.update(_pmc_traffic(name, pmc_suffix) if pmc_matches else {"traffic": None})
     if prof_isolated and name in prof:
         ins = _roofline_one(name, prof[name])
         out["in_step"] = {k: ins[k] for k in ("achieved", "frac", "launches", "avg_launch_ms")}
     return out
 
 
-def _pmc_traffic(name):
+def _pmc_traffic(name, suffix=""):
     """HBM bytes per launch of `name` from the committed rocprofv3 PMC passes of this same command
     (profiles/r2_pmc_hbm.json, else r1: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the file is absent."""
     import json
     import os
     prof_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    path = next((os.path.join(prof_dir, f) for f in ("r2_pmc_hbm.json", "r1_pmc_hbm.json")
-                 if os.path.exists(os.path.join(prof_dir, f))), os.path.join(prof_dir, "r2_pmc_hbm.json"))
+    files = (f"r2_pmc_hbm{suffix}.json",) + (("r1_pmc_hbm.json",) if not suffix else ())
+    path = next((os.path.join(prof_dir, f) for f in files if os.path.exists(os.path.join(prof_dir, f))),
+                os.path.join(prof_dir, files[0]))
     try:
         with open(path) as f:
             pmc = json.load(f)

@@ -25,6 +25,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
   python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- \
   python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch_bf16 -o f -- \
+  python $R/bench.py --dtype bf16 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_bf16.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write_bf16 -o w -- \
+  python $R/bench.py --dtype bf16 --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write_bf16.log 2>&1
 NSDP_WGRAD_STREAM=0 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
   --kernel-trace --output-format csv -d $R/gpurun_out/pmc_sq -o s -- \
   python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq.log 2>&1

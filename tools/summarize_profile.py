@@ -50,34 +50,35 @@ for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseli
     with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:   # keep the raw stats CSV too (small)
         f.write(open(stats).read())
 
-pmc = {}
-for key, sub, pre in (("FETCH_SIZE", "pmc_fetch", "f"), ("WRITE_SIZE", "pmc_write", "w")):
-    path = os.path.join(root, "gpurun_out", sub, f"{pre}_counter_collection.csv")
-    if not os.path.exists(path):
-        continue
-    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != key:
+for pmc_suffix, pmc_what in (("", "the default workload"), ("_bf16", "--dtype bf16")):
+    pmc = {}
+    for key, sub, pre in (("FETCH_SIZE", "pmc_fetch" + pmc_suffix, "f"), ("WRITE_SIZE", "pmc_write" + pmc_suffix, "w")):
+        path = os.path.join(root, "gpurun_out", sub, f"{pre}_counter_collection.csv")
+        if not os.path.exists(path):
             continue
-        a = agg[short(r["Kernel_Name"])]
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
-        a[2] = max(a[2], float(r["Counter_Value"]))
-    pmc[key] = agg
-if pmc:
-    names = sorted(set().union(*[set(v) for v in pmc.values()]),
-                   key=lambda n: -sum(pmc[k][n][1] for k in pmc if n in pmc[k]))
-    with open(os.path.join(out_dir, f"{tag}_pmc_hbm.md"), "w") as f:
-        f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 (B = 32, the default workload)\n\n")
-        f.write("Counter unit = KiB as reported.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
-                "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n")
-        f.write("| kernel | launches | FETCH_SIZE sum KiB | fetch x2 MiB | WRITE_SIZE sum KiB | max launch fetch KiB | max launch write KiB |\n|---|---:|---:|---:|---:|---:|---:|\n")
-        for n in names[:40]:
-            fe = pmc.get("FETCH_SIZE", {}).get(n, [0, 0, 0])
-            wr = pmc.get("WRITE_SIZE", {}).get(n, [0, 0, 0])
-            f.write(f"| `{n}` | {fe[0] or wr[0]} | {fe[1]:.0f} | {2*fe[1]/1024:.1f} | {wr[1]:.0f} | {fe[2]:.0f} | {wr[2]:.0f} |\n")
-    json.dump({k: {n: v for n, v in agg.items()} for k, agg in pmc.items()},
-              open(os.path.join(out_dir, f"{tag}_pmc_hbm.json"), "w"), indent=0)
+        agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != key:
+                continue
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] = max(a[2], float(r["Counter_Value"]))
+        pmc[key] = agg
+    if pmc:
+        names = sorted(set().union(*[set(v) for v in pmc.values()]),
+                       key=lambda n: -sum(pmc[k][n][1] for k in pmc if n in pmc[k]))
+        with open(os.path.join(out_dir, f"{tag}_pmc_hbm{pmc_suffix}.md"), "w") as f:
+            f.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 (B = 32, {pmc_what})\n\n")
+            f.write("Counter unit = KiB as reported.  On gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n"
+                    "(MI355X_MICROARCH.md, HBM section): the `fetch x2` column applies that correction.\n\n")
+            f.write("| kernel | launches | FETCH_SIZE sum KiB | fetch x2 MiB | WRITE_SIZE sum KiB | max launch fetch KiB | max launch write KiB |\n|---|---:|---:|---:|---:|---:|---:|\n")
+            for n in names[:40]:
+                fe = pmc.get("FETCH_SIZE", {}).get(n, [0, 0, 0])
+                wr = pmc.get("WRITE_SIZE", {}).get(n, [0, 0, 0])
+                f.write(f"| `{n}` | {fe[0] or wr[0]} | {fe[1]:.0f} | {2*fe[1]/1024:.1f} | {wr[1]:.0f} | {fe[2]:.0f} | {wr[2]:.0f} |\n")
+        json.dump({k: {n: v for n, v in agg.items()} for k, agg in pmc.items()},
+                  open(os.path.join(out_dir, f"{tag}_pmc_hbm{pmc_suffix}.json"), "w"), indent=0)
 # SQ counters (one pass, NSDP_WGRAD_STREAM=0 so that counters are per kernel): matrix-pipe busy fraction and wait split
 sq_path = os.path.join(root, "gpurun_out", "pmc_sq", "s_counter_collection.csv")
 if os.path.exists(sq_path):
