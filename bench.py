@@ -54,8 +54,9 @@ def cpu_baseline(seconds_budget=20.0):
     tdnet_ref.train_step(sd, cfg["model"], data, opt)  # warm-up
     # small per-op tensors do not scale to 256 hardware threads: pick the fastest of a few thread counts
     best = None
+    from nsdp_amd.cpu_budget import cpu_budget
     for nt in (8, 16, 32, 64):
-        if nt > (os.cpu_count() or 1):
+        if nt > cpu_budget():        # (affinity and cgroup quota, not os.cpu_count())
             break
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
@@ -156,7 +157,7 @@ def self_launch(n, argv):
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, 16 // n)))      # (the ranks share the box's CPU budget: nsdp_amd/cpu_budget.py)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
@@ -197,7 +198,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
+    # CPU thread pools within the cgroup quota (nsdp_amd/cpu_budget.py: 256 spinning OpenMP workers under a 16-CPU quota
+    # throttle the thread that enqueues the GPU work -- steps of 60-90 ms instead of 45)
+    from nsdp_amd.cpu_budget import cap_thread_pools, cpu_budget
+    cap_thread_pools(16 // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) or 1)
     import torch
+    cap_thread_pools(16 // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))) or 1)
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))

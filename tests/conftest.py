@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # CPU thread pools within the cgroup quota: the oracle's CPU runs are no faster with 128 threads, and the spinning
+    # workers throttle the whole container (nsdp_amd/cpu_budget.py)
+    from nsdp_amd.cpu_budget import cap_thread_pools
+    cap_thread_pools(16)
 
 
 @pytest.fixture(scope="session")
