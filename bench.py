@@ -73,9 +73,51 @@ def cpu_baseline(seconds_budget=20.0):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= 12:
             break
+    # `cores` (the contract's field) = the THREADS the port really used -- not cores of the host: the box has
+    # `host_logical_cpus` hardware threads of which this container may use `cpu_quota` (affinity and cgroup cpu.max)
     return {"value": round(n * N_QUERY / el, 1), "unit": "query-points/s", "cores": torch.get_num_threads(),
+            "threads": torch.get_num_threads(), "host_logical_cpus": os.cpu_count(), "cpu_quota": cpu_budget(),
             "kind": "port", "sample": f"{n} train steps at B=1 (2048 surf / 8192 query), fp32, oracle/tdnet_ref.py "
-                                      f"on {torch.get_num_threads()} host threads ({os.cpu_count()} logical CPUs)"}
+                                      f"on {torch.get_num_threads()} host threads (fastest of 8/16/32/64 within the "
+                                      f"container's {cpu_budget()}-CPU budget; {os.cpu_count()} logical CPUs on the host)"}
+
+
+def bf16_parity(workload, device):
+    """The accuracy cost of `--dtype bf16`, next to the throughput it buys: eval-mode L2 of the bf16-storage product against
+    the REFERENCE's fp32 output (tests/golden/full_forward.npz / full_arbitrary.npz: the imported reference on CPU at 2048
+    surface + 8192 query points, same procedural weights and seeded inputs), outside the timed region.  None when the
+    fixture is not in the tree."""
+    import numpy as np
+    import torch
+    from nsdp_amd import precision, synth
+    from nsdp_amd.model import build_model
+    name, mtype = ("full_forward", "forward") if workload == "forward_train" else ("full_arbitrary", "arbitrary")
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if not os.path.exists(path):
+        return None
+    fx = np.load(path, allow_pickle=False)
+    seed, b, ns, nq = (int(fx[k]) for k in ("meta_seed", "meta_batch", "meta_ns", "meta_nq"))
+    cfg = model_config()
+    cfg["model"]["type"] = mtype
+    model, *_ = build_model(cfg, device="cpu")
+    state = synth.procedural_state_dict(model.state_dict(), seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.to(device).eval()
+    d = {k: torch.from_numpy(v).to(device) for k, v in synth.make_batch(seed, b, ns, nq).items()}
+    out = {}
+    for mode in ("f32", "bf16"):
+        with precision.storage(mode), torch.no_grad():
+            s_in = d["surface_samples_inputs"]
+            if mtype == "arbitrary":
+                o = model(d["space_samples_src"], s_in[:, :, 0:3], s_in[:, :, 3:6], s_in[:, :, 6:7])
+            else:
+                o = model(d["space_samples_src"], s_in)
+        out[mode] = o.float().cpu().numpy().astype(np.float64)
+    stride = int(fx["meta_eval_stride"]) if "meta_eval_stride" in fx else 1
+    ref = fx["eval_out"].astype(np.float64)
+    l2 = {m: float(np.sqrt(((o[:, ::stride] - ref) ** 2).sum(-1).mean(-1)).max()) for m, o in out.items()}
+    return {"bf16": round(l2["bf16"], 6), "f32": round(l2["f32"], 8), "fixture": f"tests/golden/{name}.npz",
+            "metric": "max over shapes of sqrt(mean_q |pred - reference|^2), eval forward, B=%d" % b}
 
 
 def stub_main(args, rank, world):
@@ -175,6 +217,9 @@ def main():
                     help="shapes per GPU (weak scaling); default 32 for the train steps (BASELINE configs 3/4 per GPU), "
                          "8 for forward_eval (config 2), 4 for dense_inference (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reps", type=int, default=3,
+                    help="timed repetitions of the K-step region (each bracketed by barrier + synchronize); the line reports "
+                         "the MEDIAN repetition as value / ms_per_step and min / max beside it")
     ap.add_argument("--workload", default="forward_train",
                     choices=["forward_train", "arbitrary_train", "forward_eval", "dense_inference"],
                     help="forward_train (default, the headline metric) | arbitrary_train (BASELINE config 3) | "
@@ -213,13 +258,34 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}")
     if args.stub_step:
         return stub_main(args, rank, world)
-    if args.backend == "nccl" and torch.cuda.device_count() < world // max(1, int(os.environ.get("NNODES", "1"))):
+    if (args.backend == "nccl" and torch.cuda.device_count() < world // max(1, int(os.environ.get("NNODES", "1")))
+            and not (torch.cuda.device_count() == 1 and os.environ.get("HIP_VISIBLE_DEVICES", "").count(",") == 0
+                     and os.environ.get("HIP_VISIBLE_DEVICES", "") != "")):
         sys.exit(f"bench.py: --gpus {args.gpus} needs {world} visible GPUs, found {torch.cuda.device_count()}")
-    dev_index = local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank
+    # LOCAL_RANK -> GPU: with a per-rank HIP_VISIBLE_DEVICES (some launchers narrow it to ONE device per process) the only
+    # visible device is 0; otherwise rank r takes device r
+    one_visible = torch.cuda.device_count() == 1 and world > 1 and args.backend == "nccl" and \
+        len([d for d in os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")).split(",") if d]) == 1
+    dev_index = 0 if one_visible else (local_rank % torch.cuda.device_count() if args.backend != "nccl" else local_rank)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cpu_mask = None
+    if local_world > 1:
+        from nsdp_amd.cpu_budget import pin_rank
+        props = torch.cuda.get_device_properties(dev_index)
+        bdf = (f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+               if hasattr(props, "pci_bus_id") else None)
+        cpu_mask = pin_rank(local_rank, local_world, bdf)
+        print(f"bench.py: rank {rank} -> GPU {dev_index} ({bdf}), CPUs {cpu_mask}", file=sys.stderr)
+    exchange_world1 = world == 1 and args.force_reducer and args.backend == "nccl"
+    if world > 1 or exchange_world1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if exchange_world1 and "MASTER_PORT" not in os.environ:      # (a one-rank RCCL communicator on this GPU)
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -244,7 +310,7 @@ def main():
     model.to(device).train(not is_eval)
     _, optimizer = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
                                       "weight_decay": 0.0}, model.parameters())
-    reducer = GradAllReducer(model, world) if (world > 1 or args.force_reducer) else None
+    reducer = GradAllReducer(model, world, always_exchange=exchange_world1) if (world > 1 or args.force_reducer) else None
     data = {k: torch.from_numpy(v).to(device)
             for k, v in synth.make_batch(1000 + rank, args.batch, N_SURF, n_query).items()}
 
@@ -297,7 +363,7 @@ def main():
     # spans the time the kernel waits for CUs held by the other stream.
     prof_iso = None
     dominant = "linear_bf16x3_kernel" if args.dtype == "f32" else "linear_bf16_kernel"
-    if graph is None and not is_eval and world == 1:
+    if graph is None and not is_eval:      # (every rank runs it -- same program on every rank; rank 0 reports it)
         from nsdp_amd import hip_linear
         was = hip_linear._OVERLAP_WGRAD
         hip_linear._OVERLAP_WGRAD = False
@@ -321,21 +387,37 @@ def main():
     import gc
     gc.collect()
     gc.disable()
+    # host pace with an EMPTY launch queue: one step enqueued right after a synchronize -- what the host needs for a step
+    # when nothing pushes back (inside the timed region the enqueue calls also wait for queue / kernarg slots whenever the
+    # GPU is the slower side, so `host_enqueue_ms_per_step` there converges to the step time itself)
+    t0 = time.perf_counter()
+    run()
+    host_unblocked = time.perf_counter() - t0
+    fence()
     if os.environ.get("NSDP_BENCH_NO_EVENTS") != "1":    # (A/B knob: cost of the HIP events themselves)
         profiling.start(only=[dominant] if dominant else None)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
-    t_enqueued = time.perf_counter() - t0      # host time to ENQUEUE the K steps (no sync inside a step)
-    fence()
-    elapsed = time.perf_counter() - t0
+    reps = []
+    for _ in range(max(1, args.reps)):      # each repetition: EXACTLY K steps between fences, MAX over ranks
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = run()
+        t_enq = time.perf_counter() - t0       # host time to ENQUEUE the K steps (no sync inside a step)
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        reps.append((el, t_enq))
     gc.enable()
     prof = profiling.stop()
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    order = sorted(range(len(reps)), key=lambda i: reps[i][0])
+    elapsed, t_enqueued = reps[order[len(order) // 2]]        # the median repetition is the reported one
     final_loss = float(loss.item())
+    parity = None
+    if rank == 0 and args.dtype == "bf16" and args.workload in ("forward_train", "arbitrary_train"):
+        parity = bf16_parity(args.workload, device)
 
     if rank == 0:
         total_q = world * args.batch * n_query * args.steps
@@ -352,6 +434,9 @@ def main():
             "metric": names[0],
             "value": round(value, 1), "unit": "query-points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step_reps": {"n": len(reps), "median": round(1e3 * elapsed / args.steps, 3),
+                                 "min": round(1e3 * reps[order[0]][0] / args.steps, 3),
+                                 "max": round(1e3 * reps[order[-1]][0] / args.steps, 3)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{names[1]}, "
@@ -363,8 +448,11 @@ def main():
                        "parallelism": f"dp{world}"},
             "per_gpu": round(value / world, 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
-            "comm": {"backend": (dist.get_backend() if world > 1 else None),
-                     "world_size": (dist.get_world_size() if world > 1 else 1),
+            "host_enqueue_unblocked_ms": round(1e3 * host_unblocked, 3),
+            "cpu_mask": cpu_mask,
+            "parity_l2_vs_fp32": parity,
+            "comm": {"backend": (dist.get_backend() if dist.is_initialized() else None),
+                     "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
                      "grad_bytes_per_step": (reducer.nbytes if reducer is not None else None),
                      "exchange": ("flat fp32 gradient, 2 in-place all-reduce buckets after backward (not overlapped)"
                                   if reducer is not None else None)},
@@ -380,7 +468,7 @@ def main():
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.workload != "forward_train") \
             else cpu_baseline()
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

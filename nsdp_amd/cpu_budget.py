@@ -41,3 +41,48 @@ def cap_thread_pools(limit: int = 16) -> int:
     if torch is not None:
         torch.set_num_threads(min(n, int(os.environ.get("OMP_NUM_THREADS", n))))
     return n
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(pci_bus_id: str):
+    """CPUs of the NUMA node a GPU hangs off (sysfs `local_cpulist` of its PCI function), or None when unknown."""
+    try:
+        with open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/local_cpulist") as f:
+            cpus = _parse_cpulist(f.read())
+        return cpus or None
+    except (OSError, ValueError):
+        return None
+
+
+def pin_rank(local_rank: int, local_world: int, pci_bus_id: str | None = None):
+    """One process per GPU, several per node: give rank r its own slice of the CPUs this container may use, taken from the
+    NUMA node of its GPU when sysfs tells (the thread that enqueues ~1000 launches per step must not migrate across
+    sockets or share a core with another rank's enqueue thread).  Ranks whose GPUs share a NUMA node split that node's
+    CPUs by local rank.  Returns the sorted CPU list the process is now bound to (unchanged affinity on failure)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    pool = allowed
+    near = gpu_local_cpus(pci_bus_id) if pci_bus_id else None
+    if near:
+        both = [c for c in allowed if c in near]
+        if len(both) >= max(1, len(allowed) // max(1, 2 * local_world)):   # (a sane intersection, else ignore sysfs)
+            pool = both
+    n = max(1, local_world)
+    per = max(1, len(pool) // n)
+    mine = pool[(local_rank % n) * per:(local_rank % n) * per + per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return allowed
+    return mine

@@ -116,7 +116,7 @@ class _PosGrad:
     by linearity:  scatter(d(u)) = scatter(total) - scatter(d(pos)|values) = scatter(total) - dvf,  and the row sums the
     same way (sum_j d(pos)|values_ij = dy_i for a softmax over the neighbours; sum over a shape = sum_a dvf[a]).
     Without ``grad_sum`` attn_pre's kernel adds d(u) into the parked tensor (the round-1 form)."""
-    __slots__ = ("dpos", "grad_sum", "dvf", "dy", "fused")
+    __slots__ = ("dpos", "grad_sum", "dvf", "dy", "fused", "qb")
 
     def __init__(self):
         self.dpos = None
@@ -124,6 +124,7 @@ class _PosGrad:
         self.dvf = None           # fp32 scatter of attn_post's d(pos) = its dvf
         self.dy = None            # upstream gradient of attn_post (per-point correction of dq)
         self.fused = False        # attn_post's backward has run and primed grad_sum.buf
+        self.qb = False           # one query vector per shape (set by attn_pre's forward)
 
 
 class _AttnPre(torch.autograd.Function):
@@ -137,6 +138,8 @@ class _AttnPre(torch.autograd.Function):
         B, n, k, d = pos.shape
         N = kf.shape[1]
         qb = int(q.shape[1] == 1 and n != 1)  # (B,1,d): one query vector per shape
+        if link is not None:
+            link.qb = bool(qb)
         u = torch.empty_like(pos)
         dt = pos.dtype
         with on_device(pos):
@@ -227,7 +230,11 @@ class _AttnPost(torch.autograd.Function):
         da = torch.empty_like(a)
         dpos = torch.empty_like(a)
         onehot = vf is not None and _onehot_ok(dt, a_g is not None, N, d)
-        inverse = vf is not None and not onehot and a_g is None and _use_inverse(dt, False, n, N, d)
+        link = ctx.link
+        qb = bool(link.qb) if link is not None else False
+        # (a per-shape-query block has no inverse lists -- backward_lists(qb=True) builds none -- and must not build them here)
+        inverse = (vf is not None and not onehot and a_g is None and _use_inverse(dt, qb, n, N, d)
+                   and (ctx.inv is not None or not qb))
         dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if (vf is not None and not onehot and not inverse) else None
         da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
@@ -240,8 +247,10 @@ class _AttnPost(torch.autograd.Function):
             dvf = onehot_scatter(dpos.reshape(B, n * k, d), idx.reshape(B, n * k), N)
         elif inverse:  # ... or as a gather-reduce over the inverse neighbour lists
             dvf = segment_sum(dpos, idx, N, 1.0, ctx.inv)
-        link = ctx.link
-        if link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None:
+        # the fused d(pos) hand-over corrects dq by `- dy`, i.e. relies on sum_j softmax_ij = 1 over the NEIGHBOURS: with a
+        # global token the softmax has k + 1 entries and that only holds per shape (the qb form corrects by - sum_a dvf[a])
+        if (link is not None and link.grad_sum is not None and ctx.needs_input_grad[2] and dvf is not None
+                and (a_g is None or qb)):
             link.grad_sum.buf = dpos.reshape(-1, d)         # residual of the gamma MLP's first dX GEMM
             link.dvf, link.dy, link.fused = dvf, dy, True
         if dt is BF16:

@@ -514,6 +514,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
+        ctx.fwd_key = _pack_key(w_param) if w_param is not None else None
         ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -527,8 +528,11 @@ class _LinearFn(torch.autograd.Function):
         if ctx.w_param is not None:
             fn = None
             if (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
-                    and x2.shape[0] >= 4096):
-                # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates
+                    and x2.shape[0] >= 4096 and not ctx.has_res and ctx.fwd_key == _pack_key(ctx.w_param)):
+                # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates.
+                # Only when the recomputed expression IS the forward one: no residual operand (the mask would be that of
+                # relu(xW+b+res)), and the parameters are still the forward pass's (same pointer / version / epoch; a
+                # changed key falls back to the saved output as the mask)
                 fn = _wgrad_k4_remask(_padded_w4(ctx.w_param), None if ctx.b_param is None else ctx.b_param.detach(),
                                       ctx.k_orig)
             if _use_side_stream(dy2):
@@ -561,9 +565,12 @@ class _LinearFn(torch.autograd.Function):
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
 # the side stream possible, but it is invisible to everything that observes gradients THROUGH autograd: tensor hooks,
-# post-accumulate-grad hooks (DDP / FSDP register those), `torch.autograd.grad(loss, params)` and
-# `backward(inputs=[...])`.  Hooks are detected per call and switch that layer to the plain autograd path; for the
-# other two use `with hip_linear.autograd_param_grads():` around forward + backward (or NSDP_PARAM_GRADS=autograd).
+# post-accumulate-grad hooks (FSDP registers those), `torch.autograd.grad(loss, params)` and `backward(inputs=[...])`.
+# Python-visible hooks are detected per call and switch that layer to the plain autograd path.  NOT detectable:
+# torch's DistributedDataParallel -- its Reducer registers C++ post-hooks on the AccumulateGrad nodes, which Python
+# cannot see.  Under DDP (and for autograd.grad / backward(inputs=)) wrap forward + backward in
+# `with hip_linear.autograd_param_grads():` (or NSDP_PARAM_GRADS=autograd), or use nsdp_amd.parallel.GradAllReducer
+# (the data-parallel path of this repo, which needs no hooks).
 _PARAM_GRADS_DIRECT = os.environ.get("NSDP_PARAM_GRADS", "direct") != "autograd"
 
 

@@ -121,7 +121,9 @@ class _LinearB16Fn(torch.autograd.Function):
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.n_out, ctx.t_ok = x.shape, N, t_ok
-        ctx.save_for_backward(x2, wpt, y if relu_out else None, None if t_ok else w)
+        # (the fp32 fallback of the backward pass -- taken whenever dY arrives in fp32, i.e. for every out_f32 layer --
+        # multiplies by the plain weight: keep it for those as well as for the shapes without a W^T pack)
+        ctx.save_for_backward(x2, wpt, y if relu_out else None, w if (out_f32 or not t_ok) else None)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod

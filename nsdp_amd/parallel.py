@@ -15,13 +15,18 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, model: torch.nn.Module, world_size: int, process_group=None, first=("decoder",)):
+    def __init__(self, model: torch.nn.Module, world_size: int, process_group=None, first=("decoder",),
+                 always_exchange: bool = False):
+        """``always_exchange``: run the collectives even in a communicator of one rank (the sum over one rank is the
+        identity; used to exercise the RCCL path -- communicator, in-place all-reduce on the flat bucket's two halves --
+        on a single GPU, tests/test_rccl_gpu.py and ``bench.py --force-reducer``)."""
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         head = [(n, p) for n, p in named if any(("." + f + ".") in ("." + n) for f in first)]
         tail = [(n, p) for n, p in named if not any(("." + f + ".") in ("." + n) for f in first)]
         self.named = head + tail
         self.world_size = int(world_size)
         self.group = process_group
+        self.always_exchange = bool(always_exchange)
         total = sum(p.numel() for _, p in self.named)
         ref = self.named[0][1]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
@@ -68,7 +73,7 @@ class GradAllReducer:
         weight gradients are published at the end of the backward pass (hip_linear side stream), so there is nothing
         to overlap with; the two buckets only pipeline with each other (18 MB: ~0.2 ms over xGMI)."""
         self.adopt_grads()
-        if self.world_size > 1:
+        if self.world_size > 1 or (self.always_exchange and dist.is_available() and dist.is_initialized()):
             if self.split and self.split < self.flat.numel():
                 h1 = dist.all_reduce(self.flat[:self.split], group=self.group, async_op=True)
                 h2 = dist.all_reduce(self.flat[self.split:], group=self.group, async_op=True)
@@ -76,7 +81,8 @@ class GradAllReducer:
                 h2.wait()
             else:
                 dist.all_reduce(self.flat, group=self.group)
-            self.flat.div_(self.world_size)
+            if self.world_size > 1:
+                self.flat.div_(self.world_size)
 
 
 def data_parallel_step(train_on_batch, reducer: GradAllReducer):

@@ -11,6 +11,9 @@ seeds, expected outputs and sampled intermediates only.
     python oracle/make_golden.py            # writes tests/golden/{tiny_*,full_forward}.npz + json
     python oracle/make_golden.py --b16      # writes tests/golden/b16_forward.npz only (B = 16 full-shape step: ~15 GB
                                             # of CPU temporaries, about a minute)
+    python oracle/make_golden.py --arbitrary-full   # writes tests/golden/full_arbitrary.npz only: arbitrary.yaml
+                                            # (FlowArbitrary, model/flow_arbitrary.py:15-48) at B = 2, 2048 surface +
+                                            # 8192 query points -- BASELINE config 3's shapes on the reference itself
 """
 from __future__ import annotations
 
@@ -181,6 +184,11 @@ def main():
         # LDS-table attention backward, register-table scatter), 327 680 rows in the first encoder block
         run_case(ref_model, ref_utils, "forward", [2048, 500, 100], 16, 2048, 8192, 4096, "b16_forward", False,
                  eval_stride=16)
+        return
+
+    if "--arbitrary-full" in sys.argv:
+        run_case(ref_model, ref_utils, "arbitrary", [2048, 500, 100], 2, 2048, 8192, 3072, "full_arbitrary", False,
+                 eval_stride=8)
         return
 
     tiny_npl = [256, 64, 16]

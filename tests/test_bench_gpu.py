@@ -41,3 +41,24 @@ def test_bench_cpu_baseline_leg():
     d = _run()
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "query-points/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_bench_reports_repetitions_and_the_unblocked_host_pace():
+    d = _run("--no-cpu-baseline", "--reps", "3")
+    r = d["ms_per_step_reps"]
+    assert r["n"] == 3 and r["min"] <= r["median"] <= r["max"] and r["median"] == d["ms_per_step"]
+    assert d["host_enqueue_unblocked_ms"] > 0
+
+
+def test_bench_force_reducer_runs_the_exchange_over_rccl_on_one_gpu():
+    """`--force-reducer` with the default backend: a one-rank RCCL communicator, the flat-bucket all-reduce on the device."""
+    d = _run("--no-cpu-baseline", "--force-reducer", "--reps", "1")
+    assert d["comm"]["backend"] == "nccl" and d["comm"]["world_size"] == 1 and d["comm"]["grad_bytes_per_step"] > 1e7
+    assert d["final_loss"] > 0
+
+
+def test_bench_bf16_line_carries_its_accuracy_cost_against_the_reference():
+    d = _run("--no-cpu-baseline", "--dtype", "bf16", "--reps", "1")
+    par = d["parity_l2_vs_fp32"]
+    assert par is not None and par["fixture"].endswith("full_forward.npz")
+    assert par["f32"] <= 1e-4 and 1e-4 < par["bf16"] < 5e-2, par

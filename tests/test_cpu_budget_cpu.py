@@ -26,3 +26,20 @@ def test_cap_thread_pools_limits_torch_and_environment(monkeypatch):
         assert torch.get_num_threads() <= 4 and os.environ["OMP_NUM_THREADS"] == str(n)
     finally:
         torch.set_num_threads(before)
+
+
+def test_pin_rank_gives_each_local_rank_its_own_cpus():
+    import os
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); from nsdp_amd.cpu_budget import pin_rank;"
+            "a = sorted(os.sched_getaffinity(0)); m0 = pin_rank(int(sys.argv[1]), 2, '0000:ff:1f.0');"
+            "print(len(a), m0, sorted(os.sched_getaffinity(0)) == m0)") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = [subprocess.run([sys.executable, "-c", code, str(r)], capture_output=True, text=True, timeout=60).stdout.strip()
+            for r in (0, 1)]
+    n0, rest0 = outs[0].split(" ", 1)
+    assert rest0.endswith("True") and outs[1].endswith("True"), outs
+    if int(n0) >= 2:
+        m0 = eval(outs[0].split(" ", 1)[1].rsplit(" ", 1)[0])
+        m1 = eval(outs[1].split(" ", 1)[1].rsplit(" ", 1)[0])
+        assert not set(m0) & set(m1) and len(m0) == len(m1) == int(n0) // 2

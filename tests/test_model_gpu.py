@@ -187,6 +187,29 @@ def test_full_shape_train_step_matches_golden():
     assert any(n.startswith("wgrad_bf16x3<13,13") for n in names), names
 
 
+def test_full_shape_arbitrary_eval_and_train_step_match_golden():
+    """BASELINE config 3's function at its full point counts, against the REFERENCE: arbitrary.yaml (FlowArbitrary,
+    reference model/flow_arbitrary.py:15-48 -- canonicalise with the 'backward' TDNet, deform with the 'forward' one) at
+    B = 2, 2048 surface + 8192 query points, fp32.  Expected values: the imported reference run on CPU
+    (tests/golden/full_arbitrary.npz, oracle/make_golden.py --arbitrary-full): eval output, train-step loss, every
+    gradient norm + samples, None-gradient set, BatchNorm statistics, Adam deltas."""
+    fx, cfg, seed, data = fixture_setup("full_arbitrary", "arbitrary")
+    assert (int(fx["meta_batch"]), int(fx["meta_ns"]), int(fx["meta_nq"])) == (2, 2048, 8192)
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    model.eval()
+    with torch.no_grad():
+        out = run_forward(model, cfg, to_dev(data, DEV)).cpu().numpy()
+    s = int(fx["meta_eval_stride"])
+    err = np.sqrt(((out[:, ::s].astype(np.float64) - fx["eval_out"]) ** 2).sum(-1))
+    # (unstable-argsort ties of the reference's kNN, see test_full_shape_forward_matches_golden: at most a couple of queries)
+    l2 = float(np.sqrt((np.sort(err, axis=1)[:, :-2] ** 2).mean(-1)).max())
+    print(f"\nFlowArbitrary full size, eval L2 vs the reference: {l2:.2e}")
+    assert l2 <= TOL_L2, l2
+    with _variant_trace() as names:
+        _check_train_step(fx, model, train_fn, cfg, data)
+    assert any(n.startswith("linear_bf16x3<") for n in names), names
+
+
 def test_b16_train_step_matches_golden():
     """The code path bench.py times, under the reference: B = 16 shapes of 2048 / 8192 points (131 072 rows at the
     output layer -> weight gradients on the side stream; 917 504 rows in the decoder's attention layers -> the 8-wave

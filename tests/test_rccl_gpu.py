@@ -1,0 +1,75 @@
+"""One real RCCL data point on the single GPU of the test box: a world-size-1 `nccl` (= RCCL on ROCm) communicator, the
+flat-bucket gradient exchange of the real TDNet (nsdp_amd/parallel.py) run IN PLACE on the two bucket halves the 8-GPU
+job will use.  The sum over one rank is the identity, so the gradients must stay bit-equal to what the backward pass
+left in the bucket -- what this test proves is that librccl loads, a communicator comes up on the device, and the
+collective accepts exactly these buffers (views of one flat tensor written by the weight-gradient kernels on the side
+stream).  The reference has no counterpart (train.py:74-75 is single-device)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+from helpers import build_product, model_cfg, to_dev
+from nsdp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(DEV)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=DEV)
+    try:
+        yield
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_of_the_flat_gradient_bucket_world1(rccl_world1):
+    from nsdp_amd.model.utils import compute_l2_error
+    from nsdp_amd.parallel import GradAllReducer
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    cfg = model_cfg("forward", [2048, 500, 100])
+    data = to_dev(synth.make_batch(21, 16, 2048, 8192), DEV)      # 131 072 output rows: weight gradients on the side stream
+    model, _, _ = build_product(cfg, 21, DEV)
+    model.train()
+    red = GradAllReducer(model, 1, always_exchange=True)
+    assert 0 < red.split < red.flat.numel()                        # two buckets: decoder first, then the encoder
+    red.zero_grad()
+    compute_l2_error(model(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"]).backward()
+    before = red.flat.clone()
+    assert float(before.abs().sum()) > 0
+    red.all_reduce_mean()                                          # ncclAllReduce x2, in place, async + wait
+    torch.cuda.synchronize()
+    assert torch.equal(red.flat, before)
+    for (_, p), v in zip(red.named, red.views):
+        assert p.grad.data_ptr() == v.data_ptr()
+    # a raw collective on the same buffer with a non-trivial reduction, to see the kernel really ran on the device:
+    # MAX over one rank of (x) is x; PRODUCT as well; AVG divides by 1 -- run them all on the bucket halves
+    for op in (dist.ReduceOp.MAX, dist.ReduceOp.AVG):
+        dist.all_reduce(red.flat[:red.split], op=op)
+        dist.all_reduce(red.flat[red.split:], op=op)
+    torch.cuda.synchronize()
+    assert torch.equal(red.flat, before)
+    # the collective's result feeds the optimizer exactly like the plain path's gradients
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4)
+    w0 = next(model.decoder.parameters()).detach().clone()
+    opt.step()
+    assert not torch.equal(w0, next(model.decoder.parameters()).detach())
+
+
+def test_rccl_broadcast_and_barrier_world1(rccl_world1):
+    """The other two collectives a data-parallel job issues (initial weight broadcast, barrier around timed regions)."""
+    t = torch.arange(1 << 20, dtype=torch.float32, device=DEV)
+    dist.broadcast(t, src=0)
+    dist.barrier(device_ids=[0])
+    torch.cuda.synchronize()
+    assert float(t[-1]) == float((1 << 20) - 1)

@@ -39,3 +39,53 @@ for (B, N, C, S, what) in [(32, 2048, 120, 500, "step: FPS centres of level 1"),
     g = torch.randn(B, S, C, device=dev)
     t = timeit(lambda: pu.scatter_add_rows(g, idx, N))
     print(f"scatter_add_rows same shape: {t*1e6:8.1f} us  {out_b/t/1e9:7.1f} GB/s (read; atomics into [B,N,C])")
+
+# ---- the channel-major `pointnet2_ops._ext` operators (reference group_points_gpu.cu:8-64, sampling_gpu.cu:8-57,
+# ball_query_gpu.cu:9-44, interpolate_gpu.cu:9-141): achieved GB/s against their ALGORITHMIC bytes (SURVEY.md section 8d:
+# output bytes + index bytes + one read of the source; the gathered source reads hit L2 and are not counted twice)
+print()
+for (B, C, N, NP, NS, what) in [(32, 128, 2048, 500, 16, "SA level 1 shape"), (32, 256, 500, 100, 16, "SA level 2 shape"),
+                                (32, 64, 8192, 2048, 32, "PointNet++ SSG first level"), (16, 128, 16384, 4096, 32, "large")]:
+    feats = torch.randn(B, C, N, device=dev, requires_grad=True)
+    idx = torch.randint(0, N, (B, NP, NS), device=dev, dtype=torch.int32)
+    t = timeit(lambda: pu.grouping_operation(feats.detach(), idx))
+    alg = 4.0 * (B * C * NP * NS + B * NP * NS + B * C * N)
+    print(f"group_points      B={B} C={C} N={N} np={NP} ns={NS} ({what}): {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f} of HBM peak")
+    out = pu.grouping_operation(feats, idx)
+    g = torch.randn_like(out)
+    t = timeit(lambda: torch.autograd.grad(out, feats, g, retain_graph=True))
+    print(f"group_points_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f}")
+    idx1 = torch.randint(0, N, (B, NP), device=dev, dtype=torch.int32)
+    t = timeit(lambda: pu.gather_operation(feats.detach(), idx1))
+    alg1 = 4.0 * (B * C * NP + B * NP + min(B * C * N, B * C * NP * 16))      # (a gather of np columns touches <= np 64-B sectors per row)
+    print(f"gather_points     B={B} C={C} N={N} np={NP}: {t*1e6:8.1f} us  {alg1/t/1e9:7.1f} GB/s = {alg1/t/8e12:.2f}")
+    o1 = pu.gather_operation(feats, idx1)
+    g1 = torch.randn_like(o1)
+    t = timeit(lambda: torch.autograd.grad(o1, feats, g1, retain_graph=True))
+    alg1g = 4.0 * (B * C * NP + B * NP + B * C * N)                           # (the gradient tensor is zero-filled and written once)
+    print(f"gather_points_grad same shape: {t*1e6:8.1f} us  {alg1g/t/1e9:7.1f} GB/s = {alg1g/t/8e12:.2f}")
+
+print()
+for (B, N, M, ns, r, what) in [(32, 2048, 500, 16, 0.2, "SA level 1"), (32, 8192, 2048, 32, 0.1, "SSG first level"), (16, 16384, 4096, 32, 0.08, "large")]:
+    xyz = torch.rand(B, N, 3, device=dev) - 0.5
+    new_xyz = xyz[:, :M].contiguous()
+    t = timeit(lambda: pu.ball_query(r, ns, xyz, new_xyz))
+    alg = 4.0 * (B * M * ns + 3 * B * (N + M))
+    print(f"ball_query        B={B} N={N} M={M} ns={ns} r={r} ({what}): {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s; "
+          f"{B*M*N/t/1e9:7.1f} G distance tests/s (VALU / LDS-broadcast bound, not HBM)")
+    t = timeit(lambda: pu.three_nn(new_xyz, xyz))
+    alg = 4.0 * (6 * B * M + 3 * B * (N + M))
+    print(f"three_nn          B={B} n={M} m={N}: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s; {B*M*N/t/1e9:7.1f} G distance tests/s")
+
+print()
+for (B, C, M, N, what) in [(32, 256, 100, 500, "FP level 2 -> 1"), (32, 128, 500, 2048, "FP level 1 -> 0"), (16, 128, 4096, 16384, "large")]:
+    feats = torch.randn(B, C, M, device=dev, requires_grad=True)
+    idx = torch.randint(0, M, (B, N, 3), device=dev, dtype=torch.int32)
+    w = torch.rand(B, N, 3, device=dev)
+    t = timeit(lambda: pu.three_interpolate(feats.detach(), idx, w))
+    alg = 4.0 * (B * C * N + 6 * B * N + B * C * M)
+    print(f"three_interpolate B={B} c={C} m={M} n={N} ({what}): {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f}")
+    o = pu.three_interpolate(feats, idx, w)
+    g = torch.randn_like(o)
+    t = timeit(lambda: torch.autograd.grad(o, feats, g, retain_graph=True))
+    print(f"three_interpolate_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f}")

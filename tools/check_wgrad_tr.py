@@ -1,5 +1,5 @@
 """bf16 weight gradient: the transpose-read kernel against the transposing one (nsdp_debug_set(7, 8)) -- results and time.
-    python tools/test_wgrad_tr.py"""
+    python tools/check_wgrad_tr.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """fp32 (bf16x3) weight gradient: the row-wise producer + transpose-read kernel against the column-wise one
-(nsdp_debug_set(9, 0)) -- results against fp64 and time.     python tools/test_wgrad_x3_rows.py"""
+(nsdp_debug_set(9, 0)) -- results against fp64 and time.     python tools/check_wgrad_x3_rows.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

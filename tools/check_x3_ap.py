@@ -1,5 +1,5 @@
 """The anti-phase bf16x3 kernel (nsdp_debug_set(6, 128)) against the standard one and fp64; timing of both.
-    python tools/test_x3_ap.py"""
+    python tools/check_x3_ap.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
