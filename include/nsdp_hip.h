@@ -354,6 +354,20 @@ const char *nsdp_prof_name(int kind);
 /* Sums over all recorded launches of `kind`: count, elapsed ms, algorithmic flops and bytes. */
 int nsdp_prof_collect(int kind, long long *launches, double *total_ms, double *flops, double *bytes);
 
+/* ----------------------------------------------------------------------------------------------
+ * Multi-stream replay of a stream-captured step (csrc/graph_exec.hip).  No counterpart in the reference (its step is
+ * enqueued op by op from Python, train.py:150-225); this is the host side of `train_on_batch` taken off the critical
+ * path: the step is captured once into a hipGraph_t (our kernels, ATen's, memsets, copies) and replayed from C with the
+ * eager schedule's stream concurrency -- hipGraphLaunch of the same graph serialises its branches on this ROCm.
+ *   create : `graph` = the captured hipGraph_t (stays owned by the caller and must outlive the executor); nodes are
+ *            assigned to at most `max_streams` HIP streams (1 = the caller's stream only).
+ *   launch : enqueue one replay behind everything already on `stream`; `stream` continues behind all branches.
+ * -------------------------------------------------------------------------------------------- */
+int nsdp_graph_exec_create(void *graph, int max_streams, void **out_handle);
+int nsdp_graph_exec_info(void *handle, int *nodes, int *kernels, int *streams, int *cross_edges, int *own_graph_nodes);
+int nsdp_graph_exec_launch(void *handle, void *stream);
+int nsdp_graph_exec_destroy(void *handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,8 +58,8 @@ struct X3Params {
   long long M;
   int N, K;
   int relu_in, relu_out;
-  int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores -- wrong results,
-            // timing only
+  int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores, bit 9 one LDS weight
+            // read per step instead of three -- wrong results, timing only
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -104,13 +104,19 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
 // 256 registers per lane -- the second wave of a SIMD issues MFMAs while the first splits, stores or waits)
 // XREG: raw activations through registers even without a mask (frees the 32 KiB X staging: at 13 n tiles two 4-wave
 // workgroups then fit into one CU's LDS)
-template <int MT, int NT, int PRE, int WV, bool XREG = false>
+// WRES (weights RESIDENT): all KBM k blocks of the three weight planes are DMA'd into LDS ONCE per workgroup (N, K <= 128:
+// 4 x 8 x 3 KiB = 96 KiB) and stay there -- no weight DMA and no workgroup barrier inside the k loop, so the eight waves
+// drift apart and one wave's epilogue stores sit under the other waves' MFMA steps (the streaming form re-fetches the
+// planes L2 -> LDS for every 256-row tile: as many bytes as the HBM traffic, and its per-k-block barrier keeps all waves
+// in the same phase).
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
+  constexpr bool WRES = KBM > 2;
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
   // in LDS next to the weights and keeps the register path.
   constexpr bool kXLds = PRE != 1 && !XREG;
-  __shared__ __attribute__((aligned(16))) u32x4 wbuf[2][NT * 3 * 64];
+  __shared__ __attribute__((aligned(16))) u32x4 wbuf[KBM][NT * 3 * 64];
   __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? WV : 1][kXLds ? MT * 2 * 64 : 1];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -211,7 +217,11 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     for (int i = 0; i < phase * KB; ++i) __builtin_amdgcn_s_sleep(10);
   }
   // prologue (once per workgroup): block 0 of the first tile, split; block 1 in flight
-  stage(0, 0);
+  if constexpr (WRES) {
+    for (int kb = 0; kb < KB; ++kb) stage(kb, kb);
+  } else {
+    stage(0, 0);
+  }
   xissue(xa, ma, 0, 0u);
   if constexpr (kXLds) xissue(xa, ma, 1, 1u);
   xwait();
@@ -272,9 +282,11 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     X3_ADD(4, t_tile0, t_tile1);
     for (int kb = 0; kb < KB; ++kb, ++gs) {
       X3_T(t_k0);
-      const unsigned buf = gs & 1u;
+      const unsigned buf = gs & 1u;                        // X staging parity (and the weight buffer of the streaming form)
       const bool more = kb + 1 < KB || next_tile;          // a k block follows (this tile's, or the next tile's first)
-      if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
+      if constexpr (!WRES) {
+        if (more && !(p.dbg & 1)) stage(kb + 1 < KB ? kb + 1 : 0, buf ^ 1u);
+      }
       bool x_issued = false;
       if constexpr (kXLds) {   // activations two k blocks ahead into the X buffer whose block was split last iteration
         if (kb + 2 < KB) { xissue(xa, ma, kb + 2, buf); x_issued = true; }
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         if (x_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
-      const unsigned wl_addr = lds0 + buf * kBufBytes;
+      const unsigned wl_addr = lds0 + (WRES ? static_cast<unsigned>(kb) : buf) * kBufBytes;
       u32x4 wh, wm, wl;
       lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
       lds_wait(wh, wm, wl);
@@ -293,8 +305,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         constexpr int nt = decltype(I)::value;
         u32x4 nh, nm, nl;
         if constexpr (nt + 1 < NT) {
-          lds_read<(nt + 1) * 3072>(nh, wl_addr); lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
-          lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
+          lds_read<(nt + 1) * 3072>(nh, wl_addr);
+          if (!(p.dbg & 512)) {      // (ablation knob: one LDS read per step instead of three -- wrong results, timing only)
+            lds_read<(nt + 1) * 3072 + 1024>(nm, wl_addr);
+            lds_read<(nt + 1) * 3072 + 2048>(nl, wl_addr);
+          } else {
+            nm = nh; nl = nh;
+          }
         }
         if constexpr (!kXLds && nt == kConvFirst + kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
           if (kb + 2 < KB) xissue(xa, ma, kb + 2, 0u);
@@ -359,8 +376,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       // raw barrier: __syncthreads() carries a fence that drains vmcnt(0) whenever an LDS-DMA is pending -- exactly
       // the activation prefetch this loop wants to keep in flight across the barrier.  Every wave has waited for
       // its own share of the next weight block above, so after the barrier the whole block is in LDS.
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();    // every wave is done reading wbuf[buf]
+      if constexpr (!WRES) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();    // every wave is done reading wbuf[buf]
+      }
       asm volatile("" ::: "memory");
       X3_T(t_k3);
       X3_ADD(0, t_k0, t_k1); X3_ADD(1, t_k1, t_k2); X3_ADD(2, t_k2, t_k3);
@@ -778,7 +797,7 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   nsdp::pack::x3_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
-template <int MT, int NT, int PRE, int WV, bool XREG = false>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2>
 void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
@@ -786,8 +805,8 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   // last MFMAs and epilogue
   const long long slots = static_cast<long long>(nsdp::num_cus()) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
-  NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu);
-  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG>), dim3(grid), dim3(WV * 64), 0, st, p);
+  NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "");
+  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, KBM>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
 // (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
@@ -805,7 +824,13 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
   // (the masked prologue as well, up to 8 n tiles: 10-25 % over one 4-wave workgroup with more row tiles)
-  if (pre == 1 && NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), 1, 4, true>(p, st, 2);
+  // N, K <= 128 (<= 8 n tiles, <= 4 k blocks), unmasked: the weight planes stay resident in LDS for the workgroup's lifetime
+  // (96 KiB + 64 KiB of activation staging = the CU's 160 KiB): one 8-wave workgroup per CU, no barrier in the k loop.
+  // nsdp_debug_set(6, 256) switches back to the streaming two-workgroup form (A/B).
+  if (pre != 1 && NT <= 8 && p.K <= 128 && !(g_x3_dbg & 256)) {
+    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 8, false, 4>(p, st);
+    else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 8, false, 4>(p, st);
+  } else if (pre == 1 && NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), 1, 4, true>(p, st, 2);
   else if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
   else if (NT <= 8 && two_waves) {
     if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4>(p, st, 2);

@@ -23,55 +23,248 @@ inline int grid_for(long long work) {
   return static_cast<int>(g);
 }
 
-// out[b,c,j] = points[b,c,idx[b,j]]                         (sampling_gpu.cu:8-20)
-__global__ void gather_points_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
-                                     long long total, int C, int N, int M, float *__restrict__ out) {
-  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
-       e += static_cast<long long>(gridDim.x) * kThreads) {
-    const int j = static_cast<int>(e % M);
-    const long long bc = e / M;
-    const int b = static_cast<int>(bc / C);
-    out[e] = points[bc * N + idx[static_cast<long long>(b) * M + j]];
+// ---- channel-major gathers: out[b,c,e] = points[b,c,idx[b,e]]  (sampling_gpu.cu:8-20: e = j; group_points_gpu.cu:8-28:
+// e = (j,k)) and their gradients grad_points[b,c,idx[b,e]] += grad_out[b,c,e]  (sampling_gpu.cu:34-47,
+// group_points_gpu.cu:43-64).
+//
+// The reference walks (b, c, e) with one thread per element, re-reads idx[b,e] for every channel and scatters with global
+// atomics.  Measured here in that form: gathers 0.08-0.28 of the HBM peak (two 64-bit divisions per element; then, with
+// the divisions gone, 64 scattered 4-byte reads per wave instruction -- one cache line per lane through the texture path),
+// gradients 100-440 GB/s (global fp32 atomics).
+//
+// Now both directions are LDS-staged: a (b, c) row of the source / target is N floats and fits LDS.  One workgroup of
+// 1024 threads owns CH whole rows of one shape (CH x N x 4 B <= 64 KiB: two workgroups per CU; up to 128 KiB for long
+// rows) and one slice of the E index entries:
+//   gather:   rows -> LDS (coalesced), then per 4 consecutive e: one int4 of indices (loaded once for all CH channels),
+//             CH x 4 ds_read_b32 gathers, CH coalesced 16-byte stores;
+//   gradient: LDS table zeroed, per 4 consecutive e: one int4 of indices, CH float4 loads issued TOGETHER (a load -> wait
+//             -> atomics chain per channel was latency-bound at 0.9 TB/s), CH x 4 ds_add_f32, then every target element is
+//             written exactly once (plain stores; partial tables of an E-split are combined with global atomics).
+// No division anywhere.  Rows too long for LDS (N > 32768) fall back to the flat kernels.
+constexpr int kBig = 1024;                     // threads of the LDS-staged kernels
+constexpr int kLdsTableBytes = 64 * 1024;      // two workgroups per CU
+constexpr int kLdsTableMax = 128 * 1024;
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+__device__ __forceinline__ void load_idx4(const int32_t *ib, int nv, bool vec, int (&i)[4]) {
+  if (vec) {
+    const int4 v = *reinterpret_cast<const int4 *>(ib);
+    i[0] = v.x; i[1] = v.y; i[2] = v.z; i[3] = v.w;
+  } else {
+    i[0] = ib[0];
+    i[1] = nv > 1 ? ib[1] : i[0];
+    i[2] = nv > 2 ? ib[2] : i[0];
+    i[3] = nv > 3 ? ib[3] : i[0];
   }
 }
 
-// grad_points[b,c,idx[b,j]] += grad_out[b,c,j]              (sampling_gpu.cu:34-47)
-__global__ void gather_points_grad_kernel(const float *__restrict__ grad_out,
-                                          const int32_t *__restrict__ idx, long long total, int C,
-                                          int N, int M, float *__restrict__ grad_points) {
-  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
-       e += static_cast<long long>(gridDim.x) * kThreads) {
-    const int j = static_cast<int>(e % M);
-    const long long bc = e / M;
-    const int b = static_cast<int>(bc / C);
-    atomicAdd(grad_points + bc * N + idx[static_cast<long long>(b) * M + j], grad_out[e]);
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kBig) void gather_cm_lds_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                                             int C, int N, int E, int e_per_wg, float *__restrict__ out) {
+  extern __shared__ float table[];      // [CH][N]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = C - c0 < CH ? C - c0 : CH;
+  const float *src = points + (static_cast<long long>(b) * C + c0) * N;
+  if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int t = threadIdx.x * 4; t < cn * N; t += kBig * 4)
+      *reinterpret_cast<float4 *>(table + t) = *reinterpret_cast<const float4 *>(src + t);
+  } else {
+    for (int t = threadIdx.x; t < cn * N; t += kBig) table[t] = src[t];
+  }
+  __syncthreads();
+  const int e_begin = blockIdx.z * e_per_wg;
+  const int e_end = e_begin + e_per_wg < E ? e_begin + e_per_wg : E;
+  const int32_t *ib = idx + static_cast<long long>(b) * E;
+  float *o0 = out + (static_cast<long long>(b) * C + c0) * E;
+  for (int e0 = e_begin + threadIdx.x * 4; e0 < e_end; e0 += kBig * 4) {
+    const int nv = e_end - e0 < 4 ? e_end - e0 : 4;
+    int i[4];
+    load_idx4(ib + e0, nv, VEC, i);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (c < cn) {
+        const float *t = table + c * N;
+        float *o = o0 + static_cast<long long>(c) * E + e0;
+        if (VEC) {
+          *reinterpret_cast<float4 *>(o) = make_float4(t[i[0]], t[i[1]], t[i[2]], t[i[3]]);
+        } else {
+          o[0] = t[i[0]];
+          if (nv > 1) o[1] = t[i[1]];
+          if (nv > 2) o[2] = t[i[2]];
+          if (nv > 3) o[3] = t[i[3]];
+        }
+      }
+    }
   }
 }
 
-// out[b,c,j,k] = points[b,c,idx[b,j,k]]                     (group_points_gpu.cu:8-28)
-__global__ void group_points_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
-                                    long long total, int C, int N, int NPNS,
-                                    float *__restrict__ out) {
-  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
-       e += static_cast<long long>(gridDim.x) * kThreads) {
-    const int jk = static_cast<int>(e % NPNS);
-    const long long bc = e / NPNS;
-    const int b = static_cast<int>(bc / C);
-    out[e] = points[bc * N + idx[static_cast<long long>(b) * NPNS + jk]];
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kBig) void scatter_cm_lds_kernel(const float *__restrict__ grad_out,
+                                                              const int32_t *__restrict__ idx, int C, int N, int E, int e_per_wg,
+                                                              int combine, float *__restrict__ grad_points) {
+  extern __shared__ float table[];      // [CH][N]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = C - c0 < CH ? C - c0 : CH;
+  for (int t = threadIdx.x; t < cn * N; t += kBig) table[t] = 0.f;
+  __syncthreads();
+  const int e_begin = blockIdx.z * e_per_wg;
+  const int e_end = e_begin + e_per_wg < E ? e_begin + e_per_wg : E;
+  const int32_t *ib = idx + static_cast<long long>(b) * E;
+  const float *g0 = grad_out + (static_cast<long long>(b) * C + c0) * E;
+  for (int e0 = e_begin + threadIdx.x * 4; e0 < e_end; e0 += kBig * 4) {
+    const int nv = e_end - e0 < 4 ? e_end - e0 : 4;
+    int i[4];
+    load_idx4(ib + e0, nv, VEC, i);
+    float4 v[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {        // all loads of the chunk in flight together
+      const float *g = g0 + static_cast<long long>(c < cn ? c : 0) * E + e0;
+      if (VEC) {
+        v[c] = *reinterpret_cast<const float4 *>(g);
+      } else {
+        v[c].x = g[0];
+        v[c].y = nv > 1 ? g[1] : 0.f;
+        v[c].z = nv > 2 ? g[2] : 0.f;
+        v[c].w = nv > 3 ? g[3] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (c < cn) {
+        float *t = table + c * N;
+        atomicAdd(t + i[0], v[c].x);
+        if (VEC || nv > 1) atomicAdd(t + i[1], v[c].y);
+        if (VEC || nv > 2) atomicAdd(t + i[2], v[c].z);
+        if (VEC || nv > 3) atomicAdd(t + i[3], v[c].w);
+      }
+    }
+  }
+  __syncthreads();
+  float *o = grad_points + (static_cast<long long>(b) * C + c0) * N;
+  if (combine) {      // E was split over several workgroups: partial tables meet in the (zero-filled) target
+    for (int t = threadIdx.x; t < cn * N; t += kBig) {
+      const float v = table[t];
+      if (v != 0.f) atomicAdd(o + t, v);
+    }
+  } else {
+    for (int t = threadIdx.x; t < cn * N; t += kBig) o[t] = table[t];
   }
 }
 
-// grad_points[b,c,idx[b,j,k]] += grad_out[b,c,j,k]          (group_points_gpu.cu:43-64)
-__global__ void group_points_grad_kernel(const float *__restrict__ grad_out,
-                                         const int32_t *__restrict__ idx, long long total, int C,
-                                         int N, int NPNS, float *__restrict__ grad_points) {
+// flat forms (rows that do not fit LDS)
+__global__ void gather_cm_flat_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx, long long total, int C,
+                                      int N, int E, float *__restrict__ out) {
   for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
        e += static_cast<long long>(gridDim.x) * kThreads) {
-    const int jk = static_cast<int>(e % NPNS);
-    const long long bc = e / NPNS;
+    const int j = static_cast<int>(e % E);
+    const long long bc = e / E;
     const int b = static_cast<int>(bc / C);
-    atomicAdd(grad_points + bc * N + idx[static_cast<long long>(b) * NPNS + jk], grad_out[e]);
+    out[e] = points[bc * N + idx[static_cast<long long>(b) * E + j]];
   }
+}
+
+__global__ void scatter_cm_atomic_kernel(const float *__restrict__ grad_out, const int32_t *__restrict__ idx, long long total,
+                                         int C, int N, int E, float *__restrict__ grad_points) {
+  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
+       e += static_cast<long long>(gridDim.x) * kThreads) {
+    const int j = static_cast<int>(e % E);
+    const long long bc = e / E;
+    const int b = static_cast<int>(bc / C);
+    atomicAdd(grad_points + bc * N + idx[static_cast<long long>(b) * E + j], grad_out[e]);
+  }
+}
+
+// channels per workgroup (power of two <= 8) and the split of E, so that the launch has >= ~2 workgroups per CU
+struct CmPlan {
+  int ch, zsplit, e_per_wg;
+  size_t lds;
+};
+inline CmPlan plan_cm(int B, int C, int N, int E) {
+  const long long row_bytes = 4LL * N;
+  int ch = static_cast<int>((row_bytes <= kLdsTableBytes ? kLdsTableBytes : kLdsTableMax) / row_bytes);
+  ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
+  const long long want = 2LL * nsdp::num_cus();
+  while (ch > 1 && static_cast<long long>(B) * ((C + ch - 1) / ch) < want) ch >>= 1;
+  long long wgs = static_cast<long long>(B) * ((C + ch - 1) / ch);
+  int zsplit = 1;
+  // an E slice must stay much longer than the rows it stages (4 * kBig entries = one pass of the workgroup)
+  while (wgs * zsplit < want && E / (zsplit * 2) >= 4 * kBig && E / (zsplit * 2) >= 2 * N && zsplit < 64) zsplit *= 2;
+  int e_per = (E + zsplit - 1) / zsplit;
+  e_per = (e_per + 3) & ~3;                    // slices start on 16-byte boundaries
+  return {ch, (E + e_per - 1) / e_per, e_per, static_cast<size_t>(ch) * N * 4};
+}
+
+template <typename K>
+void allow_big_lds(K kernel) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTableMax);
+}
+
+template <int CH>
+void launch_gather_cm_t(const CmPlan &pl, bool vec, const float *points, const int32_t *idx, int B, int C, int N, int E,
+                        float *out, hipStream_t st) {
+  const dim3 grid((C + CH - 1) / CH, B, pl.zsplit);
+  static bool once = (allow_big_lds(&gather_cm_lds_kernel<CH, true>), allow_big_lds(&gather_cm_lds_kernel<CH, false>), true);
+  (void)once;
+  if (vec) hipLaunchKernelGGL((gather_cm_lds_kernel<CH, true>), grid, dim3(kBig), pl.lds, st, points, idx, C, N, E, pl.e_per_wg, out);
+  else hipLaunchKernelGGL((gather_cm_lds_kernel<CH, false>), grid, dim3(kBig), pl.lds, st, points, idx, C, N, E, pl.e_per_wg, out);
+}
+
+int launch_gather_cm(const float *points, const int32_t *idx, int B, int C, int N, int E, float *out, hipStream_t st) {
+  if (4LL * N > kLdsTableMax || B > 65535) {
+    const long long total = static_cast<long long>(B) * C * E;
+    NSDP_TRACE("gather_cm_flat");
+    hipLaunchKernelGGL(gather_cm_flat_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, points, idx, total, C, N, E, out);
+    return 0;
+  }
+  const CmPlan pl = plan_cm(B, C, N, E);
+  const bool vec = E % 4 == 0 && aligned16(idx) && aligned16(out);
+  NSDP_TRACE("gather_cm_lds<%d>%s z=%d", pl.ch, vec ? "" : " ragged", pl.zsplit);
+  switch (pl.ch) {
+    case 8: launch_gather_cm_t<8>(pl, vec, points, idx, B, C, N, E, out, st); break;
+    case 4: launch_gather_cm_t<4>(pl, vec, points, idx, B, C, N, E, out, st); break;
+    case 2: launch_gather_cm_t<2>(pl, vec, points, idx, B, C, N, E, out, st); break;
+    default: launch_gather_cm_t<1>(pl, vec, points, idx, B, C, N, E, out, st); break;
+  }
+  return 0;
+}
+
+template <int CH>
+void launch_scatter_cm_t(const CmPlan &pl, bool vec, const float *grad_out, const int32_t *idx, int B, int C, int N, int E,
+                         float *grad_points, hipStream_t st) {
+  const dim3 grid((C + CH - 1) / CH, B, pl.zsplit);
+  static bool once = (allow_big_lds(&scatter_cm_lds_kernel<CH, true>), allow_big_lds(&scatter_cm_lds_kernel<CH, false>), true);
+  (void)once;
+  const int combine = pl.zsplit > 1;
+  if (vec)
+    hipLaunchKernelGGL((scatter_cm_lds_kernel<CH, true>), grid, dim3(kBig), pl.lds, st, grad_out, idx, C, N, E, pl.e_per_wg, combine, grad_points);
+  else
+    hipLaunchKernelGGL((scatter_cm_lds_kernel<CH, false>), grid, dim3(kBig), pl.lds, st, grad_out, idx, C, N, E, pl.e_per_wg, combine, grad_points);
+}
+
+int launch_scatter_cm(const float *grad_out, const int32_t *idx, int B, int C, int N, int E, float *grad_points,
+                      hipStream_t st) {
+  if (4LL * N > kLdsTableMax || B > 65535) {
+    const long long total = static_cast<long long>(B) * C * E;
+    if (hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st) != hipSuccess) return 1;
+    NSDP_TRACE("scatter_cm_atomic");
+    hipLaunchKernelGGL(scatter_cm_atomic_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, grad_out, idx, total, C, N, E,
+                       grad_points);
+    return 0;
+  }
+  const CmPlan pl = plan_cm(B, C, N, E);
+  if (pl.zsplit > 1 && hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st) != hipSuccess) return 1;
+  const bool vec = E % 4 == 0 && aligned16(idx) && aligned16(grad_out);
+  NSDP_TRACE("scatter_cm_lds<%d>%s z=%d", pl.ch, vec ? "" : " ragged", pl.zsplit);
+  switch (pl.ch) {
+    case 8: launch_scatter_cm_t<8>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
+    case 4: launch_scatter_cm_t<4>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
+    case 2: launch_scatter_cm_t<2>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
+    default: launch_scatter_cm_t<1>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
+  }
+  return 0;
 }
 
 constexpr int kSrcTile = 1024;
@@ -164,11 +357,89 @@ __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float *__restr
   }
 }
 
-// out[b,l,j] = sum_t points[b,l,idx[b,j,t]] * weight[b,j,t]  (interpolate_gpu.cu:72-101)
-__global__ void three_interpolate_kernel(const float *__restrict__ points,
-                                         const int32_t *__restrict__ idx,
-                                         const float *__restrict__ weight, long long total, int c,
-                                         int m, int n, float *__restrict__ out) {
+// out[b,l,j] = sum_t points[b,l,idx[b,j,t]] * weight[b,j,t]  (interpolate_gpu.cu:72-101), LDS-staged like the gathers:
+// a workgroup owns CH whole (b, l) rows of m floats; a thread owns one j at a time -- its three indices and weights are
+// loaded once for all CH channels -- and the stores of a wave are 256 contiguous bytes of one channel row.
+// (Expression order of the reference: (p1 w1 + p2 w2) + p3 w3, one rounding per operation -- this TU is built with
+// fp contraction off.)
+template <int CH>
+__global__ __launch_bounds__(kBig) void three_interpolate_lds_kernel(const float *__restrict__ points,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     const float *__restrict__ weight, int c, int m, int n,
+                                                                     int j_per_wg, float *__restrict__ out) {
+  extern __shared__ float table[];      // [CH][m]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = c - c0 < CH ? c - c0 : CH;
+  const float *src = points + (static_cast<long long>(b) * c + c0) * m;
+  for (int t = threadIdx.x; t < cn * m; t += kBig) table[t] = src[t];
+  __syncthreads();
+  const int j_begin = blockIdx.z * j_per_wg;
+  const int j_end = j_begin + j_per_wg < n ? j_begin + j_per_wg : n;
+  float *o0 = out + (static_cast<long long>(b) * c + c0) * n;
+  for (int j = j_begin + threadIdx.x; j < j_end; j += kBig) {
+    const long long bj = static_cast<long long>(b) * n + j;
+    const float w1 = weight[bj * 3 + 0], w2 = weight[bj * 3 + 1], w3 = weight[bj * 3 + 2];
+    const int i1 = idx[bj * 3 + 0], i2 = idx[bj * 3 + 1], i3 = idx[bj * 3 + 2];
+#pragma unroll
+    for (int l = 0; l < CH; ++l) {
+      if (l < cn) {
+        const float *p = table + l * m;
+        o0[static_cast<long long>(l) * n + j] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+      }
+    }
+  }
+}
+
+// interpolate_gpu.cu:116-143: grad_points[b,l,idx[b,j,t]] += grad_out[b,l,j] * weight[b,j,t] -- the LDS-table form.
+template <int CH>
+__global__ __launch_bounds__(kBig) void three_interpolate_grad_lds_kernel(const float *__restrict__ grad_out,
+                                                                          const int32_t *__restrict__ idx,
+                                                                          const float *__restrict__ weight, int c, int n,
+                                                                          int m, int j_per_wg, int combine,
+                                                                          float *__restrict__ grad_points) {
+  extern __shared__ float table[];      // [CH][m]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = c - c0 < CH ? c - c0 : CH;
+  for (int t = threadIdx.x; t < cn * m; t += kBig) table[t] = 0.f;
+  __syncthreads();
+  const int j_begin = blockIdx.z * j_per_wg;
+  const int j_end = j_begin + j_per_wg < n ? j_begin + j_per_wg : n;
+  const float *g0 = grad_out + (static_cast<long long>(b) * c + c0) * n;
+  for (int j = j_begin + threadIdx.x; j < j_end; j += kBig) {
+    const long long bj = static_cast<long long>(b) * n + j;
+    const float w1 = weight[bj * 3 + 0], w2 = weight[bj * 3 + 1], w3 = weight[bj * 3 + 2];
+    const int i1 = idx[bj * 3 + 0], i2 = idx[bj * 3 + 1], i3 = idx[bj * 3 + 2];
+    float go[CH];
+#pragma unroll
+    for (int l = 0; l < CH; ++l) go[l] = g0[static_cast<long long>(l < cn ? l : 0) * n + j];
+#pragma unroll
+    for (int l = 0; l < CH; ++l) {
+      if (l < cn) {
+        float *t = table + l * m;
+        atomicAdd(t + i1, go[l] * w1);
+        atomicAdd(t + i2, go[l] * w2);
+        atomicAdd(t + i3, go[l] * w3);
+      }
+    }
+  }
+  __syncthreads();
+  float *o = grad_points + (static_cast<long long>(b) * c + c0) * m;
+  if (combine) {
+    for (int t = threadIdx.x; t < cn * m; t += kBig) {
+      const float v = table[t];
+      if (v != 0.f) atomicAdd(o + t, v);
+    }
+  } else {
+    for (int t = threadIdx.x; t < cn * m; t += kBig) o[t] = table[t];
+  }
+}
+
+// flat forms (rows that do not fit LDS)
+__global__ void three_interpolate_flat_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx,
+                                              const float *__restrict__ weight, long long total, int c, int m, int n,
+                                              float *__restrict__ out) {
   for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
        e += static_cast<long long>(gridDim.x) * kThreads) {
     const int j = static_cast<int>(e % n);
@@ -181,7 +452,6 @@ __global__ void three_interpolate_kernel(const float *__restrict__ points,
   }
 }
 
-// interpolate_gpu.cu:116-143
 __global__ void three_interpolate_grad_kernel(const float *__restrict__ grad_out,
                                               const int32_t *__restrict__ idx,
                                               const float *__restrict__ weight, long long total, int c,
@@ -238,9 +508,10 @@ int nsdp_gather_points(const float *points, const int32_t *idx, int B, int C, in
   const long long total = static_cast<long long>(B) * C * M;
   if (total <= 0) return 0;
   NSDP_REQUIRE(points && idx && out && N > 0, "gather_points: bad argument");
-  hipLaunchKernelGGL(gather_points_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     nsdp::as_stream(stream), points, idx, total, C, N, M, out);
-  return nsdp::launch_status("gather_points_kernel");
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kGatherRows, st, 0.0, 4.0 * (static_cast<double>(B) * M * (1 + C) + static_cast<double>(B) * C * N));
+  if (launch_gather_cm(points, idx, B, C, N, M, out, st)) return 1;
+  return nsdp::launch_status("gather_cm_kernel");
 }
 
 int nsdp_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
@@ -248,13 +519,15 @@ int nsdp_gather_points_grad(const float *grad_out, const int32_t *idx, int B, in
   const long long total = static_cast<long long>(B) * C * M;
   NSDP_REQUIRE(grad_points || static_cast<long long>(B) * C * N == 0, "gather_points_grad: null output");
   hipStream_t st = nsdp::as_stream(stream);
-  if (static_cast<long long>(B) * C * N > 0)
-    NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st));
-  if (total <= 0) return 0;
+  if (total <= 0) {
+    if (static_cast<long long>(B) * C * N > 0)
+      NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st));
+    return 0;
+  }
   NSDP_REQUIRE(grad_out && idx, "gather_points_grad: null pointer");
-  hipLaunchKernelGGL(gather_points_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, grad_out,
-                     idx, total, C, N, M, grad_points);
-  return nsdp::launch_status("gather_points_grad_kernel");
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0, 4.0 * (static_cast<double>(B) * M * (1 + C) + static_cast<double>(B) * C * N));
+  if (launch_scatter_cm(grad_out, idx, B, C, N, M, grad_points, st)) return 1;
+  return nsdp::launch_status("scatter_cm_kernel");
 }
 
 int nsdp_group_points(const float *points, const int32_t *idx, int B, int C, int N, int NP, int NS,
@@ -262,9 +535,12 @@ int nsdp_group_points(const float *points, const int32_t *idx, int B, int C, int
   const long long total = static_cast<long long>(B) * C * NP * NS;
   if (total <= 0) return 0;
   NSDP_REQUIRE(points && idx && out && N > 0, "group_points: bad argument");
-  hipLaunchKernelGGL(group_points_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     nsdp::as_stream(stream), points, idx, total, C, N, NP * NS, out);
-  return nsdp::launch_status("group_points_kernel");
+  NSDP_REQUIRE(static_cast<long long>(NP) * NS < (1LL << 31), "group_points: npoint * nsample too large");
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kGatherRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * NP * NS * (1 + C) + static_cast<double>(B) * C * N));
+  if (launch_gather_cm(points, idx, B, C, N, NP * NS, out, st)) return 1;
+  return nsdp::launch_status("gather_cm_kernel");
 }
 
 int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int NP,
@@ -272,13 +548,17 @@ int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int
   const long long total = static_cast<long long>(B) * C * NP * NS;
   NSDP_REQUIRE(grad_points || static_cast<long long>(B) * C * N == 0, "group_points_grad: null output");
   hipStream_t st = nsdp::as_stream(stream);
-  if (static_cast<long long>(B) * C * N > 0)
-    NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st));
-  if (total <= 0) return 0;
+  if (total <= 0) {
+    if (static_cast<long long>(B) * C * N > 0)
+      NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * C * N, st));
+    return 0;
+  }
   NSDP_REQUIRE(grad_out && idx, "group_points_grad: null pointer");
-  hipLaunchKernelGGL(group_points_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, grad_out,
-                     idx, total, C, N, NP * NS, grad_points);
-  return nsdp::launch_status("group_points_grad_kernel");
+  NSDP_REQUIRE(static_cast<long long>(NP) * NS < (1LL << 31), "group_points_grad: npoint * nsample too large");
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * NP * NS * (1 + C) + static_cast<double>(B) * C * N));
+  if (launch_scatter_cm(grad_out, idx, B, C, N, NP * NS, grad_points, st)) return 1;
+  return nsdp::launch_status("scatter_cm_kernel");
 }
 
 int nsdp_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M, float radius,
@@ -310,9 +590,32 @@ int nsdp_three_interpolate(const float *points, const int32_t *idx, const float 
   const long long total = static_cast<long long>(B) * c * n;
   if (total <= 0) return 0;
   NSDP_REQUIRE(points && idx && weight && out && m > 0, "three_interpolate: bad argument");
-  hipLaunchKernelGGL(three_interpolate_kernel, dim3(grid_for(total)), dim3(kThreads), 0,
-                     nsdp::as_stream(stream), points, idx, weight, total, c, m, n, out);
-  return nsdp::launch_status("three_interpolate_kernel");
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kGatherRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * n * (6 + c) + static_cast<double>(B) * c * m));
+  if (4LL * m > kLdsTableMax || B > 65535) {
+    hipLaunchKernelGGL(three_interpolate_flat_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, points, idx, weight, total,
+                       c, m, n, out);
+    return nsdp::launch_status("three_interpolate_flat_kernel");
+  }
+  const CmPlan pl = plan_cm(B, c, m, n);
+  const dim3 grid((c + pl.ch - 1) / pl.ch, B, pl.zsplit);
+  NSDP_TRACE("three_interpolate_lds<%d> z=%d", pl.ch, pl.zsplit);
+#define NSDP_TI(CH)                                                                                                        \
+  {                                                                                                                        \
+    static bool once = (allow_big_lds(&three_interpolate_lds_kernel<CH>), true);                                           \
+    (void)once;                                                                                                            \
+    hipLaunchKernelGGL((three_interpolate_lds_kernel<CH>), grid, dim3(kBig), pl.lds, st, points, idx, weight, c, m, n,      \
+                       pl.e_per_wg, out);                                                                                  \
+  }
+  switch (pl.ch) {
+    case 8: NSDP_TI(8) break;
+    case 4: NSDP_TI(4) break;
+    case 2: NSDP_TI(2) break;
+    default: NSDP_TI(1) break;
+  }
+#undef NSDP_TI
+  return nsdp::launch_status("three_interpolate_lds_kernel");
 }
 
 int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight, int B,
@@ -320,10 +623,37 @@ int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const
   const long long total = static_cast<long long>(B) * c * n;
   NSDP_REQUIRE(grad_points || static_cast<long long>(B) * c * m == 0, "three_interpolate_grad: null output");
   hipStream_t st = nsdp::as_stream(stream);
-  if (static_cast<long long>(B) * c * m > 0)
-    NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * c * m, st));
-  if (total <= 0) return 0;
+  if (total <= 0) {
+    if (static_cast<long long>(B) * c * m > 0)
+      NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * c * m, st));
+    return 0;
+  }
   NSDP_REQUIRE(grad_out && idx && weight, "three_interpolate_grad: null pointer");
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * n * (6 + c) + static_cast<double>(B) * c * m));
+  if (4LL * m <= kLdsTableMax && B <= 65535) {
+    const CmPlan pl = plan_cm(B, c, m, n);
+    if (pl.zsplit > 1) NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * c * m, st));
+    const dim3 grid((c + pl.ch - 1) / pl.ch, B, pl.zsplit);
+    const int combine = pl.zsplit > 1;
+    NSDP_TRACE("three_interpolate_grad_lds<%d> z=%d", pl.ch, pl.zsplit);
+#define NSDP_TIG(CH)                                                                                                       \
+  {                                                                                                                        \
+    static bool once = (allow_big_lds(&three_interpolate_grad_lds_kernel<CH>), true);                                      \
+    (void)once;                                                                                                            \
+    hipLaunchKernelGGL((three_interpolate_grad_lds_kernel<CH>), grid, dim3(kBig), pl.lds, st, grad_out, idx, weight, c, n,  \
+                       m, pl.e_per_wg, combine, grad_points);                                                              \
+  }
+    switch (pl.ch) {
+      case 8: NSDP_TIG(8) break;
+      case 4: NSDP_TIG(4) break;
+      case 2: NSDP_TIG(2) break;
+      default: NSDP_TIG(1) break;
+    }
+#undef NSDP_TIG
+    return nsdp::launch_status("three_interpolate_grad_lds_kernel");
+  }
+  NSDP_HIP_TRY(hipMemsetAsync(grad_points, 0, sizeof(float) * static_cast<size_t>(B) * c * m, st));
   hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st,
                      grad_out, idx, weight, total, c, n, m, grad_points);
   return nsdp::launch_status("three_interpolate_grad_kernel");

@@ -16,6 +16,7 @@ namespace {
 
 constexpr int kInvThreads = 1024;
 constexpr int kMaxSources = 8192;      // counters of one shape in LDS
+constexpr int kSortMax = 1024;         // longest list that is put into ascending order (fixed summation order)
 
 // offsets [B][N+1], entries [B][E]: entries[b][offsets[b][s] .. offsets[b][s+1]) = ascending list of e = i*k + j with
 // idx[b][e] == s
@@ -59,6 +60,10 @@ __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *
   // fixed summation order: ascending entry number inside every list (lists are short: E / N on average)
   for (int s = threadIdx.x; s < N; s += kInvThreads) {
     const int lo = offsets[s], hi = cnt[s];          // cursor ended at the list's end
+    // (one thread, insertion sort: quadratic -- lists beyond kSortMax entries keep the order the atomics produced, i.e.
+    // their sum is correct but its rounding may differ from run to run; kNN index sets stay far below the bound except
+    // the decoder's anchor lists, which use the register-table / one-hot forms instead)
+    if (hi - lo > kSortMax) continue;
     for (int i = lo + 1; i < hi; ++i) {
       const int v = entries[i];
       int j = i - 1;

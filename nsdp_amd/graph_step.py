@@ -1,0 +1,108 @@
+"""A train / inference step captured once and replayed from C with the eager schedule's stream concurrency.
+
+    step = GraphedStep(fn)            # fn(): enqueues one step on the current stream, returns tensors (e.g. the loss)
+    step.capture(warmup=3)            # runs fn eagerly `warmup` times, then captures it (torch.cuda.graph: private pool)
+    out = step()                      # one C call: ~1000 launches in ~4 ms of host time instead of 17-24 ms of Python
+
+The reference enqueues its step op by op from Python (train.py:150-225); so does this repo's eager path, at 17-24 ms of
+host time per forward.yaml step whatever the batch -- more than the GPU needs for a bf16 or small-batch step.  A plain
+hipGraph replay (`torch.cuda.CUDAGraph.replay`) is no answer on this ROCm: it serialises the graph's branches (the
+weight-gradient side stream, the geometry pyramid) and ends up SLOWER than eager (47.7 against 44.4 ms at B = 32).  Here the
+captured hipGraph_t is handed to csrc/graph_exec.hip, which replays the same nodes on real HIP streams (chain
+decomposition of the dependency graph, events on the cross-stream edges).
+
+Rules of the capture (the same as for any CUDA / HIP graph):
+  * shapes and addresses are frozen: `fn` must read its inputs from tensors that exist before `capture()` (write new
+    batches into them with `copy_`), and what it returns are static tensors overwritten by every replay;
+  * no host synchronisation inside `fn` (`.item()`, `.cpu()`, prints of tensors);
+  * optimizers must be capturable (`capturable_adam`): the step counter lives on the device; a learning rate that changes
+    must be a device tensor (`set_lr`).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import NsdpHipError, check, lib, stream_ptr
+
+
+def capturable_adam(optimizer: torch.optim.Optimizer, lr_as_tensor: bool = True, fused: bool = True):
+    """Switch a torch.optim.Adam(-like) optimizer to its capturable form IN PLACE (device-side step counter; the learning
+    rate as a device tensor so that schedulers can change it between replays).  Call before the first step.
+    ``fused``: PyTorch's fused multi-tensor Adam -- the capturable foreach form computes its bias corrections with ~15
+    tensor-list operations, i.e. ~480 tiny kernels per step for the 350 parameter tensors of a TDNet (a replay of 1495 nodes
+    instead of ~1020); the fused form is a dozen launches."""
+    for group in optimizer.param_groups:
+        group["capturable"] = True
+        if fused and "fused" in group and all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
+            group["fused"], group["foreach"] = True, False
+        if lr_as_tensor and not torch.is_tensor(group["lr"]):
+            dev = group["params"][0].device
+            group["lr"] = torch.tensor(float(group["lr"]), dtype=torch.float32, device=dev)
+    return optimizer
+
+
+def set_lr(optimizer: torch.optim.Optimizer, value: float):
+    """Change the learning rate of a `capturable_adam` optimizer between replays (fills the device tensor)."""
+    for group in optimizer.param_groups:
+        if torch.is_tensor(group["lr"]):
+            group["lr"].fill_(float(value))
+        else:
+            group["lr"] = float(value)
+
+
+class GraphedStep:
+    def __init__(self, fn, max_streams: int = 4):
+        self.fn = fn
+        self.max_streams = int(max_streams)
+        self._graph = None
+        self._handle = ctypes.c_void_p(0)
+        self._out = None
+        self.info = None
+
+    def capture(self, warmup: int = 3):
+        if self._graph is not None:
+            raise RuntimeError("already captured")
+        if not hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph"):
+            raise NsdpHipError("this PyTorch cannot hand out the captured hipGraph_t (CUDAGraph.raw_cuda_graph)")
+        # eager warm-up on a side stream (allocator steady state, weight packs, autotuned choices), as torch recommends
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(0, warmup)):
+                self.fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.cuda.graph(graph):
+            out = self.fn()
+        torch.cuda.synchronize()
+        raw = graph.raw_cuda_graph()
+        L = lib()
+        handle = ctypes.c_void_p(0)
+        check(L.nsdp_graph_exec_create(ctypes.c_void_p(int(raw)), ctypes.c_int(self.max_streams), ctypes.byref(handle)),
+              "nsdp_graph_exec_create")
+        vals = [ctypes.c_int(0) for _ in range(5)]
+        check(L.nsdp_graph_exec_info(handle, *[ctypes.byref(v) for v in vals]), "nsdp_graph_exec_info")
+        self.info = dict(zip(("nodes", "kernels", "streams", "cross_stream_edges", "own_graph_nodes"), (v.value for v in vals)))
+        self._graph, self._handle, self._out = graph, handle, out
+        return self
+
+    def __call__(self):
+        if self._graph is None:
+            raise RuntimeError("capture() first")
+        check(lib().nsdp_graph_exec_launch(self._handle, stream_ptr()), "nsdp_graph_exec_launch")
+        return self._out
+
+    def close(self):
+        if self._handle:
+            lib().nsdp_graph_exec_destroy(self._handle)
+            self._handle = ctypes.c_void_p(0)
+        self._graph = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

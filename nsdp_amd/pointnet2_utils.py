@@ -64,8 +64,22 @@ def gather_rows(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# index_points' backward: gather-reduce over inverse index lists (csrc/segment.hip: deterministic, every row read once at
+# stream rate) instead of global fp32 atomics (1.0-1.25 TB/s) wherever the lists can be built -- they are cached on the index
+# tensor, so an index set that is reused (two gathers of one kNN set, several steps over fixed geometry) builds them once.
+# NSDP_SCATTER_ROWS=atomic keeps the atomic kernel (A/B knob).
+_SCATTER_INVERSE = __import__("os").environ.get("NSDP_SCATTER_ROWS", "inverse") != "atomic"
+_SCATTER_INVERSE_MIN_ROWS = 4096        # rows per launch below which one atomic launch beats invert + segment sum
+
+
 def scatter_add_rows(grad_out: torch.Tensor, idx: torch.Tensor, N: int) -> torch.Tensor:
     B, S, C = grad_out.shape
+    # (average list length S / N <= 64: the list build sorts every list with one thread -- long lists, e.g. 57 344 gathers
+    # of 100 anchors, cost more to build than the atomics cost)
+    if (_SCATTER_INVERSE and C % 4 == 0 and 4 <= C <= 256 and 0 < int(N) <= 8192 and B * S >= _SCATTER_INVERSE_MIN_ROWS
+            and S <= 64 * int(N) and grad_out.is_cuda and grad_out.dtype is torch.float32 and grad_out.is_contiguous()):
+        from . import hip_attention
+        return hip_attention.segment_sum(grad_out, idx, int(N), 1.0)
     out = torch.empty((B, int(N), C), dtype=torch.float32, device=grad_out.device)
     with on_device(grad_out):
         check(lib().nsdp_scatter_add_rows(fptr(grad_out, "grad_out"), iptr(idx, "idx"), _c_int(B), _c_int(int(N)),

@@ -90,8 +90,9 @@ def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix=""):
     ``achieved`` / ``frac`` / ``avg_launch_ms`` are reported from the isolated pass (a kernel's own duration is what a
     roofline fraction is about; `rocprofv3 --kernel-trace --stats` of ``NSDP_WGRAD_STREAM=0 python bench.py`` is the
     matching profile); ``in_step`` repeats the figures as timed inside the overlapped region."""
-    if not prof:
+    if not prof and not prof_isolated:
         return None
+    prof = prof or {}      # (a graph replay carries no events: only the isolated pass exists then)
     base = prof_isolated if prof_isolated else prof
     name, v = max(base.items(), key=lambda kv: kv[1]["ms"])
     out = _roofline_one(name, v)

@@ -62,3 +62,14 @@ def test_bench_bf16_line_carries_its_accuracy_cost_against_the_reference():
     par = d["parity_l2_vs_fp32"]
     assert par is not None and par["fixture"].endswith("full_forward.npz")
     assert par["f32"] <= 1e-4 and 1e-4 < par["bf16"] < 5e-2, par
+
+
+def test_bench_graph_replay_is_the_default_and_eager_is_still_there():
+    d = _run("--no-cpu-baseline", "--reps", "1")
+    assert d["step_launch"].startswith("graph replay") and d["final_loss"] > 0 and d["roofline"] is not None
+    e = _run("--no-cpu-baseline", "--reps", "1", "--eager")
+    assert e["step_launch"].startswith("eager") and e["roofline"]["in_step"]["launches"] > 0
+    # (that the two ways of launching the step train alike is tests/test_graph_exec_gpu.py's subject: the runs here differ
+    # in their number of set-up steps)
+    f = _run("--no-cpu-baseline", "--reps", "1", "--force-reducer", "--backend", "gloo")
+    assert "two graphs around the eager all-reduce" in f["step_launch"] or f["step_launch"].startswith("eager")

@@ -119,6 +119,47 @@ def test_gather_and_group_ops_match_oracle():
     np.testing.assert_allclose(f.grad.cpu().numpy(), ref.group_points_grad(go, gidx, N), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,C,N,M,NS", [(2, 8, 64, 32, 4), (3, 13, 1000, 257, 3), (2, 33, 20000, 500, 16), (1, 5, 40000, 77, 8),
+                                          (4, 128, 2048, 500, 16)])
+def test_gather_and_group_ops_match_oracle_across_kernel_forms(B, C, N, M, NS):
+    """The channel-major gathers and their gradients over the shapes that select each kernel form: 16-byte index / output
+    vectors or the ragged scalar form (npoint * nsample not a multiple of 4), channel counts that are not a multiple of the
+    channel chunk, target rows in a 64 KiB / 128 KiB LDS table and rows too long for LDS (global-atomic fallback), hot
+    indices (many gathers of one source point)."""
+    from nsdp_amd import pointnet2_utils as pu
+    feats = synth.normal(41, "feats", (B, C, N))
+    idx = (synth.uniform01(42, "idx", (B, M)) * N).astype(np.int32)
+    gidx = (synth.uniform01(43, "gidx", (B, M, NS)) * N).astype(np.int32)
+    gidx[:, : M // 3, 0] = N - 1                   # a hot source point
+    f = _dev(feats).requires_grad_(True)
+    out = pu.gather_operation(f, _dev(idx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.gather_points(feats, idx))
+    go = synth.normal(44, "go", (B, C, M))
+    out.backward(_dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref.gather_points_grad(go, idx, N), rtol=1e-5, atol=1e-5)
+    f.grad = None
+    out = pu.grouping_operation(f, _dev(gidx))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.group_points(feats, gidx))
+    go = synth.normal(45, "go2", (B, C, M, NS))
+    out.backward(_dev(go))
+    want = ref.group_points_grad(go, gidx, N)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
+
+
+@pytest.mark.parametrize("B,c,m,n", [(2, 9, 1300, 700), (3, 16, 100, 501), (1, 3, 40000, 1000)])
+def test_three_interpolate_kernel_forms(B, c, m, n):
+    from nsdp_amd import pointnet2_utils as pu
+    feats = synth.normal(51, "f", (B, c, m))
+    idx = (synth.uniform01(52, "i", (B, n, 3)) * m).astype(np.int32)
+    w = synth.uniform(53, "w", (B, n, 3), 0.0, 1.0)
+    f = _dev(feats).requires_grad_(True)
+    out = pu.three_interpolate(f, _dev(idx), _dev(w))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), ref.three_interpolate(feats, idx, w))
+    go = synth.normal(54, "go", (B, c, n))
+    out.backward(_dev(go))
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ref.three_interpolate_grad(go, idx, w, m), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("radius,nsample", [(0.2, 8), (0.05, 4), (2.0, 16), (1e-4, 3)])
 def test_ball_query_matches_oracle(radius, nsample):
     from nsdp_amd import pointnet2_utils as pu
@@ -170,3 +211,29 @@ def test_rows_gather_scatter():
             np.add.at(want[b], idx[b], go[b])
         got = pu.scatter_add_rows(_dev(go), _dev(idx), 300).cpu().numpy()
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_scatter_add_rows_inverse_list_form_matches_the_atomic_form():
+    """index_points' backward at a size that takes the inverse-list + segment-sum path (deterministic) against numpy and
+    against the atomic kernel (NSDP_SCATTER_ROWS=atomic's form)."""
+    from nsdp_amd import pointnet2_utils as pu
+    B, N, C, S = 3, 700, 128, 9000
+    go = synth.normal(61, "g", (B, S, C))
+    idx = (synth.uniform01(62, "i", (B, S)) * N).astype(np.int32)
+    idx[:, :500] = 5                                    # a hot row; row 6 stays empty
+    idx[idx == 6] = 7
+    want = np.zeros((B, N, C), dtype=np.float64)
+    for b in range(B):
+        np.add.at(want[b], idx[b], go[b].astype(np.float64))
+    a = pu.scatter_add_rows(_dev(go), _dev(idx), N)
+    assert torch.equal(a, pu.scatter_add_rows(_dev(go), _dev(idx), N))          # deterministic
+    was = pu._SCATTER_INVERSE
+    pu._SCATTER_INVERSE = False
+    try:
+        b_ = pu.scatter_add_rows(_dev(go), _dev(idx), N)
+    finally:
+        pu._SCATTER_INVERSE = was
+    tol = 1e-5 * float(np.abs(want).max())
+    np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(b_.cpu().numpy(), want, rtol=1e-5, atol=tol)
+    assert float(a[:, 6].abs().max()) == 0.0

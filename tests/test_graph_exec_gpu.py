@@ -1,0 +1,79 @@
+"""The multi-stream graph executor (csrc/graph_exec.hip, nsdp_amd/graph_step.py): a captured TDNet train step replayed
+from C must train exactly like the eager step -- same losses step for step, same weights afterwards."""
+import pytest
+import torch
+
+from helpers import build_product, model_cfg, to_dev
+from nsdp_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _make(cfg, seed, data):
+    from nsdp_amd.model import optimizer_factory
+    from nsdp_amd.model.utils import compute_l2_error
+    model, _, _ = build_product(cfg, seed, DEV)
+    model.train()
+    _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-5}, model.parameters())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = model(data["space_samples_src"], data["surface_samples_inputs"])
+        loss = compute_l2_error(pred, data["space_samples_tgt"])
+        loss.backward()
+        opt.step()
+        return loss
+    return model, opt, step
+
+
+@pytest.mark.parametrize("B,npl,ns,nq,streams", [(2, [256, 64, 16], 256, 128, 4), (16, [2048, 500, 100], 2048, 8192, 4),
+                                                  (2, [256, 64, 16], 256, 128, 1)])
+def test_replayed_step_trains_like_the_eager_step(B, npl, ns, nq, streams):
+    """B = 16 at full point counts takes the weight-gradient side stream (131 072 output rows): the captured graph has
+    cross-stream edges there, which the executor turns into events between its own streams."""
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    cfg = model_cfg("forward", npl)
+    data = to_dev(synth.make_batch(91, B, ns, nq), DEV)
+    model_e, opt_e, step_e = _make(cfg, 91, data)
+    eager = [float(step_e()) for _ in range(7)]
+    model_g, opt_g, step_g = _make(cfg, 91, data)
+    capturable_adam(opt_g)
+    gs = GraphedStep(step_g, max_streams=streams).capture(warmup=3)
+    assert gs.info["kernels"] > 300 and gs.info["streams"] <= streams
+    if B == 16 and streams > 1:
+        assert gs.info["streams"] >= 2 and gs.info["cross_stream_edges"] >= 50, gs.info
+    got = [float(gs()) for _ in range(4)]
+    torch.cuda.synchronize()
+    for a, b in zip(eager[3:], got):
+        assert abs(a - b) <= 2e-3 * abs(a) + 1e-7, (eager, got)
+    # (Adam moves a weight by ~lr per step whatever the gradient's size: a gradient that is analytically zero -- the bias
+    # of a conv in front of a train-mode BatchNorm -- is rounding noise whose sign differs between two runs, so such an
+    # entry may sit anywhere within +- steps x lr; the losses above are the sharp check, this one catches a lost update)
+    for (k, p), (_, q) in zip(model_e.named_parameters(), model_g.named_parameters()):
+        assert float((p - q).abs().max()) <= 2 * 7 * 5e-5, k
+    # new inputs go in through the static tensors
+    data["space_samples_tgt"].add_(0.25)
+    moved = float(gs())
+    torch.cuda.synchronize()
+    assert moved > 1.5 * got[-1]
+    gs.close()
+
+
+def test_set_lr_changes_the_update_of_a_replayed_step():
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam, set_lr
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = to_dev(synth.make_batch(92, 2, 256, 128), DEV)
+    model, opt, step = _make(cfg, 92, data)
+    capturable_adam(opt)
+    gs = GraphedStep(step).capture(warmup=1)
+    w = next(model.decoder.parameters())
+    w0 = w.detach().clone()
+    gs()
+    d1 = float((w.detach() - w0).abs().max())
+    set_lr(opt, 5e-3)                       # 100x
+    w1 = w.detach().clone()
+    gs()
+    d2 = float((w.detach() - w1).abs().max())
+    torch.cuda.synchronize()
+    assert d2 > 20 * d1 > 0, (d1, d2)

@@ -23,6 +23,7 @@ def rccl_world1():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT")}
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(DEV)
@@ -31,6 +32,11 @@ def rccl_world1():
         yield
     finally:
         dist.destroy_process_group()
+        for k, v in saved.items():      # (later tests start subprocesses: they must not inherit this rendezvous)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_rccl_all_reduce_of_the_flat_gradient_bucket_world1(rccl_world1):

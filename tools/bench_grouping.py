@@ -37,8 +37,18 @@ for (B, N, C, S, what) in [(32, 2048, 120, 500, "step: FPS centres of level 1"),
     out_b = B * S * C * 4
     print(f"gather_rows      B={B} N={N} C={C} S={S:7d} ({what}): {t*1e6:8.1f} us  {2*out_b/t/1e9:7.1f} GB/s (gathered read + write)")
     g = torch.randn(B, S, C, device=dev)
+    pu._SCATTER_INVERSE = False
     t = timeit(lambda: pu.scatter_add_rows(g, idx, N))
-    print(f"scatter_add_rows same shape: {t*1e6:8.1f} us  {out_b/t/1e9:7.1f} GB/s (read; atomics into [B,N,C])")
+    print(f"scatter_add_rows same shape, global atomics: {t*1e6:8.1f} us  {out_b/t/1e9:7.1f} GB/s (read; atomics into [B,N,C])")
+    pu._SCATTER_INVERSE = True
+    if C % 4 == 0 and N <= 8192:
+        t = timeit(lambda: pu.scatter_add_rows(g, idx, N))
+        def cold():
+            idx.__dict__.pop("_nsdp_inverse", None)
+            return pu.scatter_add_rows(g, idx, N)
+        tc = timeit(cold)
+        print(f"scatter_add_rows same shape, inverse lists + segment sum: {t*1e6:8.1f} us  {out_b/t/1e9:7.1f} GB/s with the lists "
+              f"cached on the index tensor; {tc*1e6:8.1f} us  {out_b/tc/1e9:7.1f} GB/s including the list build")
 
 # ---- the channel-major `pointnet2_ops._ext` operators (reference group_points_gpu.cu:8-64, sampling_gpu.cu:8-57,
 # ball_query_gpu.cu:9-44, interpolate_gpu.cu:9-141): achieved GB/s against their ALGORITHMIC bytes (SURVEY.md section 8d:
