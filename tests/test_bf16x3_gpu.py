@@ -39,6 +39,12 @@ X3_CASES = [  # (M, K, N, bias, residual, mask, out_mask, relu_in, relu_out)
     (33000, 256, 128, True, False, False, True, False, False),       # out_mask epilogue
     (9000, 200, 128, True, True, False, False, True, True),          # relu on both sides + residual
     (300, 36, 200, True, False, False, False, False, False),         # K just above one k block
+    # several row blocks per persistent workgroup (the prefetch of the next block's first k blocks under the epilogue, the
+    # ragged last block), one case per width class / kernel form
+    (256 * 256 * 3 + 77, 200, 200, True, False, False, False, False, True),      # 13 n tiles, 8 waves
+    (256 * 256 * 3 + 77, 200, 200, False, False, False, False, True, False),     # no bias, ReLU prologue
+    (256 * 192 * 3 + 5, 256, 256, True, False, False, False, False, False),      # 16 n tiles, 4 waves x 3 row tiles
+    (256 * 256 * 3 + 31, 96, 104, True, False, False, False, False, True),       # resident-weight form (<= 128 wide)
 ]
 
 
