@@ -1,0 +1,180 @@
+// Training-mode forward of the decoder's cross attention as ONE register-resident chain kernel.
+//
+// Reference: CrossTransformerBlock.forward, model/decoder/blocks.py:48-95 (per query point and neighbour slot:
+// rel -> fc_delta.0 -> ReLU -> fc_delta.2 = pos;  u = q - k_anchor + pos;  fc_gamma.0 -> ReLU -> fc_gamma.2 = logits;
+// softmax over the 7 neighbours + the global token, per channel;  sum softmax * (v_anchor + pos)).  The layered training
+// path runs this as 6 launches over materialised [B*NQ*7, 200] tensors (K = 4 layer, 3 dense layers, attn_pre, attn_post:
+// 5 tensors written and 6 read back in the forward pass).
+//
+// Here one wave carries 16 query points through all of it without leaving the register file -- the fp32 MFMA chain of
+// decoder_fused.hip (chain_f32.h) -- and WRITES what the backward pass needs on the way: the hidden layer h0, pos, u,
+// the hidden layer g0, the logits (all [B*NQ*KN, D]) and the aggregate + log-sum-exp ([B*NQ, D]).  The forward pass
+// then moves 5 tensors instead of 11, in one launch instead of six; the backward pass is the layered one, unchanged (the
+// host side hands these tensors to the per-layer autograd nodes as their precomputed outputs).
+// Arithmetic: exact fp32 products (v_mfma_f32_16x16x4_f32), fp32 accumulation -- the layered path's bf16x3 layers carry the
+// same fp32-level error (tests/test_bf16x3_gpu.py), so either forward feeds the same backward.
+#include <type_traits>
+
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+#include "chain_f32.h"
+
+constexpr int DT = 13;          // 16-channel tiles of the attention width (200 -> 208)
+constexpr int D = 200;
+
+struct Vec {
+  f32x4 t[DT];
+};
+
+struct TrainParams {
+  const float *rel;          // [B,NQ,KN,3]  query - anchor
+  const int32_t *idx;        // [B,NQ,KN]
+  const float *q;            // [B,D]        w_qs(z): one query vector per shape
+  const float *kf, *vf;      // [B,A,D]      anchor key / value tables
+  const float *a_g, *v_g;    // [B,D]        global token: logits, values
+  const float *w0, *b0;      // [D,3], [D]   fc_delta.0 (row-major parameter)
+  const float *wd2, *bd2;    // fragment-major fp32 pack of fc_delta.2 (nsdp_pack_weight_f32 layout), bias [D]
+  const float *wg0, *bg0, *wg2, *bg2;
+  float *h0, *pos, *u, *g0, *logits;   // [B*NQ*KN, D]
+  float *out, *lse;                     // [B*NQ, D]
+  int B, NQ, A, KN;
+};
+
+// one activation vector of this lane's row -> row-major [.., D] (lane (li, g) holds channels 16 t + 4 g .. + 3 of tile t)
+__device__ __forceinline__ void store_vec(float *row, const f32x4 *v, int g, bool valid) {
+  if (!valid) return;
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {
+    if (t * 16 + 4 * g + 4 <= D) *reinterpret_cast<f32x4 *>(row + t * 16 + 4 * g) = v[t];
+  }
+}
+__device__ __forceinline__ float4 load_quad(const float *row, int t, int g) {      // zero past channel D
+  if (t * 16 + 4 * g + 4 <= D) return *reinterpret_cast<const float4 *>(row + t * 16 + 4 * g);
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+constexpr int kWaves = 2;   // waves per workgroup: 2 x 39 KiB of private softmax state -> two workgroups per CU
+
+__global__ __launch_bounds__(kWaves * 64) void decoder_attn_train_fwd_kernel(TrainParams p) {
+  // online-softmax state (running max / sum / weighted value per channel) in a wave-private LDS slab, as in
+  // decoder_fused.hip: [quantity][tile][lane] float4, one read + write per neighbour slot, no barriers anywhere
+  __shared__ float4 state[kWaves][3][DT][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int q0 = (blockIdx.x * kWaves + wave) * 16;
+  if (q0 >= p.NQ) return;
+  int q = q0 + li;
+  const bool qvalid = q < p.NQ;
+  q = qvalid ? q : (p.NQ - 1);
+  const size_t qrow = static_cast<size_t>(b) * p.NQ + q;
+  const float *kfb = p.kf + static_cast<size_t>(b) * p.A * D;
+  const float *vfb = p.vf + static_cast<size_t>(b) * p.A * D;
+  const float *qv = p.q + static_cast<size_t>(b) * D;
+
+  float4 (*S)[DT][64] = state[wave];
+#pragma unroll
+  for (int t = 0; t < DT; ++t) {      // the softmax starts from the global token (position encoding 0)
+    S[0][t][lane] = load_quad(p.a_g + static_cast<size_t>(b) * D, t, g);
+    S[1][t][lane] = make_float4(1.f, 1.f, 1.f, 1.f);
+    S[2][t][lane] = load_quad(p.v_g + static_cast<size_t>(b) * D, t, g);
+  }
+
+  for (int slot = 0; slot < p.KN; ++slot) {
+    // (loop-invariant weight bases laundered once per iteration: LICM would otherwise hoist ~1000 fragment loads)
+    int opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));
+    const float *w0 = p.w0 + opaque0, *b0 = p.b0 + opaque0, *wd2 = p.wd2 + opaque0, *bd2 = p.bd2 + opaque0,
+                *wg0 = p.wg0 + opaque0, *bg0 = p.bg0 + opaque0, *wg2 = p.wg2 + opaque0, *bg2 = p.bg2 + opaque0;
+    const size_t r = qrow * p.KN + slot;           // row of the [B*NQ*KN, D] tensors
+    const int a = p.idx[r];
+    // relative coordinate, augmented with 1 for the bias column: lane group g carries component g
+    const float rel = g < 3 ? p.rel[r * 3 + g] : 1.0f;
+    Vec va, vb, pos;
+    // fc_delta.0: [D x 4] * [4 x 16 rows] (K = 3 + the bias column), ReLU
+#pragma unroll
+    for (int ot = 0; ot < DT; ++ot) {
+      const int ch = ot * 16 + li;
+      float w = 0.f;
+      if (ch < D) w = g < 3 ? w0[ch * 3 + g] : b0[ch];
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w, rel, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f);
+      va.t[ot] = acc;
+    }
+    store_vec(p.h0 + r * D, va.t, g, qvalid);
+    dense<DT, DT, false, false, false, D>(wd2, bd2, va.t, pos.t, li, g);            // pos = fc_delta.2(h0)
+    store_vec(p.pos + r * D, pos.t, g, qvalid);
+    const float *ka = kfb + static_cast<size_t>(a) * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {                                                   // u = (q - k_a) + pos
+      const float4 k4 = load_quad(ka, t, g), q4 = load_quad(qv, t, g);
+      va.t[t] = f32x4{(q4.x - k4.x) + pos.t[t][0], (q4.y - k4.y) + pos.t[t][1], (q4.z - k4.z) + pos.t[t][2],
+                      (q4.w - k4.w) + pos.t[t][3]};
+    }
+    store_vec(p.u + r * D, va.t, g, qvalid);
+    dense<DT, DT, false, true, false, D>(wg0, bg0, va.t, vb.t, li, g);              // g0 = relu(fc_gamma.0(u))
+    store_vec(p.g0 + r * D, vb.t, g, qvalid);
+    dense<DT, DT, false, false, false, D>(wg2, bg2, vb.t, va.t, li, g);             // logits = fc_gamma.2(g0)
+    store_vec(p.logits + r * D, va.t, g, qvalid);
+    const float *va_row = vfb + static_cast<size_t>(a) * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      const float4 v4 = load_quad(va_row, t, g);
+      const float sv[4] = {v4.x + pos.t[t][0], v4.y + pos.t[t][1], v4.z + pos.t[t][2], v4.w + pos.t[t][3]};
+      const float4 m4 = S[0][t][lane], l4 = S[1][t][lane], y4 = S[2][t][lane];
+      float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ll[4] = {l4.x, l4.y, l4.z, l4.w}, yy[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float av = va.t[t][c];
+        const float mn = fmaxf(mm[c], av);
+        const float sc = __expf(mm[c] - mn);
+        const float w = __expf(av - mn);
+        ll[c] = ll[c] * sc + w;
+        yy[c] = yy[c] * sc + w * sv[c];
+        mm[c] = mn;
+      }
+      S[0][t][lane] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+      S[1][t][lane] = make_float4(ll[0], ll[1], ll[2], ll[3]);
+      S[2][t][lane] = make_float4(yy[0], yy[1], yy[2], yy[3]);
+    }
+  }
+  if (qvalid) {
+    float *orow = p.out + qrow * D, *lrow = p.lse + qrow * D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+      if (t * 16 + 4 * g + 4 <= D) {
+        const float4 m4 = S[0][t][lane], l4 = S[1][t][lane], y4 = S[2][t][lane];
+        *reinterpret_cast<float4 *>(orow + t * 16 + 4 * g) = make_float4(y4.x / l4.x, y4.y / l4.y, y4.z / l4.z, y4.w / l4.w);
+        *reinterpret_cast<float4 *>(lrow + t * 16 + 4 * g) =
+            make_float4(m4.x + __logf(l4.x), m4.y + __logf(l4.y), m4.z + __logf(l4.z), m4.w + __logf(l4.w));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int nsdp_decoder_attn_train_fwd(const float *rel, const int32_t *idx, const float *q, const float *kf,
+                                           const float *vf, const float *a_g, const float *v_g, const float *w0,
+                                           const float *b0, const float *wd2p, const float *bd2, const float *wg0p,
+                                           const float *bg0, const float *wg2p, const float *bg2, int B, int NQ, int A, int KN,
+                                           int dim, float *h0, float *pos, float *u, float *g0, float *logits, float *out,
+                                           float *lse, void *stream) {
+  if (static_cast<long long>(B) * NQ <= 0 || KN <= 0) return 0;
+  NSDP_REQUIRE(dim == D, "decoder_attn_train_fwd: built for dim = %d (got %d)", D, dim);
+  NSDP_REQUIRE(rel && idx && q && kf && vf && a_g && v_g && w0 && b0 && wd2p && bd2 && wg0p && bg0 && wg2p && bg2 && h0 &&
+                   pos && u && g0 && logits && out && lse, "decoder_attn_train_fwd: null pointer");
+  NSDP_REQUIRE(B <= 65535 && A > 0, "decoder_attn_train_fwd: bad batch / anchor count");
+  TrainParams p{rel, idx, q, kf, vf, a_g, v_g, w0, b0, wd2p, bd2, wg0p, bg0, wg2p, bg2, h0, pos, u, g0, logits, out, lse,
+                B, NQ, A, KN};
+  hipStream_t st = nsdp::as_stream(stream);
+  // per query and slot: 2 * D * (4 + 3 * 208) flops in the dense layers; bytes: 5 [R,D] tensors written + the small ones
+  const double rows = static_cast<double>(B) * NQ * KN;
+  nsdp::prof::Scope scope(nsdp::prof::kDecoderFwd, st, rows * 2.0 * 208 * (4 + 3 * 208), rows * (5.0 * D * 4 + 16) + 2.0 * B * NQ * D * 4);
+  NSDP_TRACE("decoder_attn_train_fwd");
+  hipLaunchKernelGGL(decoder_attn_train_fwd_kernel, dim3(nsdp::ceil_div(NQ, 16 * kWaves), B), dim3(kWaves * 64), 0, st, p);
+  return nsdp::launch_status("decoder_attn_train_fwd_kernel");
+}

@@ -131,7 +131,7 @@ class _AttnPre(torch.autograd.Function):
     """u = q[:, :, None] - kf[idx] + pos."""
 
     @staticmethod
-    def forward(ctx, q, kf, pos, idx, link=None, inv=None):
+    def forward(ctx, q, kf, pos, idx, link=None, inv=None, pre=None):
         ctx.link = link
         ctx.inv = inv
         q, kf, pos = _c(q), _c(kf), _c(pos)
@@ -140,14 +140,16 @@ class _AttnPre(torch.autograd.Function):
         qb = int(q.shape[1] == 1 and n != 1)  # (B,1,d): one query vector per shape
         if link is not None:
             link.qb = bool(qb)
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, n, N, k, d, qb)
+        if pre is not None:          # computed by a fused forward kernel: this node only records the backward
+            return pre.reshape(pos.shape)
         u = torch.empty_like(pos)
         dt = pos.dtype
         with on_device(pos):
             check(_fn("nsdp_attn_pre_fwd", dt)(_p(q, dt, "q"), _p(kf, dt, "kf"), _p(pos, dt, "pos"), iptr(idx, "idx"), _ci(B),
                                                _ci(n), _ci(N), _ci(k), _ci(d), _ci(qb), _p(u, dt), stream_ptr()),
                   "nsdp_attn_pre_fwd")
-        ctx.save_for_backward(idx)
-        ctx.dims = (B, n, N, k, d, qb)
         return u
 
     @staticmethod
@@ -191,14 +193,14 @@ class _AttnPre(torch.autograd.Function):
             link.fused = False
         if dt is BF16:           # (scatter / reduction outputs are produced in fp32; the tables are small)
             dq, dkf = dq.to(BF16), dkf.to(BF16)
-        return dq, dkf, (du if acc is None else acc), None, None, None
+        return dq, dkf, (du if acc is None else acc), None, None, None, None
 
 
 class _AttnPost(torch.autograd.Function):
     """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
 
     @staticmethod
-    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None):
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None, pre=None):
         ctx.link = link
         ctx.inv = inv
         a, pos = _c(a), _c(pos)
@@ -209,13 +211,16 @@ class _AttnPost(torch.autograd.Function):
         B, n, k, d = a.shape
         N = vf.shape[1] if vf is not None else 1
         dt = a.dtype
-        y = torch.empty((B, n, d), dtype=dt, device=a.device)
-        lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
-        with on_device(a):
-            check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
-                                                _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
-                                                _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse), stream_ptr()),
-                  "nsdp_attn_post_fwd")
+        if pre is not None:          # (aggregate, log-sum-exp) from a fused forward kernel
+            y, lse = pre[0].reshape(B, n, d), pre[1].reshape(B, n, d)
+        else:
+            y = torch.empty((B, n, d), dtype=dt, device=a.device)
+            lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
+            with on_device(a):
+                check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
+                                                    _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
+                                                    _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse),
+                                                    stream_ptr()), "nsdp_attn_post_fwd")
         ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse)
         ctx.dims = (B, n, N, k, d)
         return y
@@ -261,7 +266,7 @@ class _AttnPost(torch.autograd.Function):
             dpos = None                               # travels as the dX GEMM's residual; attn_pre reports the total
         elif link is not None and ctx.needs_input_grad[2]:
             link.dpos, dpos = dpos, None              # attn_pre's backward adds d(u) and reports the sum
-        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None, None
 
 
 def pos_grad_link():
@@ -291,13 +296,13 @@ def backward_lists(idx, n, N, d, qb=False):
     return inverse_lists(idx, N)
 
 
-def attn_pre(q, kf, pos, idx, link=None, inv=None):
+def attn_pre(q, kf, pos, idx, link=None, inv=None, precomputed=None):
     if pos.dtype is torch.bfloat16 and not NATIVE_BF16:
         return _AttnPre.apply(_f(q), _f(kf), _f(pos), idx, link, inv).to(torch.bfloat16)
-    return _AttnPre.apply(q, kf, pos, idx, link, inv)
+    return _AttnPre.apply(q, kf, pos, idx, link, inv, precomputed)
 
 
-def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None):
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None, precomputed=None):
     if a.dtype is torch.bfloat16 and not NATIVE_BF16:
         return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link, inv).to(torch.bfloat16)
-    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv)
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv, precomputed)

@@ -478,7 +478,10 @@ class InputGradSum:
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0):
+    def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
+                pre=None):
+        # pre: this layer's output, already computed by a fused forward kernel (hip_decoder.attn_train_forward): the node
+        # only records what its backward needs -- no launch
         # bw (backward contract of a Linear -> ReLU -> Linear pair whose middle tensor has no other reader):
         #   1 on the first layer ("premasked"): the incoming gradient already carries this layer's ReLU mask
         #   2 on the second ("mask_dx"): dX is masked by (x > 0) in the dX kernel's epilogue, i.e. it IS that gradient
@@ -510,7 +513,10 @@ class _LinearFn(torch.autograd.Function):
         kind_t = "x3" if _x3_ok(M, Kp, N) else "wp"                    # dX: Kp outputs, N is the reduction dim
         wp = _packs(w, owner, kind, want_t and kind_t == kind)[0]
         wpt = _packs(w, owner, kind_t, True)[1] if want_t else None
-        y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
+        if pre is not None:
+            y = pre.reshape(M, N)
+        else:
+            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
@@ -560,7 +566,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -594,7 +600,7 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False, premasked=False, mask_dx=False):
+           out_f32=False, premasked=False, mask_dx=False, precomputed=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -614,6 +620,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
+        if precomputed is not None:
+            raise ValueError("precomputed outputs belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -639,5 +647,5 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param, grad_sum, None, bw)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw)
+                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed)

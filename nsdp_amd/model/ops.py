@@ -111,12 +111,13 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # dense layers
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
-           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False) -> torch.Tensor:
+           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
-                             params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx)
+                             params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
+                             precomputed=precomputed)
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -172,6 +173,11 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
     as [B,n,k,d]); idx [B,n,k] int32; ``pos`` re-uses an already computed delta(rel) (second attention of the
     set abstraction); a_g / v_g [B,d]: logits / values of a per-shape global token (decoder).
     Returns (aggregate [B,n,d], pos [B,n,k,d])."""
+    if (pos is None and q is not None and a_g is not None and torch.is_grad_enabled() and not precision.is_bf16()
+            and not PAIR_MASK):
+        from .. import hip_decoder
+        if hip_decoder.TRAIN_FUSED and hip_decoder.attn_train_supported(rel, q, kf, a_g, fc_delta, fc_gamma):
+            return _vector_attention_fused_forward(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual, a_g, v_g)
     if pos is None:
         pos = mlp2(rel, fc_delta)                              # 2 dense layers on [B*n*k] rows
     if q is None:
@@ -187,4 +193,23 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         u = hip_attention.attn_pre(q, kf, pos, idx, link, inv)      # q_i - kf[idx] + pos, gather fused
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv)
+    return out, pos
+
+
+def _vector_attention_fused_forward(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual, a_g, v_g):
+    """The decoder's block in training mode with its forward pass in ONE launch (hip_decoder.attn_train_forward, the
+    register-resident chain kernel): the autograd graph is the layered one -- the same per-layer nodes with the same
+    backward kernels and hand-over protocols -- but every node receives its output precomputed and launches nothing."""
+    from .. import hip_decoder
+    (h0, pos_t, u_t, g0, logits_t), out_lse = hip_decoder.attn_train_forward(rel, idx, q, kf, vf, a_g, v_g, fc_delta, fc_gamma)
+    pos = linear(linear(rel, fc_delta[0], relu=True, precomputed=h0), fc_delta[2], precomputed=pos_t)
+    link = hip_attention.pos_grad_link() if pos.requires_grad else None
+    if link is not None and FUSE_DPOS:
+        link.grad_sum = hip_linear.InputGradSum()
+    inv = hip_attention.backward_lists(idx, pos.shape[1], kf.shape[1], pos.shape[-1], qb=True)
+    u = hip_attention.attn_pre(q, kf, pos, idx, link, inv, precomputed=u_t)
+    gs = link.grad_sum if link is not None else None
+    logits = linear(linear(u, fc_gamma[0], relu=True, grad_sum=gs, precomputed=g0), fc_gamma[2], precomputed=logits_t)
+    out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv,
+                                  precomputed=out_lse)
     return out, pos
