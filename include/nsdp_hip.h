@@ -65,6 +65,16 @@ int nsdp_group_points(const float *points, const int32_t *idx, int B, int C, int
 int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int NP,
                            int NS, float *grad_points, void *stream);
 
+/* The gradient of gather_points / group_points for callers that hold the inverse of the index map (nsdp_knn_invert on
+ * idx viewed as (B,E): offsets (B,N+1), entries (B,E), lists ascending): grad_points(B,C,N)[b,c,s] = sum over the list of s
+ * of grad_out(B,C,E)[b,c,entry] -- no atomics, deterministic, a stream over grad_out (the index set is shared by all C
+ * channels, so one list build serves them all).  Same result as nsdp_group_points_grad (sampling_gpu.cu:34-57,
+ * group_points_gpu.cu:43-75) up to the order of the fp32 sums.  Needs a row of E floats to fit LDS
+ * (nsdp_scatter_cm_lists_supported). */
+int nsdp_scatter_cm_lists_supported(int B, int C, int N, int E);
+int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const int32_t *entries, int B, int C, int N,
+                          int E, float *grad_points, void *stream);
+
 /* ball_query(new_xyz(B,M,3), xyz(B,N,3), radius, nsample) -> (B,M,nsample) i32;
  * ball_query.cpp:8-34, ball_query_gpu.cu:9-54 */
 int nsdp_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M, float radius,

@@ -154,6 +154,49 @@ __global__ __launch_bounds__(kBig) void scatter_cm_lds_kernel(const float *__res
   }
 }
 
+// The same gradient WITHOUT atomics, for callers that hold the inverse of the index map (nsdp_knn_invert: offsets
+// [B][N+1], entries [B][E], every list ascending): grad_points[b,c,s] = sum over the list of s of grad_out[b,c,entry].
+// LDS fp32 atomics run at ~0.4 per clock and CU on this part -- the table kernel above is bound by them at 0.9 TB/s.
+// Here a workgroup stages CH whole rows of grad_out (E floats each) in LDS with coalesced float4 loads and every thread
+// owns target points: it walks its list once for all CH channels (LDS reads), sums in list order and writes each target
+// element exactly once -- a stream over grad_out, deterministic.  The lists depend on idx[b, :] only: one build serves all
+// channels (and is cached by the Python host on the index tensor).
+template <int CH>
+__global__ __launch_bounds__(kBig) void scatter_cm_lists_kernel(const float *__restrict__ grad_out,
+                                                                const int32_t *__restrict__ offsets,
+                                                                const int32_t *__restrict__ entries, int C, int N, int E,
+                                                                float *__restrict__ grad_points) {
+  extern __shared__ float table[];      // [CH][E]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = C - c0 < CH ? C - c0 : CH;
+  const float *src = grad_out + (static_cast<long long>(b) * C + c0) * E;
+  if ((E & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int t = threadIdx.x * 4; t < cn * E; t += kBig * 4)
+      *reinterpret_cast<float4 *>(table + t) = *reinterpret_cast<const float4 *>(src + t);
+  } else {
+    for (int t = threadIdx.x; t < cn * E; t += kBig) table[t] = src[t];
+  }
+  __syncthreads();
+  const int32_t *off = offsets + static_cast<long long>(b) * (N + 1);
+  const int32_t *ent = entries + static_cast<long long>(b) * E;
+  float *o0 = grad_points + (static_cast<long long>(b) * C + c0) * N;
+  for (int s = threadIdx.x; s < N; s += kBig) {
+    const int lo = off[s], hi = off[s + 1];
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+    for (int i = lo; i < hi; ++i) {
+      const int e = ent[i];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[c] += table[(c < cn ? c : 0) * E + e];
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < cn) o0[static_cast<long long>(c) * N + s] = acc[c];
+  }
+}
+
 // flat forms (rows that do not fit LDS)
 __global__ void gather_cm_flat_kernel(const float *__restrict__ points, const int32_t *__restrict__ idx, long long total, int C,
                                       int N, int E, float *__restrict__ out) {
@@ -657,6 +700,43 @@ int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const
   hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st,
                      grad_out, idx, weight, total, c, n, m, grad_points);
   return nsdp::launch_status("three_interpolate_grad_kernel");
+}
+
+int nsdp_scatter_cm_lists_supported(int B, int C, int N, int E) {
+  return B > 0 && B <= 65535 && C > 0 && N > 0 && E > 0 && 4LL * E <= kLdsTableMax;
+}
+
+int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const int32_t *entries, int B, int C, int N,
+                          int E, float *grad_points, void *stream) {
+  if (static_cast<long long>(B) * C * N <= 0) return 0;
+  NSDP_REQUIRE(grad_out && offsets && entries && grad_points, "scatter_cm_lists: null pointer");
+  NSDP_REQUIRE(nsdp_scatter_cm_lists_supported(B, C, N, E), "scatter_cm_lists: a row of E=%d floats must fit LDS (<= %d bytes)", E,
+               kLdsTableMax);
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * E * (1 + C) + static_cast<double>(B) * C * N));
+  const long long row_bytes = 4LL * E;
+  int ch = static_cast<int>((row_bytes <= kLdsTableBytes ? kLdsTableBytes : kLdsTableMax) / row_bytes);
+  ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
+  while (ch > 1 && static_cast<long long>(B) * ((C + ch - 1) / ch) < 2LL * nsdp::num_cus()) ch >>= 1;
+  const dim3 grid((C + ch - 1) / ch, B);
+  const size_t lds = static_cast<size_t>(ch) * E * 4;
+  NSDP_TRACE("scatter_cm_lists<%d>", ch);
+#define NSDP_SCL(CH)                                                                                                       \
+  {                                                                                                                        \
+    static bool once = (allow_big_lds(&scatter_cm_lists_kernel<CH>), true);                                                \
+    (void)once;                                                                                                            \
+    hipLaunchKernelGGL((scatter_cm_lists_kernel<CH>), grid, dim3(kBig), lds, st, grad_out, offsets, entries, C, N, E,       \
+                       grad_points);                                                                                       \
+  }
+  switch (ch) {
+    case 8: NSDP_SCL(8) break;
+    case 4: NSDP_SCL(4) break;
+    case 2: NSDP_SCL(2) break;
+    default: NSDP_SCL(1) break;
+  }
+#undef NSDP_SCL
+  return nsdp::launch_status("scatter_cm_lists_kernel");
 }
 
 int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int C, int S, float *out,

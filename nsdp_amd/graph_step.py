@@ -75,7 +75,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph(keep_graph=True)
-        with torch.cuda.graph(graph):
+        # thread_local: other threads of the process (the RCCL watchdog of a data-parallel job polls events) may keep
+        # making HIP calls while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self.fn()
         torch.cuda.synchronize()
         raw = graph.raw_cuda_graph()

@@ -107,6 +107,25 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+def _scatter_cm(grad_out3, idx2, N, idx_obj=None):
+    """grad (B,C,N) of a channel-major gather: grad_out3 (B,C,E), idx2 (B,E).  Through the inverse index lists (cached on the
+    index tensor; csrc/segment.hip builds them) and the atomics-free LDS-staged kernel where a row of E floats fits LDS and
+    the lists are short; None otherwise (the caller then uses the LDS-table / atomic entry point)."""
+    B, C, E = grad_out3.shape
+    L = lib()
+    if not (_SCATTER_INVERSE and 0 < N <= 8192 and E <= 64 * N and L.nsdp_scatter_cm_lists_supported(_c_int(B), _c_int(C),
+                                                                                                 _c_int(N), _c_int(E))):
+        return None
+    from . import hip_attention
+    # (the cache of the lists lives on the index tensor OBJECT the caller holds across calls, not on a view of it)
+    offsets, entries = hip_attention.inverse_lists(idx2 if idx_obj is None else idx_obj, N)
+    grad = torch.empty((B, C, N), dtype=torch.float32, device=grad_out3.device)
+    with on_device(grad_out3):
+        check(L.nsdp_scatter_cm_lists(fptr(grad_out3, "grad_out"), iptr(offsets), iptr(entries), _c_int(B), _c_int(C), _c_int(N),
+                                      _c_int(E), fptr(grad), stream_ptr()), "nsdp_scatter_cm_lists")
+    return grad
+
+
 class GatherOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):
@@ -126,6 +145,9 @@ class GatherOperation(Function):
         B, C, N = features.shape
         M = idx.shape[1]
         grad_out = grad_out.contiguous()
+        grad = _scatter_cm(grad_out, idx, N)
+        if grad is not None:
+            return grad, None
         grad = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
         with on_device(grad_out):
             check(lib().nsdp_gather_points_grad(fptr(grad_out, "grad_out"), iptr(idx), _c_int(B), _c_int(C),
@@ -213,6 +235,9 @@ class GroupingOperation(Function):
         B, C, N = features.shape
         _, NP, NS = idx.shape
         grad_out = grad_out.contiguous()
+        grad = _scatter_cm(grad_out.view(B, C, NP * NS), idx.view(B, NP * NS), N, idx_obj=idx)
+        if grad is not None:
+            return grad, torch.zeros_like(idx)
         grad = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
         with on_device(grad_out):
             check(lib().nsdp_group_points_grad(fptr(grad_out, "grad_out"), iptr(idx), _c_int(B), _c_int(C),

@@ -64,7 +64,15 @@ for (B, C, N, NP, NS, what) in [(32, 128, 2048, 500, 16, "SA level 1 shape"), (3
     out = pu.grouping_operation(feats, idx)
     g = torch.randn_like(out)
     t = timeit(lambda: torch.autograd.grad(out, feats, g, retain_graph=True))
-    print(f"group_points_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f}")
+    def cold():
+        idx.__dict__.pop("_nsdp_inverse", None)
+        return torch.autograd.grad(out, feats, g, retain_graph=True)
+    tc = timeit(cold)
+    pu._SCATTER_INVERSE = False
+    ta = timeit(lambda: torch.autograd.grad(out, feats, g, retain_graph=True))
+    pu._SCATTER_INVERSE = True
+    print(f"group_points_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f} (inverse lists cached on the index "
+          f"tensor; {tc*1e6:.1f} us = {alg/tc/8e12:.2f} including the list build; LDS-table form {ta*1e6:.1f} us = {alg/ta/8e12:.2f})")
     idx1 = torch.randint(0, N, (B, NP), device=dev, dtype=torch.int32)
     t = timeit(lambda: pu.gather_operation(feats.detach(), idx1))
     alg1 = 4.0 * (B * C * NP + B * NP + min(B * C * N, B * C * NP * 16))      # (a gather of np columns touches <= np 64-B sectors per row)

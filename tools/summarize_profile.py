@@ -23,8 +23,8 @@ def short(name):
     return (m.group(1) if m else name)[:90]
 
 
-for suffix, title in (("", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline"),
-                      ("_iso", "NSDP_WGRAD_STREAM=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
+for suffix, title in (("", "python bench.py --eager --reps 1 --steps 5 --warmup 2 --no-cpu-baseline (the eager launcher: the same kernels as the graph replay, which the tracer does not need to see captured)"),
+                      ("_iso", "NSDP_WGRAD_STREAM=0 python bench.py --eager --reps 1 --steps 5 --warmup 2 --no-cpu-baseline "
                                "(weight gradients on the main stream: every duration is the kernel alone -- the profile "
                                "that matches bench.py's `roofline`)"),
                       ("_bf16", "NSDP_WGRAD_STREAM=0 python bench.py --dtype bf16 --workload arbitrary_train --steps 5 "
@@ -112,7 +112,8 @@ if os.path.exists(sq_path):
                     f"{100*v.get('SQ_WAIT_INST_ANY',0)/wc:.0f} % | {100*v.get('SQ_ACTIVE_INST_ANY',0)/wc:.0f} % |\n")
 for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json",
              "bench_forward_eval.json", "bench_forward_bf16.json", "bench_arbitrary_bf16.json", "bench_b8_bf16.json",
-             "bench_2ranks_gloo.json"):
+             "bench_2ranks_gloo.json", "bench_default_eager.json", "bench_b8_eager.json", "bench_forward_bf16_eager.json",
+             "bench_arbitrary_bf16_eager.json", "bench_force_reducer_nccl.json"):
     src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
     if os.path.exists(src) and open(src).read().strip():
         open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
