@@ -70,7 +70,7 @@ int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int
  * of grad_out(B,C,E)[b,c,entry] -- no atomics, deterministic, a stream over grad_out (the index set is shared by all C
  * channels, so one list build serves them all).  Same result as nsdp_group_points_grad (sampling_gpu.cu:34-57,
  * group_points_gpu.cu:43-75) up to the order of the fp32 sums.  Needs a row of E floats to fit LDS
- * (nsdp_scatter_cm_lists_supported). */
+ * (nsdp_scatter_cm_lists_supported: E <= 32768). */
 int nsdp_scatter_cm_lists_supported(int B, int C, int N, int E);
 int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const int32_t *entries, int B, int C, int N,
                           int E, float *grad_points, void *stream);

@@ -710,6 +710,7 @@ int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const i
                           int E, float *grad_points, void *stream) {
   if (static_cast<long long>(B) * C * N <= 0) return 0;
   NSDP_REQUIRE(grad_out && offsets && entries && grad_points, "scatter_cm_lists: null pointer");
+  // (rows longer than LDS were tried in slices with atomically combined partial sums: no faster than the LDS-table kernel)
   NSDP_REQUIRE(nsdp_scatter_cm_lists_supported(B, C, N, E), "scatter_cm_lists: a row of E=%d floats must fit LDS (<= %d bytes)", E,
                kLdsTableMax);
   hipStream_t st = nsdp::as_stream(stream);

@@ -61,27 +61,34 @@ for (B, C, N, NP, NS, what) in [(32, 128, 2048, 500, 16, "SA level 1 shape"), (3
     t = timeit(lambda: pu.grouping_operation(feats.detach(), idx))
     alg = 4.0 * (B * C * NP * NS + B * NP * NS + B * C * N)
     print(f"group_points      B={B} C={C} N={N} np={NP} ns={NS} ({what}): {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f} of HBM peak")
-    out = pu.grouping_operation(feats, idx)
-    g = torch.randn_like(out)
-    t = timeit(lambda: torch.autograd.grad(out, feats, g, retain_graph=True))
+    g = torch.randn(B, C, NP * NS, device=dev)
+    idx2 = idx.view(B, NP * NS)
+    # (the kernels behind GroupingOperation.backward, called directly: torch.autograd.grad alone costs ~50 us of Python)
+    t = timeit(lambda: pu._scatter_cm(g, idx2, N, idx_obj=idx))
     def cold():
         idx.__dict__.pop("_nsdp_inverse", None)
-        return torch.autograd.grad(out, feats, g, retain_graph=True)
+        return pu._scatter_cm(g, idx2, N, idx_obj=idx)
     tc = timeit(cold)
-    pu._SCATTER_INVERSE = False
-    ta = timeit(lambda: torch.autograd.grad(out, feats, g, retain_graph=True))
-    pu._SCATTER_INVERSE = True
-    print(f"group_points_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f} (inverse lists cached on the index "
-          f"tensor; {tc*1e6:.1f} us = {alg/tc/8e12:.2f} including the list build; LDS-table form {ta*1e6:.1f} us = {alg/ta/8e12:.2f})")
+    gp = torch.empty(B, C, N, device=dev)
+    import ctypes
+    from nsdp_amd._lib import lib, fptr, iptr, stream_ptr
+    ta = timeit(lambda: lib().nsdp_group_points_grad(fptr(g), iptr(idx), ctypes.c_int(B), ctypes.c_int(C), ctypes.c_int(N),
+                                                     ctypes.c_int(NP), ctypes.c_int(NS), fptr(gp), stream_ptr()))
+    if pu._scatter_cm(g, idx2, N, idx_obj=idx) is None:
+        print(f"group_points_grad same shape: LDS-table form {ta*1e6:.1f} us = {alg/ta/8e12:.2f} (no inverse lists: N > 8192 sources)")
+    else:
+        print(f"group_points_grad same shape: {t*1e6:8.1f} us  {alg/t/1e9:7.1f} GB/s = {alg/t/8e12:.2f} (inverse lists cached on the "
+              f"index tensor; {tc*1e6:.1f} us = {alg/tc/8e12:.2f} including the list build; LDS-table form {ta*1e6:.1f} us = {alg/ta/8e12:.2f})")
     idx1 = torch.randint(0, N, (B, NP), device=dev, dtype=torch.int32)
     t = timeit(lambda: pu.gather_operation(feats.detach(), idx1))
     alg1 = 4.0 * (B * C * NP + B * NP + min(B * C * N, B * C * NP * 16))      # (a gather of np columns touches <= np 64-B sectors per row)
     print(f"gather_points     B={B} C={C} N={N} np={NP}: {t*1e6:8.1f} us  {alg1/t/1e9:7.1f} GB/s = {alg1/t/8e12:.2f}")
-    o1 = pu.gather_operation(feats, idx1)
-    g1 = torch.randn_like(o1)
-    t = timeit(lambda: torch.autograd.grad(o1, feats, g1, retain_graph=True))
+    g1 = torch.randn(B, C, NP, device=dev)
+    t = timeit(lambda: pu._scatter_cm(g1, idx1, N))
     alg1g = 4.0 * (B * C * NP + B * NP + B * C * N)                           # (the gradient tensor is zero-filled and written once)
-    print(f"gather_points_grad same shape: {t*1e6:8.1f} us  {alg1g/t/1e9:7.1f} GB/s = {alg1g/t/8e12:.2f}")
+    if pu._scatter_cm(g1, idx1, N) is None:
+        t = float("nan")
+    print(f"gather_points_grad same shape (inverse lists, cached): {t*1e6:8.1f} us  {alg1g/t/1e9:7.1f} GB/s = {alg1g/t/8e12:.2f}")
 
 print()
 for (B, N, M, ns, r, what) in [(32, 2048, 500, 16, 0.2, "SA level 1"), (32, 8192, 2048, 32, 0.1, "SSG first level"), (16, 16384, 4096, 32, 0.08, "large")]:
