@@ -262,6 +262,8 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
       ++g->n_cross;
     }
   }
+  // (branch streams at normal priority: hipStreamCreateWithPriority at EITHER end of the device's range made the B = 32 step
+  // 64 ms instead of 43 ms -- docs/EXPERIMENTS.md)
   for (int s = 1; s < used; ++s) {
     hipStream_t st = nullptr;
     e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
