@@ -109,18 +109,8 @@ WG_CASES = [  # (M, N, K, mask, relu_x)
 ]
 
 
-@pytest.fixture(params=["rows", "columns"])
-def wgrad_form(request):
-    """Both forms of the bf16x3 weight-gradient kernel: row-wise float4 producer + transpose reads (default), and the
-    column-wise producer that writes fragment-ordered planes (nsdp_debug_set(9, 0))."""
-    from nsdp_amd import _lib
-    _lib.lib().nsdp_debug_set(9, 1 if request.param == "rows" else 0)
-    yield request.param
-    _lib.lib().nsdp_debug_set(9, 1)
-
-
 @pytest.mark.parametrize("M,N,K,mask,relu_x", WG_CASES)
-def test_wgrad_bf16x3_matches_fp64(M, N, K, mask, relu_x, wgrad_form):
+def test_wgrad_bf16x3_matches_fp64(M, N, K, mask, relu_x):
     from nsdp_amd import hip_linear
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     dy, x = _rand(g, M, N), _rand(g, M, K)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the GPU suite under each A/B knob of the library (every variant must stay parity-green, not only the default)
 for kv in "NSDP_WGRAD_STREAM=0" "NSDP_WGRAD_STREAM=1" "NSDP_PARAM_GRADS=autograd" "NSDP_INVERSE_LISTS=0" "NSDP_FUSE_DPOS=0" \
-          "NSDP_X3_DBG=128" "NSDP_X3_DBG=32" "NSDP_PAIR_MASK=1" "NSDP_ONEHOT_SCATTER=0" "NSDP_BF16X3=0" "NSDP_FUSED_DECODER=0" "NSDP_WG16_DBG=8" "NSDP_REMASK_K4=0" "NSDP_WG3_ROWS=0"; do
+          "NSDP_X3_DBG=128" "NSDP_X3_DBG=32" "NSDP_PAIR_MASK=1" "NSDP_ONEHOT_SCATTER=0" "NSDP_BF16X3=0" "NSDP_FUSED_DECODER=0" "NSDP_WG16_DBG=8" "NSDP_REMASK_K4=0" "NSDP_X3_DBG=256" "NSDP_DECODER_TRAIN_FUSED=1" "NSDP_GRAPH_STREAMS=4" "NSDP_SCATTER_ROWS=atomic"; do
   printf "%-28s " "$kv"
   env $kv timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -1
 done
