@@ -111,3 +111,45 @@ class GraphedStep:
             self.close()
         except Exception:
             pass
+
+
+class GraphedTrainOnBatch:
+    """Drop-in for the reference-shaped ``train_on_batch(model, optimizer, data_dict, config) -> float`` of
+    nsdp_amd.model (reference model/deformation_networks.py:63-77, model/flow_arbitrary.py:30-48): the first call with a
+    given set of batch shapes copies the batch into static tensors, captures the step (its ``tensor_step`` form: the same
+    statements without ``loss.item()``) and from then on every call is a copy of the batch into the static tensors plus
+    one replay.  A batch of other shapes (the last, shorter one of an epoch) runs eagerly.  Returns the loss as a float,
+    like the reference -- that read-back is the one host sync per step the reference has as well."""
+
+    def __init__(self, train_on_batch, max_streams: int | None = None, warmup: int = 2):
+        if not hasattr(train_on_batch, "tensor_step"):
+            raise TypeError("train_on_batch has no `tensor_step` form (the step without its loss.item())")
+        self.eager = train_on_batch
+        self.max_streams, self.warmup = max_streams, warmup
+        self._shapes = None
+        self._static = None
+        self._step = None
+        self.replays = self.eager_calls = 0
+
+    @staticmethod
+    def _sig(data_dict):
+        return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in data_dict.items() if torch.is_tensor(v)))
+
+    def __call__(self, model, optimizer, data_dict, config):
+        sig = self._sig(data_dict)
+        if self._step is None:
+            capturable_adam(optimizer)
+            self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
+            fn = lambda: self.eager.tensor_step(model, optimizer, self._static, config)      # noqa: E731
+            # (the warm-up steps are real optimizer steps on this batch -- the capture itself executes nothing)
+            self._step = GraphedStep(fn, self.max_streams).capture(warmup=self.warmup)
+            self._shapes = sig
+            self.eager_calls += self.warmup
+        if sig != self._shapes:
+            self.eager_calls += 1
+            return self.eager(model, optimizer, data_dict, config)
+        for k, v in data_dict.items():
+            if torch.is_tensor(v):
+                self._static[k].copy_(v, non_blocking=True)
+        self.replays += 1
+        return float(self._step())

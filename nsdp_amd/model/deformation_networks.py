@@ -33,14 +33,23 @@ class Deformation_Networks(nn.Module):
         return self.decoder(points, encoding)
 
 
-def train_on_batch_with_cano(model, optimizer, data_dict, config):
-    """reference model/deformation_networks.py:63-77."""
+def _train_step_with_cano(model, optimizer, data_dict, config):
+    """The step of train_on_batch_with_cano up to (not including) the host read-back of the loss: everything that is
+    enqueued on the GPU.  This is what nsdp_amd.graph_step captures and replays."""
     optimizer.zero_grad()
     pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
     loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
     loss.backward()
     optimizer.step()
-    return loss.item()
+    return loss
+
+
+def train_on_batch_with_cano(model, optimizer, data_dict, config):
+    """reference model/deformation_networks.py:63-77."""
+    return _train_step_with_cano(model, optimizer, data_dict, config).item()
+
+
+train_on_batch_with_cano.tensor_step = _train_step_with_cano
 
 
 @torch.no_grad()

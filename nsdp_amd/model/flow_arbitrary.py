@@ -28,15 +28,23 @@ def _split(data_dict):
     return s[:, :, 0:3], s[:, :, 3:6], s[:, :, 6:7]
 
 
-def train_on_batch_with_arbitrary(model, optimizer, data_dict, config):
-    """reference model/flow_arbitrary.py:30-48."""
+def _train_step_with_arbitrary(model, optimizer, data_dict, config):
+    """train_on_batch_with_arbitrary without the host read-back of the loss (what nsdp_amd.graph_step captures)."""
     optimizer.zero_grad()
     src, tgt, mask = _split(data_dict)
     pred = model(data_dict["space_samples_src"], src, tgt, mask)
     loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
     loss.backward()
     optimizer.step()
-    return loss.item()
+    return loss
+
+
+def train_on_batch_with_arbitrary(model, optimizer, data_dict, config):
+    """reference model/flow_arbitrary.py:30-48."""
+    return _train_step_with_arbitrary(model, optimizer, data_dict, config).item()
+
+
+train_on_batch_with_arbitrary.tensor_step = _train_step_with_arbitrary
 
 
 @torch.no_grad()

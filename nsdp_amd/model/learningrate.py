@@ -1,4 +1,5 @@
 """Learning-rate schedule used by optimizer_factory (mirror of the reference's model/learningrate.py)."""
+import torch
 
 
 class LearningRateSchedule:
@@ -22,7 +23,11 @@ def adjust_learning_rate(lr_schedules, optimizer, epoch):
     """reference model/learningrate.py:28-34."""
     for i, group in enumerate(optimizer.param_groups):
         sched = lr_schedules[i] if isinstance(lr_schedules, list) else lr_schedules
-        group["lr"] = sched.get_learning_rate(epoch)
+        lr = sched.get_learning_rate(epoch)
+        if torch.is_tensor(group["lr"]):      # capturable optimizers keep the rate on the device (graph replay reads it there)
+            group["lr"].fill_(float(lr))
+        else:
+            group["lr"] = lr
 
 
 def get_learning_rates(optimizer):

@@ -119,6 +119,9 @@ def main(argv=None):
     ap.add_argument("--synthetic", type=int, default=4, help="procedural batches per epoch (no dataset readers yet)")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the train step once and replay it (nsdp_amd.graph_step.GraphedTrainOnBatch): batches of "
+                         "one fixed shape; note that the capture's warm-up runs two extra optimizer steps on the first batch")
     args = ap.parse_args(argv)
     args.best_val_loss = float("inf")
     seed_everything(args.seed)
@@ -137,6 +140,9 @@ def main(argv=None):
               "config's training section or on the command line)")
     model, train_fn, val_fn, _ = build_model(config, *weights, device=device)
     lr_scheduler, optimizer = optimizer_factory(config["training"], model.parameters())
+    if args.graph:
+        from .graph_step import GraphedTrainOnBatch
+        train_fn = GraphedTrainOnBatch(train_fn)
     train = SyntheticLoader(args.seed, args.synthetic, args.batch)
     val = SyntheticLoader(args.seed + 10000, max(1, args.synthetic // 4), args.batch)
     fit(model, (train_fn, val_fn), lr_scheduler, optimizer, train, val, config, args.experiment_directory, args, device)

@@ -80,6 +80,40 @@ def test_short_training_run_through_the_harness(tmp_path):
     assert "decoder.ct1.fc_gamma.0.weight" in sd and "encoder.enc_sdf.weight" in sd
 
 
+def test_harness_with_the_replayed_train_step(tmp_path):
+    """fit() with train_on_batch replaced by its graph-replay drop-in (GraphedTrainOnBatch): same loop, same checkpoints,
+    the learning-rate schedule reaching the captured step through the device-side rate, a batch of another shape falling back
+    to the eager function."""
+    from nsdp_amd.graph_step import GraphedTrainOnBatch
+    from nsdp_amd.model import build_model, optimizer_factory
+    cfg = model_cfg("forward", [256, 64, 16])
+    cfg["training"] = {"epochs": 4, "save_frequency": 2, "optimizer": "Adam", "lr": 5e-4, "lr_step": 2,
+                       "lr_decay": 0.1, "weight_decay": 0.0}
+    cfg["validation"] = {"frequency": 2}
+    hists = []
+    for graph in (False, True):
+        train.seed_everything(27)
+        model, train_fn, val_fn, _ = build_model(cfg, device=DEV)
+        sched, opt = optimizer_factory(cfg["training"], model.parameters())
+        loader = train.SyntheticLoader(3, 3, 2, n_surf=256, n_query=128)
+        odd = train.SyntheticLoader(9, 1, 1, n_surf=256, n_query=128)          # one batch of another shape per epoch
+        both = list(loader) + list(odd)
+        fn = GraphedTrainOnBatch(train_fn, warmup=0) if graph else train_fn
+        args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+        sub = tmp_path / ("g" if graph else "e")
+        sub.mkdir()
+        hists.append(train.fit(model, (fn, val_fn), sched, opt, both, loader, cfg, str(sub), args, DEV, log=lambda *_: None))
+        if graph:
+            assert fn.replays == 4 * 3 and fn.eager_calls == 4
+            assert torch.is_tensor(opt.param_groups[0]["lr"]) and abs(float(opt.param_groups[0]["lr"]) - 5e-5) < 1e-9
+    e = [h[2] for h in hists[0] if h[0] == "train"]
+    g = [h[2] for h in hists[1] if h[0] == "train"]
+    assert len(e) == len(g) == 4
+    for a, b in zip(e, g):
+        assert abs(a - b) <= 2e-2 * abs(a), (e, g)
+    assert g[-1] < g[0]
+
+
 @pytest.mark.parametrize("inverse,noise_level", [(False, 0.0), (True, 0.02)])
 def test_prepare_batch_matches_oracle(inverse, noise_level):
     from nsdp_amd import dataset
