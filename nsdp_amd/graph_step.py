@@ -16,7 +16,8 @@ Rules of the capture (the same as for any CUDA / HIP graph):
     batches into them with `copy_`), and what it returns are static tensors overwritten by every replay;
   * no host synchronisation inside `fn` (`.item()`, `.cpu()`, prints of tensors);
   * optimizers must be capturable (`capturable_adam`): the step counter lives on the device; a learning rate that changes
-    must be a device tensor (`set_lr`).
+    must be a device tensor (`set_lr`); and the optimizer STATE must exist before the capture (run at least one eager
+    step, `warmup >= 1`): state created inside a capture is re-initialised by every replay.
 """
 from __future__ import annotations
 
@@ -115,17 +116,17 @@ class GraphedStep:
 
 class GraphedTrainOnBatch:
     """Drop-in for the reference-shaped ``train_on_batch(model, optimizer, data_dict, config) -> float`` of
-    nsdp_amd.model (reference model/deformation_networks.py:63-77, model/flow_arbitrary.py:30-48): the first call with a
-    given set of batch shapes copies the batch into static tensors, captures the step (its ``tensor_step`` form: the same
-    statements without ``loss.item()``) and from then on every call is a copy of the batch into the static tensors plus
-    one replay.  A batch of other shapes (the last, shorter one of an epoch) runs eagerly.  Returns the loss as a float,
+    nsdp_amd.model (reference model/deformation_networks.py:63-77, model/flow_arbitrary.py:30-48): the first call runs
+    eagerly, the second one captures the step (its ``tensor_step`` form: the same statements without ``loss.item()``) over
+    static copies of the batch, and from then on every call is a copy of the batch into the static tensors plus one replay
+    -- the sequence of optimizer steps is exactly the eager loop's.  A batch of other shapes (the last, shorter one of an epoch) runs eagerly.  Returns the loss as a float,
     like the reference -- that read-back is the one host sync per step the reference has as well."""
 
-    def __init__(self, train_on_batch, max_streams: int | None = None, warmup: int = 2):
+    def __init__(self, train_on_batch, max_streams: int | None = None):
         if not hasattr(train_on_batch, "tensor_step"):
             raise TypeError("train_on_batch has no `tensor_step` form (the step without its loss.item())")
         self.eager = train_on_batch
-        self.max_streams, self.warmup = max_streams, warmup
+        self.max_streams = max_streams
         self._shapes = None
         self._static = None
         self._step = None
@@ -137,17 +138,21 @@ class GraphedTrainOnBatch:
 
     def __call__(self, model, optimizer, data_dict, config):
         sig = self._sig(data_dict)
-        if self._step is None:
+        if self._shapes is None:
+            # The very first step runs eagerly (with the optimizer already in its capturable form): it creates the optimizer
+            # state.  State created INSIDE a capture would be re-initialised by every replay (Adam's moments zeroed each
+            # step) -- and an extra warm-up step would change what the loop computes.
             capturable_adam(optimizer)
-            self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
-            fn = lambda: self.eager.tensor_step(model, optimizer, self._static, config)      # noqa: E731
-            # (the warm-up steps are real optimizer steps on this batch -- the capture itself executes nothing)
-            self._step = GraphedStep(fn, self.max_streams).capture(warmup=self.warmup)
             self._shapes = sig
-            self.eager_calls += self.warmup
+            self.eager_calls += 1
+            return float(self.eager.tensor_step(model, optimizer, data_dict, config))
         if sig != self._shapes:
             self.eager_calls += 1
             return self.eager(model, optimizer, data_dict, config)
+        if self._step is None:
+            self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
+            fn = lambda: self.eager.tensor_step(model, optimizer, self._static, config)      # noqa: E731
+            self._step = GraphedStep(fn, self.max_streams).capture(warmup=0)      # (a capture executes nothing)
         for k, v in data_dict.items():
             if torch.is_tensor(v):
                 self._static[k].copy_(v, non_blocking=True)

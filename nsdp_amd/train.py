@@ -121,7 +121,7 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--graph", action="store_true",
                     help="capture the train step once and replay it (nsdp_amd.graph_step.GraphedTrainOnBatch): batches of "
-                         "one fixed shape; note that the capture's warm-up runs two extra optimizer steps on the first batch")
+                         "one fixed shape replay, others run eagerly; the sequence of optimizer steps is the eager loop's")
     args = ap.parse_args(argv)
     args.best_val_loss = float("inf")
     seed_everything(args.seed)

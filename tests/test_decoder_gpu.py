@@ -101,7 +101,9 @@ def test_train_step_through_the_fused_decoder_forward_matches_the_reference(trai
     model, train_fn, _ = build_product(cfg, seed, DEV)
     with _variant_trace() as names:
         _check_train_step(fx, model, train_fn, cfg, data)
-    assert "decoder_attn_train_fwd" in names, sorted(names)
+    from nsdp_amd.model import ops
+    if not ops.PAIR_MASK:          # (NSDP_PAIR_MASK=1 keeps the layered forward: its backward contract differs)
+        assert "decoder_attn_train_fwd" in names, sorted(names)
 
 
 def test_fused_decoder_forward_tensors_equal_the_layered_ones():

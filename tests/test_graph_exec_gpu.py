@@ -77,3 +77,23 @@ def test_set_lr_changes_the_update_of_a_replayed_step():
     d2 = float((w.detach() - w1).abs().max())
     torch.cuda.synchronize()
     assert d2 > 20 * d1 > 0, (d1, d2)
+
+
+def test_optimizer_state_created_inside_a_capture_is_reset_by_every_replay():
+    """Why capture() warms up / GraphedTrainOnBatch runs its first step eagerly: documented behaviour of stream capture."""
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    p = torch.nn.Parameter(torch.ones(1024, device=DEV))
+    opt = torch.optim.Adam([p], lr=1e-2)
+    capturable_adam(opt)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        (p * p).sum().backward()
+        opt.step()
+        return p.detach().sum()
+    gs = GraphedStep(step).capture(warmup=0)
+    for _ in range(3):
+        gs()
+    torch.cuda.synchronize()
+    assert float(opt.state[p]["step"]) == 1.0          # re-initialised and incremented once per replay, never beyond 1
+    gs.close()

@@ -1,7 +1,14 @@
 #!/bin/bash
 # the GPU suite under each A/B knob of the library (every variant must stay parity-green, not only the default)
-for kv in "NSDP_WGRAD_STREAM=0" "NSDP_WGRAD_STREAM=1" "NSDP_PARAM_GRADS=autograd" "NSDP_INVERSE_LISTS=0" "NSDP_FUSE_DPOS=0" \
-          "NSDP_X3_DBG=128" "NSDP_X3_DBG=32" "NSDP_PAIR_MASK=1" "NSDP_ONEHOT_SCATTER=0" "NSDP_BF16X3=0" "NSDP_FUSED_DECODER=0" "NSDP_WG16_DBG=8" "NSDP_REMASK_K4=0" "NSDP_X3_DBG=256" "NSDP_DECODER_TRAIN_FUSED=1" "NSDP_GRAPH_STREAMS=4" "NSDP_SCATTER_ROWS=atomic"; do
+#   tools/knob_matrix.sh [knob=value ...]      (default: all knobs)
+knobs=("NSDP_WGRAD_STREAM=0" "NSDP_WGRAD_STREAM=1" "NSDP_PARAM_GRADS=autograd" "NSDP_INVERSE_LISTS=0" "NSDP_FUSE_DPOS=0" \
+       "NSDP_X3_DBG=128" "NSDP_X3_DBG=32" "NSDP_PAIR_MASK=1" "NSDP_ONEHOT_SCATTER=0" "NSDP_BF16X3=0" "NSDP_FUSED_DECODER=0" \
+       "NSDP_WG16_DBG=8" "NSDP_REMASK_K4=0" "NSDP_X3_DBG=256" "NSDP_DECODER_TRAIN_FUSED=1" "NSDP_GRAPH_STREAMS=4" \
+       "NSDP_SCATTER_ROWS=atomic")
+[ $# -gt 0 ] && knobs=("$@")
+for kv in "${knobs[@]}"; do
   printf "%-28s " "$kv"
-  env $kv timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -1
+  env $kv timeout 900 python -m pytest tests -m gpu -q -x 2>&1 > /tmp/knob_out.txt
+  grep -E "^[0-9]+ (passed|failed)|passed|failed" /tmp/knob_out.txt | tail -1
+  grep -E "^FAILED|^E  " /tmp/knob_out.txt | head -6
 done
