@@ -226,7 +226,8 @@ def test_scatter_add_rows_inverse_list_form_matches_the_atomic_form():
     for b in range(B):
         np.add.at(want[b], idx[b], go[b].astype(np.float64))
     a = pu.scatter_add_rows(_dev(go), _dev(idx), N)
-    assert torch.equal(a, pu.scatter_add_rows(_dev(go), _dev(idx), N))          # deterministic
+    if pu._SCATTER_INVERSE:            # (NSDP_SCATTER_ROWS=atomic: the atomic kernel's order of summation varies)
+        assert torch.equal(a, pu.scatter_add_rows(_dev(go), _dev(idx), N))          # deterministic
     was = pu._SCATTER_INVERSE
     pu._SCATTER_INVERSE = False
     try:
