@@ -41,7 +41,9 @@ def test_replayed_step_trains_like_the_eager_step(B, npl, ns, nq, streams):
     capturable_adam(opt_g)
     gs = GraphedStep(step_g, max_streams=streams).capture(warmup=3)
     assert gs.info["kernels"] > 300 and gs.info["streams"] <= streams
-    if B == 16 and streams > 1:
+    from nsdp_amd import hip_linear
+    side = hip_linear._PARAM_GRADS_DIRECT and hip_linear._OVERLAP_WGRAD is not False      # (knobs that keep one stream)
+    if streams > 1 and side:      # (a captured step takes the weight-gradient side stream at every batch size)
         assert gs.info["streams"] >= 2 and gs.info["cross_stream_edges"] >= 50, gs.info
     got = [float(gs()) for _ in range(4)]
     torch.cuda.synchronize()
