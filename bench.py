@@ -239,11 +239,11 @@ def main():
                          "products, fp32 accuracy) | bf16 (BASELINE config 3: bf16 activations and saved tensors, fp32 "
                          "accumulation, fp32 master weights)")
     ap.add_argument("--eager", action="store_true",
-                    help="enqueue every launch of every step from Python (the reference's way).  Default for the train "
-                         "workloads: the step is captured once and replayed through the multi-stream graph executor "
+                    help="enqueue every launch of every step from Python (the reference's way).  Default: the step "
+                         "(train or inference) is captured once and replayed through the multi-stream graph executor "
                          "(nsdp_amd/graph_step.py: one C call per step instead of ~1000 Python-enqueued launches; same "
                          "kernels, same stream schedule, same numbers step for step)")
-    ap.add_argument("--graph", action="store_true", help="(the default for train workloads; kept for symmetry with --eager)")
+    ap.add_argument("--graph", action="store_true", help="(the default; kept for symmetry with --eager)")
     ap.add_argument("--stub-step", action="store_true",
                     help="replace the TDNet step by a tiny CPU model (tests of the launch / rendezvous / all-reduce / "
                          "timing / JSON plumbing on a box without GPUs; the line says so and is not a measurement)")
@@ -360,7 +360,7 @@ def main():
     graph = None
     graph_note = "eager (Python enqueues every launch)"
     eager_run = run
-    if (args.graph or not is_eval) and not args.eager:
+    if not args.eager:
         # the step captured once, replayed from C on real HIP streams (plain hipGraphLaunch serialises the branches of the
         # captured graph on this ROCm and is slower than eager).  A collective cannot be captured:
         # with a gradient exchange the step is two replays around it -- [zero_grad, forward, loss, backward] and
@@ -414,8 +414,8 @@ def main():
     # spans the time the kernel waits for CUs held by the other stream.
     prof_iso = None
     dominant = "linear_bf16x3_kernel" if args.dtype == "f32" else "linear_bf16_kernel"
-    if not is_eval:      # (every rank runs it -- same program on every rank; rank 0 reports it)
-        # (with --graph this pass runs the EAGER step function: the kernels are the same, and a replay carries no events)
+    if not is_eval or graph is not None:      # (every rank runs it -- same program on every rank; rank 0 reports it)
+        # (with graph replay this pass runs the EAGER step function: the kernels are the same, and a replay carries no events)
         from nsdp_amd import hip_linear
         one = eager_run if graph is not None else run
         was = hip_linear._OVERLAP_WGRAD
