@@ -848,7 +848,20 @@ int launch_x3(const X3Params &p, hipStream_t st) {
     else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
   } else {
     constexpr int MT0 = NT >= 16 ? 3 : 4;
-    if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
+    // Tile quantisation (16 n tiles): one persistent workgroup per CU walks row blocks of 4 waves x MT0 x 16 = 192 rows;
+    // 51 200 rows (the 100-anchor attention blocks of a 32-shape batch) are 267 blocks on 256 CUs -- two rounds, the
+    // second one 4 % full.  Two row tiles per wave (128-row blocks: 400 blocks, two shorter rounds) win whenever
+    // rounds x rows per block is smaller by more than what the narrower wave tile costs per row (~8 %).
+    bool narrow = false;
+    if constexpr (NT >= 16) {
+      const long long cus = nsdp::num_cus();
+      const long long r3 = ((p.M + 191) / 192 + cus - 1) / cus * 192, r2 = ((p.M + 127) / 128 + cus - 1) / cus * 128;
+      narrow = !(g_x3_dbg & 4096) && r2 * 108 < r3 * 100;
+    }
+    if (narrow) {
+      if (pre == 0) launch_x3_pre<2, NT, 0, 4>(p, st);
+      else launch_x3_pre<2, NT, 2, 4>(p, st);
+    } else if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
     else launch_x3_pre<MT0, NT, 2, 4>(p, st);
   }
   return nsdp::launch_status("linear_bf16x3_kernel");
