@@ -39,7 +39,6 @@ struct GraphExec {
   std::vector<hipStream_t> side;      // owned side streams (stream index s >= 1 -> side[s - 1])
   std::vector<hipEvent_t> events;
   hipEvent_t begin;
-  std::vector<int> first_on_stream;   // node index of the first node of every side stream (waits for `begin`)
   std::vector<hipEvent_t> tail_events;
   int n_kernels = 0, n_cross = 0, n_streams = 1, n_sub = 0;
 };
@@ -236,15 +235,8 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
   g->n_streams = used;
   // ---- cross-stream edges -> events (a wait on event E of stream S also covers everything S ran before E) ----------
   std::vector<std::vector<int>> covered(used, std::vector<int>(used, -1));     // [dst][src]: latest src position waited for
-  std::vector<char> started(used, 0);
-  started[0] = 1;
-  g->first_on_stream.assign(used, -1);
   for (size_t p = 0; p < n; ++p) {
     ExecNode &x = g->nodes[p];
-    if (!started[x.stream]) {
-      started[x.stream] = 1;
-      g->first_on_stream[x.stream] = static_cast<int>(p);
-    }
     std::vector<int> ds = dpos[p];
     std::sort(ds.begin(), ds.end(), [](int a, int b) { return a > b; });       // latest first: covers the earlier ones
     for (int d : ds) {
