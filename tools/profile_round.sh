@@ -25,6 +25,8 @@ python bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --warmup 2 --no-cpu-
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag} -o ${tag} -- \
   python $R/bench.py --eager --reps 1 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_replay -o ${tag}_replay -- \
+  python $R/bench.py --reps 1 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_replay.log 2>&1
 NSDP_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_iso -o ${tag}_iso -- \
   python $R/bench.py --eager --reps 1 --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof_${tag}_iso.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- \

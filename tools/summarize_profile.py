@@ -27,6 +27,9 @@ for suffix, title in (("", "python bench.py --eager --reps 1 --steps 5 --warmup 
                       ("_iso", "NSDP_WGRAD_STREAM=0 python bench.py --eager --reps 1 --steps 5 --warmup 2 --no-cpu-baseline "
                                "(weight gradients on the main stream: every duration is the kernel alone -- the profile "
                                "that matches bench.py's `roofline`)"),
+                      ("_replay", "python bench.py --reps 1 --steps 5 --warmup 2 --no-cpu-baseline (the DEFAULT launcher: the captured "
+                                  "step replayed by the multi-stream graph executor, traced as it runs -- durations include the "
+                                  "time a kernel shares the chip with the other stream's kernel)"),
                       ("_bf16", "NSDP_WGRAD_STREAM=0 python bench.py --dtype bf16 --workload arbitrary_train --steps 5 "
                                 "--warmup 2 --no-cpu-baseline (BASELINE config 3: FlowArbitrary, bf16 storage)")):
     stats = os.path.join(root, "gpurun_out", f"prof_{tag}{suffix}", f"{tag}{suffix}_kernel_stats.csv")
