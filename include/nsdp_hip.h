@@ -260,6 +260,14 @@ int nsdp_segment_sum_rows_bf16(const void *src, const int32_t *offsets, const in
 size_t nsdp_scatter_rows_onehot_bf16_workspace_bytes(int B, long long rows, int N, int d);
 int nsdp_scatter_rows_onehot_bf16(const void *src, const int32_t *idx, int B, long long rows, int N, int d, float *table,
                                   float *workspace, size_t workspace_bytes, void *stream);
+/* The same for fp32 storage: src (B, rows, d) fp32 is split into its three bf16 planes on the fly (csrc/wgrad_bf16x3.hip,
+ * one-hot mode) and the one-hot operand is exact, so table[b][a][c] is the fp32 sum of the selected rows in a FIXED order --
+ * the deterministic replacement of the fp32-atomic scatters (register-table / LDS-table kernels) behind the decoder's
+ * anchor-table gradients (reference model/decoder/blocks.py:72-77: the backward of index_points over 100 anchors).
+ * N <= 128, 16 < d <= 208, d % 4 == 0; table (B, N, d) is overwritten. */
+size_t nsdp_scatter_rows_onehot_f32_workspace_bytes(int B, long long rows, int N, int d);
+int nsdp_scatter_rows_onehot_f32(const float *src, const int32_t *idx, int B, long long rows, int N, int d, float *table,
+                                 float *workspace, size_t workspace_bytes, void *stream);
 
 /* K = 4 layers with bf16 storage (first layer of every position-encoding MLP: fp32 relative coordinates zero-padded
  * to 4 columns in, bf16 out; csrc/k4_bf16.hip).  W is the plain [N,4] fp32 matrix.  N % 8 == 0.
@@ -300,6 +308,21 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        const int32_t *idx, const float *a_g, const float *v_g, const float *y,
                        const float *residual, const float *lse, int B, int n, int N, int k, int d,
                        float *da, float *dpos, float *dvf, float *da_g, float *dv_g, void *stream);
+
+/* nsdp_attn_post_bwd for a block whose value scatter (dvf) is done by the caller (nsdp_scatter_rows_onehot_*): da, dpos and
+ * the global-token gradients with NO atomics -- a workgroup owns centres of one shape, partial sums are combined in a
+ * fixed order through `workspace` (>= nsdp_attn_post_bwd_det_workspace_bytes).  Bit-reproducible run to run.  vf required;
+ * a_g / v_g / da_g / dv_g all present or all NULL. */
+size_t nsdp_attn_post_bwd_det_workspace_bytes(int B, int n, int k, int d);
+int nsdp_attn_post_bwd_det(const float *dy, const float *a, const float *vf, const float *pos, const int32_t *idx,
+                           const float *a_g, const float *v_g, const float *y, const float *residual, const float *lse,
+                           int B, int n, int N, int k, int d, float *da, float *dpos, float *da_g, float *dv_g,
+                           float *workspace, size_t workspace_bytes, void *stream);
+int nsdp_attn_post_bwd_det_bf16(const void *dy, const void *a, const void *vf, const void *pos, const int32_t *idx,
+                                const void *a_g, const void *v_g, const void *y, const void *residual, const float *lse,
+                                int B, int n, int N, int k, int d, void *da, void *dpos, float *da_g, float *dv_g,
+                                float *workspace, size_t workspace_bytes, void *stream);
+
 
 /* ----------------------------------------------------------------------------------------------
  * Fused cross-attention decoder forward (no-grad / inference path): CrossTransformerDecoder.forward,

@@ -612,6 +612,121 @@ inline int launch_regtab_scatter(const T *src, const int32_t *idx, float *table,
   return nsdp::launch_status("scatter_rows_regtab_kernel");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic pure-stream form of attn_post_bwd for the blocks whose scatter is done elsewhere (the decoder: dvf comes out
+// of nsdp_scatter_rows_onehot_*): da and dpos as above, and the global-token gradients WITHOUT atomics -- a workgroup owns a
+// range of centres of ONE shape (grid.y), its waves' partial sums are combined through LDS in a fixed order and written to
+// gpart[b][blockIdx.x][{da_g, dv_g}][d]; global_token_reduce_kernel adds a shape's partials in order.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_post_bwd_shape_kernel(
+    AttnShape s, const T *__restrict__ dy, const T *__restrict__ a, const T *__restrict__ vf,
+    const T *__restrict__ pos, const int32_t *__restrict__ idx, const T *__restrict__ a_g,
+    const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
+    const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos, float *__restrict__ gpart) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 2 * 256];      // [wave][sub][{dag, dvg}][lpp quads]: <= 4 x 2 x 256 floats
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lpp = s.d >> 2, ppw = 64 / lpp;
+  const int sub = lane / lpp, cq = lane - sub * lpp;
+  const bool active = sub < ppw;
+  const int per_iter = ppw * 4;
+  const long long base = static_cast<long long>(b) * s.n;
+  const long long i0 = static_cast<long long>(blockIdx.x) * per_iter * s.iters + wave * ppw;
+  const long long blk_end = static_cast<long long>(blockIdx.x + 1) * per_iter * s.iters;
+  const long long pend = base + (blk_end < s.n ? blk_end : s.n);
+  const bool has_g = a_g != nullptr;
+  const long long tsz = static_cast<long long>(s.N) * s.d;
+  Quad dag{0.f, 0.f, 0.f, 0.f}, dvg{0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const T *vfb = vf + static_cast<long long>(b) * tsz;
+    Quad ag{0.f, 0.f, 0.f, 0.f}, vg{0.f, 0.f, 0.f, 0.f};
+    if (has_g) {
+      ag = ldc(a_g + static_cast<long long>(b) * s.d, cq);
+      vg = ldc(v_g + static_cast<long long>(b) * s.d, cq);
+    }
+    for (int it = 0; it < s.iters; ++it) {
+      const long long pt = base + i0 + static_cast<long long>(it) * per_iter + sub;
+      if (pt >= pend) break;
+      const int32_t *ip = idx + pt * s.k;
+      const long long r0 = pt * s.k * s.d;
+      const Quad g = ldc(dy + pt * s.d, cq);
+      Quad yb = ldc(y + pt * s.d, cq);
+      if (residual) {
+        const Quad r = ldc(residual + pt * s.d, cq);
+        yb.x -= r.x; yb.y -= r.y; yb.z -= r.z; yb.w -= r.w;
+      }
+      const Quad Lse = ldc(lse + pt * s.d, cq);
+#pragma unroll 2
+      for (int j = 0; j < s.k; ++j) {
+        const long long rj = r0 + static_cast<long long>(j) * s.d;
+        const Quad av = ldc(a + rj, cq);
+        Quad sv = ldc(pos + rj, cq);
+        const Quad vv = ldc(vfb + static_cast<long long>(ip[j]) * s.d, cq);
+        sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
+        const Quad ds{__expf(av.x - Lse.x) * g.x, __expf(av.y - Lse.y) * g.y, __expf(av.z - Lse.z) * g.z,
+                      __expf(av.w - Lse.w) * g.w};
+        stc(da + rj, cq,
+            Quad{ds.x * (sv.x - yb.x), ds.y * (sv.y - yb.y), ds.z * (sv.z - yb.z), ds.w * (sv.w - yb.w)});
+        stc(dpos + rj, cq, ds);
+      }
+      if (has_g) {
+        const Quad ds{__expf(ag.x - Lse.x) * g.x, __expf(ag.y - Lse.y) * g.y, __expf(ag.z - Lse.z) * g.z,
+                      __expf(ag.w - Lse.w) * g.w};
+        dag.x += ds.x * (vg.x - yb.x); dag.y += ds.y * (vg.y - yb.y);
+        dag.z += ds.z * (vg.z - yb.z); dag.w += ds.w * (vg.w - yb.w);
+        dvg.x += ds.x; dvg.y += ds.y; dvg.z += ds.z; dvg.w += ds.w;
+      }
+    }
+  }
+  if (!has_g) return;      // (uniform)
+  // slot (wave, sub) -> red[(wave * ppw + sub) * 2 + {0, 1}][4 lpp floats]; every slot is written (zeros where no centre)
+  if (active) {
+    float *r0 = red + static_cast<size_t>((wave * ppw + sub) * 2) * (4 * lpp);
+    stc(r0, cq, dag);
+    stc(r0 + 4 * lpp, cq, dvg);
+  }
+  __syncthreads();
+  const int slots = 4 * ppw;
+  for (int e = threadIdx.x; e < 2 * s.d; e += 256) {
+    const int which = e / s.d, c = e - which * s.d;
+    float t = 0.f;
+    for (int sl = 0; sl < slots; ++sl) t += red[static_cast<size_t>(sl * 2 + which) * (4 * lpp) + c];
+    gpart[(static_cast<long long>(b) * gridDim.x + blockIdx.x) * (2 * s.d) + e] = t;
+  }
+}
+
+// da_g[b][c] = sum over the S block partials of shape b (fixed order, 4 chains); dv_g likewise
+__global__ __launch_bounds__(256) void global_token_reduce_kernel(const float *__restrict__ gpart, int S, int d,
+                                                                  float *__restrict__ da_g, float *__restrict__ dv_g) {
+  const int b = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 2 * d) return;
+  const float *w = gpart + static_cast<long long>(b) * S * (2 * d) + e;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int sidx = 0;
+  for (; sidx + 4 <= S; sidx += 4) {
+    a0 += w[static_cast<long long>(sidx) * 2 * d]; a1 += w[static_cast<long long>(sidx + 1) * 2 * d];
+    a2 += w[static_cast<long long>(sidx + 2) * 2 * d]; a3 += w[static_cast<long long>(sidx + 3) * 2 * d];
+  }
+  for (; sidx < S; ++sidx) a0 += w[static_cast<long long>(sidx) * 2 * d];
+  const float t = (a0 + a1) + (a2 + a3);
+  if (e < d) da_g[static_cast<long long>(b) * d + e] = t;
+  else dv_g[static_cast<long long>(b) * d + (e - d)] = t;
+}
+
+// centres per workgroup / workgroups per shape of the deterministic stream form: ~4096 workgroups in total
+inline void shape_plan(AttnShape &s, dim3 &grid) {
+  const int ppw = 64 / (s.d >> 2), per_iter = ppw * 4;
+  long long iters = (static_cast<long long>(s.B) * s.n + 4096LL * per_iter - 1) / (4096LL * per_iter);
+  if (iters < iters_for(s.k)) iters = iters_for(s.k);
+  const long long max_iters = (s.n + per_iter - 1) / per_iter;
+  if (iters > max_iters) iters = max_iters;
+  s.iters = static_cast<int>(iters);
+  grid = dim3(static_cast<unsigned>((s.n + iters * per_iter - 1) / (iters * per_iter)), s.B);
+}
+
 inline bool lds_table_fits(const AttnShape &s) {
   return static_cast<long long>(s.N) * s.d * 4 <= 110 * 1024 && s.B <= 65535 && s.n >= 4 * s.N;
 }
@@ -784,9 +899,71 @@ int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const in
   return nsdp::launch_status("attn_post_bwd_kernel");
 }
 
+
+template <typename T>
+int attn_post_bwd_det_t(const T *dy, const T *a, const T *vf, const T *pos, const int32_t *idx, const T *a_g, const T *v_g,
+                        const T *y, const T *residual, const float *lse, int B, int n, int N, int k, int d, T *da, T *dpos,
+                        float *da_g, float *dv_g, float *workspace, size_t workspace_bytes, void *stream) {
+  constexpr double kEl = sizeof(T);
+  AttnShape s{B, n, N, k, d, 0, iters_for(k)};
+  hipStream_t st = nsdp::as_stream(stream);
+  if (static_cast<long long>(B) * n * k * d <= 0) {
+    if (da_g && static_cast<long long>(B) * d > 0) {
+      NSDP_HIP_TRY(hipMemsetAsync(da_g, 0, sizeof(float) * static_cast<size_t>(B) * d, st));
+      NSDP_HIP_TRY(hipMemsetAsync(dv_g, 0, sizeof(float) * static_cast<size_t>(B) * d, st));
+    }
+    return 0;
+  }
+  NSDP_REQUIRE(shape_ok(s) && B <= 65535, "attn_post_bwd_det: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
+  NSDP_REQUIRE(dy && a && vf && pos && idx && y && lse && da && dpos, "attn_post_bwd_det: null pointer");
+  NSDP_REQUIRE((a_g == nullptr) == (da_g == nullptr) && (a_g == nullptr) == (v_g == nullptr) &&
+                   (a_g == nullptr) == (dv_g == nullptr),
+               "attn_post_bwd_det: global-token pointers go together");
+  dim3 grid;
+  shape_plan(s, grid);
+  const size_t need = a_g ? static_cast<size_t>(B) * grid.x * 2 * d * sizeof(float) : 0;
+  NSDP_REQUIRE(workspace_bytes >= need && (!a_g || workspace), "attn_post_bwd_det: workspace too small");
+  nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
+                          kEl * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + N) * d));
+  NSDP_TRACE("attn_post_bwd_det");
+  hipLaunchKernelGGL((attn_post_bwd_shape_kernel<T>), grid, dim3(256), 0, st, s, dy, a, vf, pos, idx, a_g, v_g, y, residual,
+                     lse, da, dpos, workspace);
+  int rc = nsdp::launch_status("attn_post_bwd_shape_kernel");
+  if (rc || !a_g) return rc;
+  hipLaunchKernelGGL(global_token_reduce_kernel, dim3((2 * d + 255) / 256, B), dim3(256), 0, st, workspace,
+                     static_cast<int>(grid.x), d, da_g, dv_g);
+  return nsdp::launch_status("global_token_reduce_kernel");
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t nsdp_attn_post_bwd_det_workspace_bytes(int B, int n, int k, int d) {
+  if (B <= 0 || n <= 0 || d < 4) return 0;
+  AttnShape s{B, n, 1, k, d, 0, iters_for(k)};
+  dim3 grid;
+  shape_plan(s, grid);
+  return static_cast<size_t>(B) * grid.x * 2 * d * sizeof(float);
+}
+int nsdp_attn_post_bwd_det(const float *dy, const float *a, const float *vf, const float *pos, const int32_t *idx,
+                           const float *a_g, const float *v_g, const float *y, const float *residual, const float *lse,
+                           int B, int n, int N, int k, int d, float *da, float *dpos, float *da_g, float *dv_g,
+                           float *workspace, size_t workspace_bytes, void *stream) {
+  return attn_post_bwd_det_t<float>(dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, B, n, N, k, d, da, dpos, da_g, dv_g,
+                                    workspace, workspace_bytes, stream);
+}
+int nsdp_attn_post_bwd_det_bf16(const void *dy, const void *a, const void *vf, const void *pos, const int32_t *idx,
+                                const void *a_g, const void *v_g, const void *y, const void *residual, const float *lse,
+                                int B, int n, int N, int k, int d, void *da, void *dpos, float *da_g, float *dv_g,
+                                float *workspace, size_t workspace_bytes, void *stream) {
+  return attn_post_bwd_det_t<bf16_t>(reinterpret_cast<const bf16_t *>(dy), reinterpret_cast<const bf16_t *>(a),
+                                     reinterpret_cast<const bf16_t *>(vf), reinterpret_cast<const bf16_t *>(pos), idx,
+                                     reinterpret_cast<const bf16_t *>(a_g), reinterpret_cast<const bf16_t *>(v_g),
+                                     reinterpret_cast<const bf16_t *>(y), reinterpret_cast<const bf16_t *>(residual), lse, B, n,
+                                     N, k, d, reinterpret_cast<bf16_t *>(da), reinterpret_cast<bf16_t *>(dpos), da_g, dv_g,
+                                     workspace, workspace_bytes, stream);
+}
 
 int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const int32_t *idx, int B, int n,
                       int N, int k, int d, int q_per_shape, float *u, void *stream) {

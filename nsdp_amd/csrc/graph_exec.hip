@@ -70,8 +70,9 @@ hipError_t one_node_exec(hipGraph_t graph, const std::vector<hipGraphNode_t> &ha
   return hipSuccess;
 }
 
+// `what` == nullptr: the caller has already written the specific message (kept as it is)
 int fail(GraphExec *g, const char *what, hipError_t e) {
-  nsdp::set_error("graph_exec: %s: %s", what, hipGetErrorString(e));
+  if (what) nsdp::set_error("graph_exec: %s: %s", what, hipGetErrorString(e));
   if (g) {
     for (auto &x : g->nodes) {
       if (x.sub) (void)hipGraphExecDestroy(x.sub);
@@ -173,17 +174,20 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
         if (e != hipSuccess) return fail(g, "hipGraphKernelNodeGetParams", e);
         if (!x.kp.func || (!x.kp.kernelParams && !x.kp.extra)) {
           nsdp::set_error("graph_exec_create: kernel node %zu has no function / argument block", p);
-          return fail(g, "kernel node", hipErrorInvalidValue);
+          return fail(g, nullptr, hipErrorInvalidValue);
         }
         if (!x.kp.kernelParams) {      // (module launches with an `extra` buffer: not produced by this step)
           nsdp::set_error("graph_exec_create: kernel node %zu passes its arguments through `extra` (unsupported)", p);
-          return fail(g, "kernel node", hipErrorNotSupported);
+          return fail(g, nullptr, hipErrorNotSupported);
         }
         ++g->n_kernels;
         break;
       case hipGraphNodeTypeMemset:
         e = hipGraphMemsetNodeGetParams(h, &x.ms);
         if (e != hipSuccess) return fail(g, "hipGraphMemsetNodeGetParams", e);
+        // hipMemset2DAsync has byte semantics only: a 2-D memset of 2- / 4-byte elements (whose pattern bytes may differ)
+        // is replayed as the node it is, through a graph of its own
+        if (x.ms.height > 1 && x.ms.elementSize > 1) own_graph = true;
         break;
       case hipGraphNodeTypeMemcpy:
         // (a 1-D memcpy node answers with an empty 3-D description or an error: replay it through its own graph)
@@ -203,7 +207,7 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
       if (e != hipSuccess) {
         nsdp::set_error("graph_exec_create: node %zu (type %d) could not be isolated into a graph of its own: %s", p,
                         static_cast<int>(x.type), hipGetErrorString(e));
-        return fail(g, "one_node_exec", e);
+        return fail(g, nullptr, e);
       }
       ++g->n_sub;
     }

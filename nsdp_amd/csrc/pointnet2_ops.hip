@@ -240,19 +240,34 @@ inline CmPlan plan_cm(int B, int C, int N, int E) {
   return {ch, (E + e_per - 1) / e_per, e_per, static_cast<size_t>(ch) * N * 4};
 }
 
-template <typename K>
-void allow_big_lds(K kernel) {
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsTableMax);
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute belongs to the CURRENT device's function object and the
+// library serves several devices per process (on_device(...) on the Python side): once per (kernel, device), tracked in a
+// bitmask per kernel instance; the return code is the caller's to report.
+template <auto Kernel>
+bool allow_big_lds() {
+  static unsigned long long done = 0;      // bit d: set on device d (benign race: setting the attribute twice is harmless)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+  if (dev < 64 && ((done >> dev) & 1ull)) return true;
+  const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kLdsTableMax);
+  if (e != hipSuccess) {
+    nsdp::set_error("pointnet2_ops: opting a kernel in to %d bytes of LDS failed on device %d: %s", kLdsTableMax, dev,
+                    hipGetErrorString(e));
+    return false;
+  }
+  if (dev < 64) done |= 1ull << dev;
+  return true;
 }
 
 template <int CH>
-void launch_gather_cm_t(const CmPlan &pl, bool vec, const float *points, const int32_t *idx, int B, int C, int N, int E,
-                        float *out, hipStream_t st) {
+int launch_gather_cm_t(const CmPlan &pl, bool vec, const float *points, const int32_t *idx, int B, int C, int N, int E,
+                       float *out, hipStream_t st) {
   const dim3 grid((C + CH - 1) / CH, B, pl.zsplit);
-  static bool once = (allow_big_lds(&gather_cm_lds_kernel<CH, true>), allow_big_lds(&gather_cm_lds_kernel<CH, false>), true);
-  (void)once;
+  if (!(vec ? allow_big_lds<&gather_cm_lds_kernel<CH, true>>() : allow_big_lds<&gather_cm_lds_kernel<CH, false>>())) return NSDP_EINVAL;
   if (vec) hipLaunchKernelGGL((gather_cm_lds_kernel<CH, true>), grid, dim3(kBig), pl.lds, st, points, idx, C, N, E, pl.e_per_wg, out);
   else hipLaunchKernelGGL((gather_cm_lds_kernel<CH, false>), grid, dim3(kBig), pl.lds, st, points, idx, C, N, E, pl.e_per_wg, out);
+  return 0;
 }
 
 int launch_gather_cm(const float *points, const int32_t *idx, int B, int C, int N, int E, float *out, hipStream_t st) {
@@ -266,25 +281,24 @@ int launch_gather_cm(const float *points, const int32_t *idx, int B, int C, int 
   const bool vec = E % 4 == 0 && aligned16(idx) && aligned16(out);
   NSDP_TRACE("gather_cm_lds<%d>%s z=%d", pl.ch, vec ? "" : " ragged", pl.zsplit);
   switch (pl.ch) {
-    case 8: launch_gather_cm_t<8>(pl, vec, points, idx, B, C, N, E, out, st); break;
-    case 4: launch_gather_cm_t<4>(pl, vec, points, idx, B, C, N, E, out, st); break;
-    case 2: launch_gather_cm_t<2>(pl, vec, points, idx, B, C, N, E, out, st); break;
-    default: launch_gather_cm_t<1>(pl, vec, points, idx, B, C, N, E, out, st); break;
+    case 8: return launch_gather_cm_t<8>(pl, vec, points, idx, B, C, N, E, out, st);
+    case 4: return launch_gather_cm_t<4>(pl, vec, points, idx, B, C, N, E, out, st);
+    case 2: return launch_gather_cm_t<2>(pl, vec, points, idx, B, C, N, E, out, st);
+    default: return launch_gather_cm_t<1>(pl, vec, points, idx, B, C, N, E, out, st);
   }
-  return 0;
 }
 
 template <int CH>
-void launch_scatter_cm_t(const CmPlan &pl, bool vec, const float *grad_out, const int32_t *idx, int B, int C, int N, int E,
+int launch_scatter_cm_t(const CmPlan &pl, bool vec, const float *grad_out, const int32_t *idx, int B, int C, int N, int E,
                          float *grad_points, hipStream_t st) {
   const dim3 grid((C + CH - 1) / CH, B, pl.zsplit);
-  static bool once = (allow_big_lds(&scatter_cm_lds_kernel<CH, true>), allow_big_lds(&scatter_cm_lds_kernel<CH, false>), true);
-  (void)once;
+  if (!(vec ? allow_big_lds<&scatter_cm_lds_kernel<CH, true>>() : allow_big_lds<&scatter_cm_lds_kernel<CH, false>>())) return NSDP_EINVAL;
   const int combine = pl.zsplit > 1;
   if (vec)
     hipLaunchKernelGGL((scatter_cm_lds_kernel<CH, true>), grid, dim3(kBig), pl.lds, st, grad_out, idx, C, N, E, pl.e_per_wg, combine, grad_points);
   else
     hipLaunchKernelGGL((scatter_cm_lds_kernel<CH, false>), grid, dim3(kBig), pl.lds, st, grad_out, idx, C, N, E, pl.e_per_wg, combine, grad_points);
+  return 0;
 }
 
 int launch_scatter_cm(const float *grad_out, const int32_t *idx, int B, int C, int N, int E, float *grad_points,
@@ -302,10 +316,10 @@ int launch_scatter_cm(const float *grad_out, const int32_t *idx, int B, int C, i
   const bool vec = E % 4 == 0 && aligned16(idx) && aligned16(grad_out);
   NSDP_TRACE("scatter_cm_lds<%d>%s z=%d", pl.ch, vec ? "" : " ragged", pl.zsplit);
   switch (pl.ch) {
-    case 8: launch_scatter_cm_t<8>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
-    case 4: launch_scatter_cm_t<4>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
-    case 2: launch_scatter_cm_t<2>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
-    default: launch_scatter_cm_t<1>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st); break;
+    case 8: return launch_scatter_cm_t<8>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st);
+    case 4: return launch_scatter_cm_t<4>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st);
+    case 2: return launch_scatter_cm_t<2>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st);
+    default: return launch_scatter_cm_t<1>(pl, vec, grad_out, idx, B, C, N, E, grad_points, st);
   }
   return 0;
 }
@@ -646,8 +660,7 @@ int nsdp_three_interpolate(const float *points, const int32_t *idx, const float 
   NSDP_TRACE("three_interpolate_lds<%d> z=%d", pl.ch, pl.zsplit);
 #define NSDP_TI(CH)                                                                                                        \
   {                                                                                                                        \
-    static bool once = (allow_big_lds(&three_interpolate_lds_kernel<CH>), true);                                           \
-    (void)once;                                                                                                            \
+    if (!allow_big_lds<&three_interpolate_lds_kernel<CH>>()) return NSDP_EINVAL;                                        \
     hipLaunchKernelGGL((three_interpolate_lds_kernel<CH>), grid, dim3(kBig), pl.lds, st, points, idx, weight, c, m, n,      \
                        pl.e_per_wg, out);                                                                                  \
   }
@@ -682,8 +695,7 @@ int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const
     NSDP_TRACE("three_interpolate_grad_lds<%d> z=%d", pl.ch, pl.zsplit);
 #define NSDP_TIG(CH)                                                                                                       \
   {                                                                                                                        \
-    static bool once = (allow_big_lds(&three_interpolate_grad_lds_kernel<CH>), true);                                      \
-    (void)once;                                                                                                            \
+    if (!allow_big_lds<&three_interpolate_grad_lds_kernel<CH>>()) return NSDP_EINVAL;                                        \
     hipLaunchKernelGGL((three_interpolate_grad_lds_kernel<CH>), grid, dim3(kBig), pl.lds, st, grad_out, idx, weight, c, n,  \
                        m, pl.e_per_wg, combine, grad_points);                                                              \
   }
@@ -725,8 +737,7 @@ int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const i
   NSDP_TRACE("scatter_cm_lists<%d>", ch);
 #define NSDP_SCL(CH)                                                                                                       \
   {                                                                                                                        \
-    static bool once = (allow_big_lds(&scatter_cm_lists_kernel<CH>), true);                                                \
-    (void)once;                                                                                                            \
+    if (!allow_big_lds<&scatter_cm_lists_kernel<CH>>()) return NSDP_EINVAL;                                        \
     hipLaunchKernelGGL((scatter_cm_lists_kernel<CH>), grid, dim3(kBig), lds, st, grad_out, offsets, entries, C, N, E,       \
                        grad_points);                                                                                       \
   }

@@ -113,6 +113,9 @@ constexpr int tr_pitch_bytes(int cols) {
 __device__ __forceinline__ void gload4(f32x4 &dst, const float *uniform_base, unsigned byte_off) {
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform_base));
 }
+__device__ __forceinline__ void gload_i32(int &dst, const float *uniform_base, unsigned byte_off) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(uniform_base));
+}
 template <int OFF>
 __device__ __forceinline__ void tr_read(unsigned long long &dst, unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
@@ -120,6 +123,9 @@ __device__ __forceinline__ void tr_read(unsigned long long &dst, unsigned addr) 
 struct Frag3 {
   unsigned long long h[2], m[2], l[2];
 };
+__device__ __forceinline__ void frag_wait_h(Frag3 &f) {      // (one-hot operand: only the h plane exists)
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.h[0]), "+v"(f.h[1]));
+}
 __device__ __forceinline__ void frag_wait(Frag3 &f) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.h[0]), "+v"(f.h[1]), "+v"(f.m[0]), "+v"(f.m[1]), "+v"(f.l[0]), "+v"(f.l[1]));
 }
@@ -128,23 +134,30 @@ __device__ __forceinline__ u32x4 frag_vec(const unsigned long long (&q)[2]) {
                static_cast<unsigned>(q[1] >> 32)};
 }
 
-template <int NTA, int KTB, bool MASK, bool TAIL>
+// ONEHOT ("scatter as a GEMM", nsdp_scatter_rows_onehot_f32): the dY operand is the one-hot matrix of a row -> table-row
+// index list (p.dY points at int32 indices), generated by the producer straight into the h plane image -- 1.0 is exact in
+// bf16, so table[a][c] = sum_{r: idx[r] = a} X[r][c] needs the three products 1 x {h, m, l} only and comes out in a fixed
+// summation order (no atomics).  grid.y = shapes, each with its own p.M rows, index list and table.
+template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
+  static_assert(!ONEHOT || (!MASK && NTA == 8), "one-hot operand: 128 table rows, no mask");
   constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
   constexpr int kColsA = NTA * 16, kColsB = KTB * 16, kC4A = NTA * 4, kC4B = KTB * 4;
   constexpr int kPitchA = tr_pitch_bytes(kColsA), kPitchB = tr_pitch_bytes(kColsB);
   constexpr int kPlaneA = 32 * kPitchA, kPlaneB = 32 * kPitchB;
   constexpr unsigned kBufBytes = 3 * (kPlaneA + kPlaneB);            // [A h, m, l][B h, m, l], row-major images
-  constexpr int RA = (32 * kC4A + 255) / 256, RB = (32 * kC4B + 255) / 256;   // float4 slots per lane
+  constexpr int RA = ONEHOT ? 1 : (32 * kC4A + 255) / 256, RB = (32 * kC4B + 255) / 256;   // float4 slots per lane
   __shared__ __attribute__((aligned(16))) unsigned char planes[2 * kBufBytes];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 1, wb = wave & 1;
   const int i = lane & 15, g = lane >> 4;
   const int N = p.N, K = p.K;
-  const int k_off = static_cast<int>(blockIdx.y) * kColsB;
+  const int k_off = ONEHOT ? 0 : static_cast<int>(blockIdx.y) * kColsB;
   const int Kpart = K - k_off < kColsB ? K - k_off : kColsB;
-  const float *const dYp = sgpr_ptr(p.dY), *const Xp = sgpr_ptr(p.X), *const Mp = sgpr_ptr(p.mask);
+  // (one-hot: blockIdx.y is the shape; its index list and rows start blockIdx.y * M entries / rows in)
+  const long long shape_rows = ONEHOT ? static_cast<long long>(blockIdx.y) * p.M : 0;
+  const float *const dYp = sgpr_ptr(p.dY + shape_rows), *const Xp = sgpr_ptr(p.X + shape_rows * K), *const Mp = sgpr_ptr(p.mask);
   const long long Mrows = p.M;
   const long long mb0 = static_cast<long long>(blockIdx.x) * p.blocks_per_wg;
   const long long mb_all = (p.M + 31) >> 5;
@@ -156,16 +169,22 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   unsigned offA[RA], offB[RB];       // byte offset of the slot's float4 in dY / X for the block loaded next
   unsigned ldsA[RA], ldsB[RB];       // byte offset inside a plane image
   int rowA[RA], rowB[RB];            // image row (TAIL)
-  const unsigned strideA = static_cast<unsigned>(N) * 4u, strideB = static_cast<unsigned>(K) * 4u;
+  const unsigned strideA = ONEHOT ? 4u : static_cast<unsigned>(N) * 4u, strideB = static_cast<unsigned>(K) * 4u;
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
-    int s = tid + 256 * r;
-    s = s < 32 * kC4A ? s : s - 256;
-    const int row = s / kC4A, c4 = s % kC4A;
-    const int col = 4 * c4 + 4 <= N ? 4 * c4 : N - 4;      // padding columns re-read the last real ones (never reduced)
-    rowA[r] = row;
-    offA[r] = static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
-    ldsA[r] = static_cast<unsigned>(row * kPitchA + c4 * 8);
+    if constexpr (ONEHOT) {      // thread = (image row tid / 8, 16-column segment tid % 8); the row's index is one dword
+      rowA[r] = tid >> 3;
+      offA[r] = static_cast<unsigned>((mb0 * 32 + (tid >> 3)) * 4);
+      ldsA[r] = static_cast<unsigned>((tid >> 3) * kPitchA + (tid & 7) * 32);
+    } else {
+      int s = tid + 256 * r;
+      s = s < 32 * kC4A ? s : s - 256;
+      const int row = s / kC4A, c4 = s % kC4A;
+      const int col = 4 * c4 + 4 <= N ? 4 * c4 : N - 4;      // padding columns re-read the last real ones (never reduced)
+      rowA[r] = row;
+      offA[r] = static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
+      ldsA[r] = static_cast<unsigned>(row * kPitchA + c4 * 8);
+    }
   }
 #pragma unroll
   for (int r = 0; r < RB; ++r) {
@@ -180,6 +199,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&planes[0])));
 
   f32x4 rawA[RA], rawM[MASK ? RA : 1], rawB[RB];
+  int rawI = -1;                     // (one-hot) table row of image row tid / 8 of the block loaded next
   f32x4 dbsum[RA];
 #pragma unroll
   for (int r = 0; r < RA; ++r) dbsum[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -190,8 +210,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
       const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
       if (rowA[r] > last_row) off -= static_cast<unsigned>(rowA[r] - last_row) * strideA;
     }
-    gload4(rawA[r], dYp, off);
-    if (MASK) gload4(rawM[r], Mp, off);
+    if constexpr (ONEHOT) {
+      gload_i32(rawI, dYp, off);
+    } else {
+      gload4(rawA[r], dYp, off);
+      if (MASK) gload4(rawM[r], Mp, off);
+    }
   };
   auto issue_b = [&](int r, long long mb) {
     unsigned off = offB[r];
@@ -214,8 +238,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     for (int r = 0; r < RB; ++r) offB[r] += 32u * strideB;
   };
   auto gwait = [&]() {
+    if constexpr (ONEHOT) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawI));
 #pragma unroll
-    for (int r = 0; r < RA; ++r) {
+    for (int r = 0; r < (ONEHOT ? 0 : RA); ++r) {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA[r]));
       if (MASK) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawM[r]));
     }
@@ -232,6 +257,20 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     *reinterpret_cast<unsigned long long *>(dst + 2 * plane_bytes) = (static_cast<unsigned long long>(l1) << 32) | l0;
   };
   auto produce_a = [&](int r, unsigned buf_off, int rows_left, bool real) {
+    if constexpr (ONEHOT) {
+      // 16 columns of one image row: a single bf16 1.0 where the row's table index falls into them (rows past M: none)
+      const int rel = ((TAIL && rowA[r] >= rows_left) ? -1 : rawI) - 16 * (tid & 7);
+      u32x4 lo, hi;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        lo[w] = rel == 2 * w ? 0x00003f80u : (rel == 2 * w + 1 ? 0x3f800000u : 0u);
+        hi[w] = rel == 8 + 2 * w ? 0x00003f80u : (rel == 9 + 2 * w ? 0x3f800000u : 0u);
+      }
+      unsigned char *dst = &planes[0] + buf_off + ldsA[r];
+      *reinterpret_cast<u32x4 *>(dst) = lo;
+      *reinterpret_cast<u32x4 *>(dst + 16) = hi;
+      return;
+    }
     f32x4 v = rawA[r];
     if (MASK) {
 #pragma unroll
@@ -284,8 +323,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   auto read_a = [&](auto T, Frag3 &f, unsigned base) {
     constexpr int t = decltype(T)::value;
     tr_read<t * 32>(f.h[0], base); tr_read<t * 32 + 16 * kPitchA>(f.h[1], base);
-    tr_read<t * 32 + kPlaneA>(f.m[0], base); tr_read<t * 32 + kPlaneA + 16 * kPitchA>(f.m[1], base);
-    tr_read<t * 32 + 2 * kPlaneA>(f.l[0], base); tr_read<t * 32 + 2 * kPlaneA + 16 * kPitchA>(f.l[1], base);
+    if constexpr (!ONEHOT) {
+      tr_read<t * 32 + kPlaneA>(f.m[0], base); tr_read<t * 32 + kPlaneA + 16 * kPitchA>(f.m[1], base);
+      tr_read<t * 32 + 2 * kPlaneA>(f.l[0], base); tr_read<t * 32 + 2 * kPlaneA + 16 * kPitchA>(f.l[1], base);
+    }
   };
   auto read_b = [&](auto T, Frag3 &f, unsigned base) {
     constexpr int t = decltype(T)::value;
@@ -318,8 +359,13 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
       u32x4 ah[na], am[na], al[na];
       static_for<0, na>([&](auto I) {
         constexpr int a = decltype(I)::value;
-        frag_wait(fa[a]);
-        ah[a] = frag_vec(fa[a].h); am[a] = frag_vec(fa[a].m); al[a] = frag_vec(fa[a].l);
+        if constexpr (ONEHOT) {
+          frag_wait_h(fa[a]);
+          ah[a] = frag_vec(fa[a].h); am[a] = ah[a]; al[a] = ah[a];      // (m, l: unused)
+        } else {
+          frag_wait(fa[a]);
+          ah[a] = frag_vec(fa[a].h); am[a] = frag_vec(fa[a].m); al[a] = frag_vec(fa[a].l);
+        }
       });
       frag_wait(fb);
       u32x4 bh = frag_vec(fb.h), bm = frag_vec(fb.m), bl = frag_vec(fb.l);
@@ -334,21 +380,25 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
           if constexpr (slot < RA) produce_a(slot, nbuf, rl_next, ib + 1 < nblk);
           else if constexpr (slot < kSlots) produce_b(slot - RA, nbuf);
         });
+        if constexpr (!ONEHOT) {
 #pragma unroll
-        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(al[a], bh, acc[a0 + a][b]);
+          for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(al[a], bh, acc[a0 + a][b]);
+        }
 #pragma unroll
         for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bl, acc[a0 + a][b]);
+        if constexpr (!ONEHOT) {
 #pragma unroll
-        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bm, acc[a0 + a][b]);
+          for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bm, acc[a0 + a][b]);
 #pragma unroll
-        for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bh, acc[a0 + a][b]);
+          for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(am[a], bh, acc[a0 + a][b]);
+        }
 #pragma unroll
         for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bm, acc[a0 + a][b]);
 #pragma unroll
         for (int a = 0; a < na; ++a) acc[a0 + a][b] = mfma_bf16(ah[a], bh, acc[a0 + a][b]);
         if constexpr (st * kPerStep < kSlots) {
 #pragma unroll
-          for (int q = 0; q < 6 * na; ++q) {
+          for (int q = 0; q < (ONEHOT ? 3 : 6) * na; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 2 * kPerStep, 0);
           }
@@ -492,6 +542,43 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
   }
 }
 
+// table[b][n][k] = sum over the S partials of shape b (fragment order, see wgrad_bf16x3_reduce_kernel), fixed order
+__global__ __launch_bounds__(256) void onehot_tables_reduce_kernel(const float *__restrict__ ws, int S, int NTA, int KTB, int N,
+                                                                   int K, float *__restrict__ table) {
+  const long long e = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+  if (e >= static_cast<long long>(N) * K) return;
+  const int n = static_cast<int>(e / K), k = static_cast<int>(e % K);
+  const int nl = n & 15, kl = k & 15;
+  const size_t stride = static_cast<size_t>(NTA) * KTB * 256 + NTA * 16;
+  const float *w = ws + static_cast<size_t>(blockIdx.y) * S * stride +
+                   (static_cast<size_t>(n >> 4) * KTB + (k >> 4)) * 256 + (16 * (nl >> 2) + kl) * 4 + (nl & 3);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    a0 += w[(s + 0) * stride]; a1 += w[(s + 1) * stride]; a2 += w[(s + 2) * stride]; a3 += w[(s + 3) * stride];
+  }
+  for (; s < S; ++s) a0 += w[s * stride];
+  table[static_cast<long long>(blockIdx.y) * N * K + e] = (a0 + a1) + (a2 + a3);
+}
+
+struct OneHotPlan {
+  int ktb, grid;
+  long long blocks_per_wg;
+  size_t ws_floats;
+};
+
+OneHotPlan plan_onehot(int B, long long rows, int d) {
+  OneHotPlan pl;
+  pl.ktb = d <= 128 ? 8 : 13;
+  const long long mb_all = (rows + 31) / 32;
+  long long grid = (nsdp::num_cus() + B - 1) / B;      // workgroups per shape: one per CU in total (126 KiB of LDS each)
+  if (grid > mb_all / 4) grid = mb_all / 4 > 0 ? mb_all / 4 : 1;
+  pl.blocks_per_wg = (mb_all + grid - 1) / grid;
+  pl.grid = static_cast<int>((mb_all + pl.blocks_per_wg - 1) / pl.blocks_per_wg);
+  pl.ws_floats = static_cast<size_t>(B) * pl.grid * (static_cast<size_t>(8) * pl.ktb * 256 + 8 * 16);
+  return pl;
+}
+
 }  // namespace
 
 namespace nsdp {
@@ -535,6 +622,49 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
   hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
                      workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
   return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
+}
+
+size_t nsdp_scatter_rows_onehot_f32_workspace_bytes(int B, long long rows, int N, int d) {
+  if (B <= 0 || rows <= 0) return 0;
+  (void)N;
+  return plan_onehot(B, rows, d).ws_floats * sizeof(float);
+}
+
+int nsdp_scatter_rows_onehot_f32(const float *src, const int32_t *idx, int B, long long rows, int N, int d, float *table,
+                                 float *workspace, size_t workspace_bytes, void *stream) {
+  if (B <= 0 || N <= 0 || d <= 0) return 0;
+  NSDP_REQUIRE(table, "scatter_rows_onehot_f32: null table");
+  hipStream_t st = nsdp::as_stream(stream);
+  if (rows <= 0) {
+    NSDP_HIP_TRY(hipMemsetAsync(table, 0, sizeof(float) * static_cast<size_t>(B) * N * d, st));
+    return 0;
+  }
+  NSDP_REQUIRE(src && idx && workspace, "scatter_rows_onehot_f32: null pointer");
+  NSDP_REQUIRE(N <= 128 && d % 4 == 0 && d > 16 && d <= 208,
+               "scatter_rows_onehot_f32: need N <= 128 table rows and 16 < d <= 208, d %% 4 == 0 (N=%d d=%d)", N, d);
+  NSDP_REQUIRE(B <= 65535 && static_cast<double>(rows) * d * 4.0 < 4.0e9, "scatter_rows_onehot_f32: shape too large");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_scatter_rows_onehot_f32_workspace_bytes(B, rows, N, d),
+               "scatter_rows_onehot_f32: workspace too small");
+  const OneHotPlan pl = plan_onehot(B, rows, d);
+  WgX3Params p{reinterpret_cast<const float *>(idx), src, nullptr, 0, workspace, rows, 128, d, pl.blocks_per_wg, 0, 1};
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * rows * (d + 1) + static_cast<double>(B) * N * d));
+  const dim3 g(pl.grid, B);
+  const bool tail = (rows & 31) != 0;
+  NSDP_TRACE("scatter_rows_onehot_f32<8,%d,%s>", pl.ktb, tail ? "tail" : "notail");
+  if (pl.ktb == 8) {
+    if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<8, 8, false, true, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<8, 8, false, false, true>), g, dim3(256), 0, st, p);
+  } else {
+    if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<8, 13, false, true, true>), g, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<8, 13, false, false, true>), g, dim3(256), 0, st, p);
+  }
+  const int rc = nsdp::launch_status("wgrad_bf16x3_rows_kernel<onehot>");
+  if (rc) return rc;
+  const long long ne = static_cast<long long>(N) * d;
+  hipLaunchKernelGGL(onehot_tables_reduce_kernel, dim3(static_cast<unsigned>((ne + 255) / 256), B), dim3(256), 0, st, workspace,
+                     pl.grid, 8, pl.ktb, N, d, table);
+  return nsdp::launch_status("onehot_tables_reduce_kernel");
 }
 
 #ifdef WG3_TIMING

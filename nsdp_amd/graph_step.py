@@ -78,6 +78,12 @@ class GraphedStep:
                 self.fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # Every host-side cache that mirrors the WEIGHTS (the fragment-major packs of hip_linear / hip_linear_bf16, the
+        # fused decoder's pack) is declared stale here, so that their rebuild becomes a node at the head of the captured
+        # step: a replay runs no Python -- a pack that happened to be valid at capture time (an eval forward just before)
+        # would otherwise be frozen into every replay.
+        from . import hip_linear
+        hip_linear.invalidate_weight_packs()
         graph = torch.cuda.CUDAGraph(keep_graph=True)
         # thread_local: other threads of the process (the RCCL watchdog of a data-parallel job polls events) may keep
         # making HIP calls while this thread captures
@@ -99,6 +105,12 @@ class GraphedStep:
         if self._graph is None:
             raise RuntimeError("capture() first")
         check(lib().nsdp_graph_exec_launch(self._handle, stream_ptr()), "nsdp_graph_exec_launch")
+        # A replay runs no Python: the optimizer's post-step hook (which advances the weights epoch in the eager loop) does
+        # not fire, while the packs -- rebuilt at the HEAD of the replayed step -- are one optimizer step older than the
+        # parameters afterwards.  Declare them stale, so that the next EAGER forward (validate_on_batch, an odd-shape batch
+        # of GraphedTrainOnBatch) repacks; the next replay repacks anyway.  One integer increment.
+        from . import hip_linear
+        hip_linear.invalidate_weight_packs()
         return self._out
 
     def close(self):
@@ -120,21 +132,38 @@ class GraphedTrainOnBatch:
     eagerly, the second one captures the step (its ``tensor_step`` form: the same statements without ``loss.item()``) over
     static copies of the batch, and from then on every call is a copy of the batch into the static tensors plus one replay
     -- the sequence of optimizer steps is exactly the eager loop's.  A batch of other shapes (the last, shorter one of an epoch) runs eagerly.  Returns the loss as a float,
-    like the reference -- that read-back is the one host sync per step the reference has as well."""
+    like the reference -- that read-back is the one host sync per step the reference has as well.
 
-    def __init__(self, train_on_batch, max_streams: int | None = None):
+    ``reducer`` (nsdp_amd.parallel.GradAllReducer): this process is one rank of a data-parallel job.  A collective cannot be
+    captured, so the step becomes TWO graphs around the eager gradient exchange -- [zero the flat gradient, forward, loss,
+    backward] and [optimizer.step] -- with the RCCL all-reduce enqueued between them on the same stream; eager steps (the
+    first one, odd shapes) run the exchange as a pre-hook of ``optimizer.step``.  The returned loss is this rank's."""
+
+    def __init__(self, train_on_batch, max_streams: int | None = None, reducer=None):
         if not hasattr(train_on_batch, "tensor_step"):
             raise TypeError("train_on_batch has no `tensor_step` form (the step without its loss.item())")
+        if reducer is not None and not hasattr(train_on_batch, "loss_fn"):
+            raise TypeError("train_on_batch has no `loss_fn` form (forward + loss), needed to split the step around the exchange")
         self.eager = train_on_batch
         self.max_streams = max_streams
+        self.reducer = reducer
+        self.exchanges_gradients = reducer is not None      # (nsdp_amd.train.fit: do not wrap me again)
         self._shapes = None
         self._static = None
         self._step = None
+        self._update = None
         self.replays = self.eager_calls = 0
 
     @staticmethod
     def _sig(data_dict):
         return tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in data_dict.items() if torch.is_tensor(v)))
+
+    def _eager_step(self, model, optimizer, data_dict, config):
+        self.eager_calls += 1
+        if self.reducer is None:
+            return float(self.eager.tensor_step(model, optimizer, data_dict, config))
+        from .parallel import data_parallel_step
+        return float(data_parallel_step(self.eager.tensor_step, self.reducer)(model, optimizer, data_dict, config))
 
     def __call__(self, model, optimizer, data_dict, config):
         sig = self._sig(data_dict)
@@ -144,17 +173,30 @@ class GraphedTrainOnBatch:
             # step) -- and an extra warm-up step would change what the loop computes.
             capturable_adam(optimizer)
             self._shapes = sig
-            self.eager_calls += 1
-            return float(self.eager.tensor_step(model, optimizer, data_dict, config))
+            return self._eager_step(model, optimizer, data_dict, config)
         if sig != self._shapes:
-            self.eager_calls += 1
-            return self.eager(model, optimizer, data_dict, config)
+            return self._eager_step(model, optimizer, data_dict, config)
         if self._step is None:
             self._static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data_dict.items()}
-            fn = lambda: self.eager.tensor_step(model, optimizer, self._static, config)      # noqa: E731
-            self._step = GraphedStep(fn, self.max_streams).capture(warmup=0)      # (a capture executes nothing)
+            if self.reducer is None:
+                fn = lambda: self.eager.tensor_step(model, optimizer, self._static, config)      # noqa: E731
+                self._step = GraphedStep(fn, self.max_streams).capture(warmup=0)      # (a capture executes nothing)
+            else:
+                red = self.reducer
+
+                def fwd_bwd():
+                    red.zero_grad()
+                    loss = self.eager.loss_fn(model, self._static, config)
+                    loss.backward()
+                    return loss
+                self._step = GraphedStep(fwd_bwd, self.max_streams).capture(warmup=0)
+                self._update = GraphedStep(lambda: optimizer.step(), self.max_streams).capture(warmup=0)
         for k, v in data_dict.items():
             if torch.is_tensor(v):
                 self._static[k].copy_(v, non_blocking=True)
         self.replays += 1
-        return float(self._step())
+        loss = self._step()
+        if self.reducer is not None:
+            self.reducer.all_reduce_mean()
+            self._update()
+        return float(loss)

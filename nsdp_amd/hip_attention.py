@@ -33,11 +33,20 @@ def _fn(name, dtype):
     return getattr(lib(), name + ("_bf16" if dtype is BF16 else ""))
 
 
-ONEHOT_SCATTER = os.environ.get("NSDP_ONEHOT_SCATTER", "1") != "0"   # bf16 storage, decoder (<= 128 table rows): scatter as a GEMM
+# Decoder (<= 128 table rows per shape, tens of thousands of rows to scatter): the anchor-table gradients as a GEMM against
+# the one-hot index matrix -- no atomics, a fixed summation order (the train step is bit-reproducible with it), and faster
+# than the register-table / LDS-table atomic kernels.  bf16 storage: nsdp_scatter_rows_onehot_bf16; fp32: the three bf16
+# planes of the source times the (exact) one-hot operand, nsdp_scatter_rows_onehot_f32.  "0": the atomic kernels (A/B knob).
+ONEHOT_SCATTER = os.environ.get("NSDP_ONEHOT_SCATTER", "1") != "0"
+ONEHOT_SCATTER_F32 = os.environ.get("NSDP_ONEHOT_SCATTER_F32", "1") != "0"
 
 
 def _onehot_ok(dt, qb_or_decoder, N, d):
-    return ONEHOT_SCATTER and dt is BF16 and qb_or_decoder and N <= 128 and N % 2 == 0 and d % 8 == 0 and d <= 256
+    if not qb_or_decoder:
+        return False
+    if dt is BF16:
+        return ONEHOT_SCATTER and N <= 128 and N % 2 == 0 and d % 8 == 0 and d <= 256
+    return ONEHOT_SCATTER_F32 and dt is torch.float32 and N <= 128 and d % 4 == 0 and 16 < d <= 208
 
 
 # Encoder levels whose source table fits neither LDS nor registers (2048 / 500 source points): scatter through inverse
@@ -58,11 +67,19 @@ def _use_inverse(dt, qb, n, N, d):
 
 
 def inverse_lists(idx, N):
-    """(offsets [B,N+1], entries [B,E]) of idx [B,n,k] (nsdp_knn_invert), cached on the index tensor."""
-    cache = idx.__dict__.setdefault("_nsdp_inverse", {}) if hasattr(idx, "__dict__") else {}
-    hit = cache.get(N)
+    """(offsets [B,N+1], entries [B,E]) of idx [B,n,k] (nsdp_knn_invert), cached on the index tensor.
+    The cache is keyed by the CONTENTS' identity as far as PyTorch exposes it -- (N, storage pointer, version counter): an
+    index buffer that is refilled in place (`copy_` into a static input of a captured step) gets new lists.  While a stream
+    capture is running the cache is neither read nor written: the list build must be a node of the graph (a replay sees
+    new index contents at the same address and version), and lists built for a capture must not outlive it."""
+    capturing = idx.is_cuda and torch.cuda.is_current_stream_capturing()
+    cache = idx.__dict__.setdefault("_nsdp_inverse", {}) if (hasattr(idx, "__dict__") and not capturing) else {}
+    key = (N, idx.data_ptr(), idx._version)
+    hit = cache.get(key)
     if hit is not None:
         return hit
+    for stale in [k for k in cache if k[1:] != key[1:]]:      # (lists of older contents of this buffer)
+        del cache[stale]
     B = idx.shape[0]
     E = idx.numel() // B
     offsets = torch.empty((B, N + 1), dtype=torch.int32, device=idx.device)
@@ -70,7 +87,7 @@ def inverse_lists(idx, N):
     with on_device(idx):
         check(lib().nsdp_knn_invert(iptr(idx, "idx"), _ci(B), _ci(E), _ci(N), iptr(offsets), iptr(entries), stream_ptr()),
               "nsdp_knn_invert")
-    cache[N] = (offsets, entries)
+    cache[key] = (offsets, entries)
     return offsets, entries
 
 
@@ -90,9 +107,19 @@ def segment_sum(src, idx, N, scale=1.0, inv=None):
 
 
 def onehot_scatter(src, idx, N):
-    """table [B,N,d] fp32 = sum of the rows of src [B,rows,d] (bf16) by idx [B,rows] (nsdp_scatter_rows_onehot_bf16)."""
+    """table [B,N,d] fp32 = sum of the rows of src [B,rows,d] (bf16 / fp32) by idx [B,rows] (nsdp_scatter_rows_onehot_*)."""
     B, rows, d = src.shape
     L = lib()
+    if src.dtype is torch.float32:
+        L.nsdp_scatter_rows_onehot_f32_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.nsdp_scatter_rows_onehot_f32_workspace_bytes(_ci(B), ctypes.c_longlong(rows), _ci(N), _ci(d)))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=src.device)
+        table = torch.empty((B, N, d), dtype=torch.float32, device=src.device)
+        with on_device(src):
+            check(L.nsdp_scatter_rows_onehot_f32(fptr(src, "src"), iptr(idx, "idx"), _ci(B), ctypes.c_longlong(rows), _ci(N),
+                                                 _ci(d), fptr(table), fptr(ws), ctypes.c_size_t(nbytes), stream_ptr()),
+                  "nsdp_scatter_rows_onehot_f32")
+        return table
     L.nsdp_scatter_rows_onehot_bf16_workspace_bytes.restype = ctypes.c_size_t
     nbytes = int(L.nsdp_scatter_rows_onehot_bf16_workspace_bytes(_ci(B), ctypes.c_longlong(rows), _ci(N), _ci(d)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=src.device)
@@ -243,11 +270,24 @@ class _AttnPost(torch.autograd.Function):
         dvf = torch.empty((B, N, d), dtype=torch.float32, device=dev) if (vf is not None and not onehot and not inverse) else None
         da_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
         dv_g = torch.empty((B, d), dtype=torch.float32, device=dev) if a_g is not None else None
-        with on_device(dy):
-            check(_fn("nsdp_attn_post_bwd", dt)(_p(dy, dt, "dy"), _p(a, dt), _p(vf, dt), _p(pos, dt), iptr(idx), _p(a_g, dt),
-                                                _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B), _ci(n), _ci(N),
-                                                _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(dvf), optptr(da_g),
-                                                optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
+        if onehot:
+            # pure stream, no atomics at all (the global-token sums go through per-workgroup partials in a fixed order)
+            L = lib()
+            L.nsdp_attn_post_bwd_det_workspace_bytes.restype = ctypes.c_size_t
+            nbytes = int(L.nsdp_attn_post_bwd_det_workspace_bytes(_ci(B), _ci(n), _ci(k), _ci(d))) if a_g is not None else 0
+            ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+            with on_device(dy):
+                check(_fn("nsdp_attn_post_bwd_det", dt)(_p(dy, dt, "dy"), _p(a, dt), _p(vf, dt), _p(pos, dt), iptr(idx),
+                                                        _p(a_g, dt), _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B),
+                                                        _ci(n), _ci(N), _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(da_g),
+                                                        optptr(dv_g), fptr(ws), ctypes.c_size_t(nbytes), stream_ptr()),
+                      "nsdp_attn_post_bwd_det")
+        else:
+            with on_device(dy):
+                check(_fn("nsdp_attn_post_bwd", dt)(_p(dy, dt, "dy"), _p(a, dt), _p(vf, dt), _p(pos, dt), iptr(idx),
+                                                    _p(a_g, dt), _p(v_g, dt), _p(y, dt), _p(residual, dt), fptr(lse), _ci(B),
+                                                    _ci(n), _ci(N), _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(dvf),
+                                                    optptr(da_g), optptr(dv_g), stream_ptr()), "nsdp_attn_post_bwd")
         if onehot:     # the kernel only streamed; dvf = scatter(d(pos)) as a GEMM against the one-hot index matrix
             dvf = onehot_scatter(dpos.reshape(B, n * k, d), idx.reshape(B, n * k), N)
         elif inverse:  # ... or as a gather-reduce over the inverse neighbour lists

@@ -8,6 +8,9 @@ from .. import ops
 from ... import hip_decoder, hip_linear, precision
 from .blocks import CrossTransformerBlock, ResnetBlockFC
 
+# bf16 storage: the decoder's residual trunk in fp32 storage (NSDP_BF16_TRUNK=f32), see forward()
+TRUNK_F32 = __import__("os").environ.get("NSDP_BF16_TRUNK", "bf16") == "f32"
+
 
 class CrossTransformerDecoder(nn.Module):
     """xyz_q [B,NQ,3] + encoding -> [B,NQ,out_dim]
@@ -29,6 +32,16 @@ class CrossTransformerDecoder(nn.Module):
             # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
             return hip_decoder.decoder_forward(self, xyz_q, encoding)
         lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
+        if precision.is_bf16() and TRUNK_F32:
+            # bf16 storage keeps the [B, NQ, 7, 200] tensors of the attention block in bf16 -- 7 x the rows and 1.6 x the width
+            # of the trunk -- while the residual stream `net` (128 wide, one row per query: the tensor that accumulates six
+            # additions and becomes the output POSITION) stays fp32: a bf16 `net` rounds a coordinate-sized value to 8 bits
+            # six times (tools/bf16_bisect.py)
+            with precision.storage(torch.float32):
+                return self._trunk(lat.float())
+        return self._trunk(lat)
+
+    def _trunk(self, lat):
         # the latent code feeds n_blocks + 1 layers: its gradient is summed inside their dX GEMMs
         fan = hip_linear.InputGradSum() if (torch.is_grad_enabled() and lat.requires_grad) else None
         net = ops.linear(lat, self.init_enc, grad_sum=fan)

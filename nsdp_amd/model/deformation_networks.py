@@ -33,12 +33,17 @@ class Deformation_Networks(nn.Module):
         return self.decoder(points, encoding)
 
 
+def _loss_with_cano(model, data_dict, config):
+    """forward + l2 loss of train_on_batch_with_cano (reference :66-72), as a tensor."""
+    pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
+    return compute_l2_error(pred, data_dict["space_samples_tgt"])
+
+
 def _train_step_with_cano(model, optimizer, data_dict, config):
     """The step of train_on_batch_with_cano up to (not including) the host read-back of the loss: everything that is
     enqueued on the GPU.  This is what nsdp_amd.graph_step captures and replays."""
     optimizer.zero_grad()
-    pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
-    loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
+    loss = _loss_with_cano(model, data_dict, config)
     loss.backward()
     optimizer.step()
     return loss
@@ -50,6 +55,7 @@ def train_on_batch_with_cano(model, optimizer, data_dict, config):
 
 
 train_on_batch_with_cano.tensor_step = _train_step_with_cano
+train_on_batch_with_cano.loss_fn = _loss_with_cano      # (data-parallel replay: two graphs around the gradient exchange)
 
 
 @torch.no_grad()

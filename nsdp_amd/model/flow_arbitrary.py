@@ -28,12 +28,17 @@ def _split(data_dict):
     return s[:, :, 0:3], s[:, :, 3:6], s[:, :, 6:7]
 
 
+def _loss_with_arbitrary(model, data_dict, config):
+    """forward + l2 loss of train_on_batch_with_arbitrary (reference :33-43), as a tensor."""
+    src, tgt, mask = _split(data_dict)
+    pred = model(data_dict["space_samples_src"], src, tgt, mask)
+    return compute_l2_error(pred, data_dict["space_samples_tgt"])
+
+
 def _train_step_with_arbitrary(model, optimizer, data_dict, config):
     """train_on_batch_with_arbitrary without the host read-back of the loss (what nsdp_amd.graph_step captures)."""
     optimizer.zero_grad()
-    src, tgt, mask = _split(data_dict)
-    pred = model(data_dict["space_samples_src"], src, tgt, mask)
-    loss = compute_l2_error(pred, data_dict["space_samples_tgt"])
+    loss = _loss_with_arbitrary(model, data_dict, config)
     loss.backward()
     optimizer.step()
     return loss
@@ -45,6 +50,7 @@ def train_on_batch_with_arbitrary(model, optimizer, data_dict, config):
 
 
 train_on_batch_with_arbitrary.tensor_step = _train_step_with_arbitrary
+train_on_batch_with_arbitrary.loss_fn = _loss_with_arbitrary
 
 
 @torch.no_grad()

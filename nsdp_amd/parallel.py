@@ -101,3 +101,87 @@ def data_parallel_step(train_on_batch, reducer: GradAllReducer):
         finally:
             handle.remove()
     return step
+
+
+class DataParallel:
+    """The data-parallel side of the train harness (nsdp_amd.train.fit), one instance per rank.  Policy, stated once:
+
+    * shapes are sharded by BATCH: of every ``world`` consecutive batches of a loader, rank r takes the r-th (the global
+      batch is the reference's batch x world); a trailing group of fewer than ``world`` batches is dropped, so every rank
+      takes the same number of steps (the gradient exchange is a collective);
+    * one exchange per step: the mean of the flat fp32 gradient (GradAllReducer), then the identical Adam update on every
+      rank -- weights stay bit-equal across ranks (``in_sync``);
+    * BatchNorm: batch statistics are per rank (the reference has no SyncBN).  The running buffers are therefore per rank
+      too; rank 0's are THE model's (as with torch DDP's ``broadcast_buffers``): they are broadcast to every rank before a
+      validation pass and before a checkpoint, so every rank evaluates -- and rank 0 saves -- the same model;
+    * files are written by rank 0 only; every rank reads them at resume (same node), and the initial weights are broadcast
+      from rank 0 on top, so the ranks start identical whatever they loaded or initialised."""
+
+    def __init__(self, model: torch.nn.Module, rank: int, world_size: int, process_group=None, always_exchange: bool = False):
+        self.rank, self.world_size, self.group = int(rank), int(world_size), process_group
+        self.reducer = GradAllReducer(model, world_size, process_group, always_exchange=always_exchange)
+
+    @property
+    def is_main(self) -> bool:
+        return self.rank == 0
+
+    def _active(self) -> bool:
+        return self.world_size > 1 and dist.is_available() and dist.is_initialized()
+
+    def _broadcast(self, tensors):
+        """rank 0's values into every rank's tensors, coalesced per dtype (one collective per dtype instead of ~400)."""
+        if not self._active():
+            return
+        by_dtype = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        with torch.no_grad():
+            for ts in by_dtype.values():
+                flat = torch.cat([t.detach().reshape(-1) for t in ts])
+                dist.broadcast(flat, src=0, group=self.group)
+                off = 0
+                for t in ts:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    def broadcast_model(self, model: torch.nn.Module):
+        """Parameters AND buffers from rank 0 (start of training / after a resume)."""
+        self._broadcast(list(model.parameters()) + list(model.buffers()))
+        self._weights_rewritten()
+
+    def broadcast_buffers(self, model: torch.nn.Module):
+        """BatchNorm running statistics and counters from rank 0 (before validation / a checkpoint)."""
+        self._broadcast(list(model.buffers()))
+
+    @staticmethod
+    def _weights_rewritten():
+        from . import hip_linear
+        hip_linear.invalidate_weight_packs()      # (parameters changed behind the optimizer's back)
+
+    def shard(self, loader):
+        """This rank's batches of one pass over ``loader`` (see the class docstring)."""
+        batches = list(loader)
+        groups = len(batches) // self.world_size
+        return [batches[g * self.world_size + self.rank] for g in range(groups)]
+
+    def mean(self, value: float, device="cpu") -> float:
+        """Mean over ranks of a per-rank scalar (epoch losses, validation losses)."""
+        if not self._active():
+            return float(value)
+        t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, group=self.group)
+        return float(t.item()) / self.world_size
+
+    def in_sync(self, model: torch.nn.Module) -> bool:
+        """Do all ranks hold bit-identical parameters?  (min == max over ranks of every element)"""
+        if not self._active():
+            return True
+        w = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+        lo, hi = w.clone(), w.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(torch.equal(lo, hi))
+
+    def wrap(self, train_on_batch):
+        """The reference-shaped step function with the gradient exchange in front of ``optimizer.step``."""
+        return data_parallel_step(train_on_batch, self.reducer)

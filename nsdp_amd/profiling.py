@@ -107,12 +107,13 @@ def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix=""):
 
 def _pmc_traffic(name, suffix=""):
     """HBM bytes per launch of `name` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r3_pmc_hbm.json, else r2 / r1: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
+    (profiles/rN_pmc_hbm.json of the newest round N: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950).  None when the file is absent."""
     import json
     import os
     prof_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-    files = (f"r3_pmc_hbm{suffix}.json", f"r2_pmc_hbm{suffix}.json") + (("r1_pmc_hbm.json",) if not suffix else ())
+    # (the newest round's file: profiles/rN_pmc_hbm{suffix}.json)
+    files = [f"r{n}_pmc_hbm{suffix}.json" for n in range(9, 0, -1)]
     path = next((os.path.join(prof_dir, f) for f in files if os.path.exists(os.path.join(prof_dir, f))),
                 os.path.join(prof_dir, files[0]))
     try:

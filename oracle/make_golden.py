@@ -11,6 +11,7 @@ seeds, expected outputs and sampled intermediates only.
     python oracle/make_golden.py            # writes tests/golden/{tiny_*,full_forward}.npz + json
     python oracle/make_golden.py --b16      # writes tests/golden/b16_forward.npz only (B = 16 full-shape step: ~15 GB
                                             # of CPU temporaries, about a minute)
+    python oracle/make_golden.py --b32      # writes tests/golden/b32_forward.npz only (the B = 32 shard bench.py times; ~30 GB)
     python oracle/make_golden.py --arbitrary-full   # writes tests/golden/full_arbitrary.npz only: arbitrary.yaml
                                             # (FlowArbitrary, model/flow_arbitrary.py:15-48) at B = 2, 2048 surface +
                                             # 8192 query points -- BASELINE config 3's shapes on the reference itself
@@ -184,6 +185,13 @@ def main():
         # LDS-table attention backward, register-table scatter), 327 680 rows in the first encoder block
         run_case(ref_model, ref_utils, "forward", [2048, 500, 100], 16, 2048, 8192, 4096, "b16_forward", False,
                  eval_stride=16)
+        return
+
+    if "--b32" in sys.argv:
+        # the headline's own per-GPU shard (bench.py default, BASELINE config 4: 32 shapes / GPU): ~30 GB of CPU temporaries
+        # in the reference (every [B, NQ, 8, 200] tensor materialised and kept for backward), a few minutes on 8 cores
+        run_case(ref_model, ref_utils, "forward", [2048, 500, 100], 32, 2048, 8192, 8192, "b32_forward", False,
+                 eval_stride=32)
         return
 
     if "--arbitrary-full" in sys.argv:

@@ -62,3 +62,24 @@ def l2_err(a, b):
     """max over shapes of sqrt(mean_n ||delta||^2)  (SURVEY.md section 8c parity metric)."""
     d = np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)
     return float(np.sqrt((d ** 2).sum(-1).mean(-1)).max())
+
+
+def snapshot_model(model):
+    """Clones of every parameter and buffer (weights, BatchNorm running statistics and counters)."""
+    return {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+
+def restore_model(model, snap, optimizer=None):
+    """Copies a snapshot_model() back IN PLACE (addresses stay what a captured step recorded) and, with ``optimizer``,
+    returns its existing state to that of a fresh optimizer (moments and step counters zeroed in place): the next step
+    is then step 1 from the snapshot's weights, whether it runs eagerly or as a replay."""
+    from nsdp_amd import hip_linear
+    with torch.no_grad():
+        for k, v in model.state_dict().items():
+            v.copy_(snap[k])
+        if optimizer is not None:
+            for st in optimizer.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+    hip_linear.invalidate_weight_packs()      # (weights rewritten behind the optimizer's back)

@@ -174,3 +174,66 @@ def test_attention_backward_through_inverse_lists_matches_the_atomic_kernels(dt)
     for kk in outs[0]:
         scale = max(float(outs[1][kk].abs().max()), floor)
         assert float((outs[0][kk] - outs[1][kk]).abs().max()) <= (2e-2 if dt is torch.bfloat16 else 1e-4) * scale, kk
+
+
+@pytest.mark.parametrize("B,rows,N,d", [(2, 4096, 100, 200), (3, 1000, 100, 200), (1, 57344, 100, 200), (2, 777, 128, 128),
+                                        (2, 2048, 7, 120), (1, 33, 100, 20)])
+def test_onehot_scatter_fp32_is_the_exact_sum_in_a_fixed_order(B, rows, N, d):
+    """nsdp_scatter_rows_onehot_f32 (scatter as a GEMM, three bf16 planes of the source x the exact one-hot operand):
+    against an fp64 index_add -- error at fp32 summation level, nothing like a bf16's -- and bit-identical run to run
+    (no atomics: the decoder's anchor-table gradients are reproducible, which the fp32-atomic kernels were not)."""
+    from nsdp_amd.hip_attention import onehot_scatter
+    g = torch.Generator().manual_seed(rows + N + d)
+    src = (torch.randn(B, rows, d, generator=g) * torch.exp(2.0 * torch.randn(B, rows, 1, generator=g))).to(DEV)
+    idx = torch.randint(0, N, (B, rows), generator=g).to(DEV).int()
+    idx[:, : min(rows, N)] = torch.arange(min(rows, N), device=DEV, dtype=torch.int32)        # every table row is hit
+    t1 = onehot_scatter(src, idx, N)
+    t2 = onehot_scatter(src, idx, N)
+    assert t1.shape == (B, N, d) and torch.equal(t1, t2)
+    ref = torch.zeros(B, N, d, dtype=torch.float64, device=DEV)
+    ref.scatter_add_(1, idx.long()[:, :, None].expand(-1, -1, d), src.double())
+    mag = torch.zeros(B, N, d, dtype=torch.float64, device=DEV)
+    mag.scatter_add_(1, idx.long()[:, :, None].expand(-1, -1, d), src.double().abs())
+    # fp32 accumulation of up to rows / N x 3 addends per entry: a few ulps of the sum of magnitudes
+    err = ((t1.double() - ref).abs() / (mag + 1e-30)).max()
+    assert float(err) <= 3e-6, float(err)
+
+
+@pytest.mark.parametrize("B,n,N,k,d", [(3, 4096, 100, 7, 200), (2, 130, 20, 7, 200), (1, 8192, 100, 7, 200)])
+def test_decoder_attention_backward_is_bit_reproducible_and_matches_the_atomic_path(B, n, N, k, d):
+    """The decoder form (one query vector per shape, global token): with the one-hot scatters and the partial-sum
+    global-token reduction the backward has no atomics -- two runs are bit-equal -- and equals the atomic kernels' result
+    up to their summation order."""
+    from nsdp_amd import hip_attention as ha
+    g = torch.Generator().manual_seed(B * n + d)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    q0, kf0, vf0, pos0 = mk(B, 1, d), mk(B, N, d), mk(B, N, d), mk(B, n, k, d)
+    ag0, vg0 = mk(B, d), mk(B, d)
+    w = mk(d, d) * 0.2
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    go = mk(B, n, d)
+
+    def run():
+        from nsdp_amd import hip_linear
+        ts = [t.clone().requires_grad_(True) for t in (q0, kf0, vf0, pos0, ag0, vg0)]
+        q, kf, vf, pos, a_g, v_g = ts
+        link = ha.pos_grad_link()
+        link.grad_sum = hip_linear.InputGradSum()
+        u = ha.attn_pre(q, kf, pos, idx, link)
+        a = hip_linear.linear(u, w, grad_sum=link.grad_sum)
+        out = ha.attn_post(a, vf, pos, idx, a_g, v_g, link=link)
+        return torch.autograd.grad(out, ts, go)
+
+    was = ha.ONEHOT_SCATTER_F32
+    try:
+        ha.ONEHOT_SCATTER_F32 = True
+        r1, r2 = run(), run()
+        ha.ONEHOT_SCATTER_F32 = False
+        ra = run()
+    finally:
+        ha.ONEHOT_SCATTER_F32 = was
+    for x, y in zip(r1, r2):
+        assert torch.equal(x, y)
+    for x, e in zip(r1, ra):
+        assert x.shape == e.shape
+        assert float((x - e).abs().max()) <= 3e-5 * (float(e.abs().max()) + 1.0)

@@ -3,7 +3,7 @@ from C must train exactly like the eager step -- same losses step for step, same
 import pytest
 import torch
 
-from helpers import build_product, model_cfg, to_dev
+from helpers import build_product, model_cfg, restore_model, snapshot_model, to_dev
 from nsdp_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -62,6 +62,57 @@ def test_replayed_step_trains_like_the_eager_step(B, npl, ns, nq, streams):
     gs.close()
 
 
+@pytest.mark.parametrize("B,npl,ns,nq", [(2, [256, 64, 16], 256, 128), (16, [2048, 500, 100], 2048, 8192)])
+def test_replayed_step_is_bit_equal_to_the_eager_step(B, npl, ns, nq):
+    """The train step has no floating-point atomics left (decoder anchor tables: scatter as a GEMM; global token: ordered
+    partial sums; encoder: inverse neighbour lists; weight gradients: ordered partial sums), so its result does not depend
+    on WHEN a kernel runs -- only on whether it ran after its inputs were complete.  That makes bit-equality the race
+    detector of the replay: the captured step replayed on 1, 2 and 4 streams (csrc/graph_exec.hip: own topological order,
+    chain decomposition, events on the cross-stream edges) must reproduce the eager step's loss, EVERY gradient, every
+    updated weight and every BatchNorm buffer bit for bit, for two consecutive steps.  A dropped cross-stream wait shows up
+    as a gradient computed from a half-written tensor.  B = 16 at full point counts is the shape class bench.py times
+    (weight gradients on the side stream, 8-wave bf16x3 GEMMs, one-hot scatters)."""
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    cfg = model_cfg("forward", npl)
+    data = to_dev(synth.make_batch(93, B, ns, nq), DEV)
+    model, opt, step = _make(cfg, 93, data)
+    capturable_adam(opt)
+    snap = snapshot_model(model)
+    step()                                     # creates the optimizer state (a capture must find it in place)
+    torch.cuda.synchronize()
+
+    def two_steps(run):
+        restore_model(model, snap, opt)
+        out = []
+        for _ in range(2):
+            loss = run()
+            torch.cuda.synchronize()
+            out.append({"loss": loss.detach().clone(),
+                        "grads": {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                        "state": snapshot_model(model)})
+        return out
+
+    def same(a, b, what):
+        bad = []
+        for i, (x, y) in enumerate(zip(a, b)):
+            if not torch.equal(x["loss"], y["loss"]):
+                bad.append(f"step {i} loss {float(x['loss'])!r} vs {float(y['loss'])!r}")
+            assert x["grads"].keys() == y["grads"].keys()
+            bad += [f"step {i} grad {k}" for k in x["grads"] if not torch.equal(x["grads"][k], y["grads"][k])]
+            bad += [f"step {i} state {k}" for k in x["state"] if not torch.equal(x["state"][k], y["state"][k])]
+        assert not bad, f"{what}: {len(bad)} tensors differ, first: {bad[:8]}"
+
+    eager = two_steps(step)
+    same(eager, two_steps(step), "eager step run twice (is the step deterministic at all?)")
+    for streams in (1, 2, 4):
+        restore_model(model, snap, opt)
+        gs = GraphedStep(step, max_streams=streams).capture(warmup=0)      # (a capture executes nothing)
+        if streams > 1:
+            assert gs.info["streams"] >= 2 and gs.info["cross_stream_edges"] >= 2, gs.info
+        same(eager, two_steps(gs), f"replay on {streams} stream(s) vs eager")
+        gs.close()
+
+
 def test_set_lr_changes_the_update_of_a_replayed_step():
     from nsdp_amd.graph_step import GraphedStep, capturable_adam, set_lr
     cfg = model_cfg("forward", [256, 64, 16])
@@ -99,3 +150,44 @@ def test_optimizer_state_created_inside_a_capture_is_reset_by_every_replay():
     torch.cuda.synchronize()
     assert float(opt.state[p]["step"]) == 1.0          # re-initialised and incremented once per replay, never beyond 1
     gs.close()
+
+
+def test_replays_interleaved_with_validation_and_odd_shape_batches_equal_the_eager_loop():
+    """GraphedTrainOnBatch in the shape of a real epoch: replays, a validation pass in between (an EAGER forward right after
+    a replay: the weight packs a replay leaves behind are one optimizer step old and must not be taken for current), a batch
+    of another shape (eager fallback: its gradient must be taken at the current weights), replays again.  The step is
+    deterministic, so the whole sequence -- train losses, validation losses, final weights -- must equal the plain eager
+    loop's bit for bit."""
+    from nsdp_amd.graph_step import GraphedTrainOnBatch, capturable_adam
+    from nsdp_amd.model import optimizer_factory
+    from nsdp_amd.model.deformation_networks import validate_on_batch_with_cano as val_fn
+    cfg = model_cfg("forward", [256, 64, 16])
+    main = to_dev(synth.make_batch(95, 2, 256, 128), DEV)
+    other = to_dev(synth.make_batch(96, 2, 256, 128), DEV)
+    odd = to_dev(synth.make_batch(97, 1, 256, 128), DEV)
+    script = [("train", main), ("train", other), ("train", main), ("val", other), ("train", odd), ("train", other),
+              ("val", main), ("train", main), ("val", odd)]
+
+    def run(graphed):
+        model, train_fn, _ = build_product(cfg, 95, DEV)
+        _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-5}, model.parameters())
+        capturable_adam(opt)
+        fn = GraphedTrainOnBatch(train_fn) if graphed else train_fn
+        out = []
+        for what, batch in script:
+            if what == "train":
+                model.train()
+                out.append(fn(model, opt, batch, cfg))
+            else:
+                model.eval()
+                out.append(val_fn(model, batch, cfg))
+        torch.cuda.synchronize()
+        if graphed:
+            assert fn.replays == 4 and fn.eager_calls == 2, (fn.replays, fn.eager_calls)
+        return out, {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    e_out, e_state = run(False)
+    g_out, g_state = run(True)
+    assert e_out == g_out, (e_out, g_out)
+    bad = [k for k in e_state if not torch.equal(e_state[k], g_state[k])]
+    assert not bad, bad[:8]

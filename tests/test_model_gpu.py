@@ -96,9 +96,12 @@ def _variant_trace():
     return cm()
 
 
-def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None):
+def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, replay=False):
     """One optimizer step of the product against what the imported reference produced for the same seeded inputs:
     loss, every gradient (norm + 16 samples), the None-gradient set, BatchNorm running statistics, Adam deltas.
+    ``replay``: the checked step is a REPLAY of the captured step through the multi-stream graph executor
+    (nsdp_amd.graph_step, what bench.py times) -- one eager step creates the optimizer state, weights / buffers / optimizer
+    state are put back in place, the step is captured (nothing executes) and replayed once.
     ``chaotic_prefix``: parameters UPSTREAM of a discontinuous index selection (FlowArbitrary's first network: its output
     points are what the second network samples and groups) -- one neighbour that flips on a 1e-7 difference changes their
     gradient by percents while the loss moves by 1e-7; their norms are held to 5 % and their samples / Adam deltas are not
@@ -108,7 +111,21 @@ def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None):
     _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4, "lr_step": 200, "lr_decay": 0.1,
                                 "weight_decay": 0.0}, model.parameters())
     before = {k: p.detach().clone() for k, p in model.named_parameters()}
-    loss = train_fn(model, opt, to_dev(data, DEV), cfg)
+    if replay:
+        from helpers import restore_model, snapshot_model
+        from nsdp_amd.graph_step import GraphedStep, capturable_adam
+        capturable_adam(opt)
+        dd = to_dev(data, DEV)
+        snap = snapshot_model(model)
+        train_fn.tensor_step(model, opt, dd, cfg)
+        torch.cuda.synchronize()
+        restore_model(model, snap, opt)
+        gs = GraphedStep(lambda: train_fn.tensor_step(model, opt, dd, cfg)).capture(warmup=0)
+        assert gs.info["kernels"] > 300, gs.info
+        loss = float(gs())
+        torch.cuda.synchronize()
+    else:
+        loss = train_fn(model, opt, to_dev(data, DEV), cfg)
     assert abs(loss - float(fx["train_loss"])) <= 2e-5 * max(1.0, abs(loss)), (loss, float(fx["train_loss"]))
     none = sorted(k for k, p in model.named_parameters() if p.grad is None)
     assert none == sorted(str(s) for s in fx["none_grads"])
@@ -257,8 +274,22 @@ def test_b16_train_step_matches_golden():
     assert eight_wave, names
     from nsdp_amd.model import ops
     masked = () if ops.PAIR_MASK else ("wgrad_bf16x3<13,13,mask,notail>",)   # (NSDP_PAIR_MASK=1 removes the masked variants)
-    for needed in ("attn_post_bwd_lds", "scatter_rows_regtab<8>", "wgrad_bf16x3<13,13,plain,notail>") + masked:
+    from nsdp_amd import hip_attention
+    # (the decoder's anchor-table gradients: scatter as a GEMM + the atomics-free attention backward, or the fp32-atomic
+    # kernels under NSDP_ONEHOT_SCATTER_F32=0)
+    scatter = (("attn_post_bwd_det", "scatter_rows_onehot_f32<8,13,notail>") if hip_attention.ONEHOT_SCATTER_F32
+               else ("attn_post_bwd_lds", "scatter_rows_regtab<8>"))
+    for needed in scatter + ("wgrad_bf16x3<13,13,plain,notail>",) + masked:
         assert needed in names, (needed, sorted(names))
+
+
+def test_b16_replayed_train_step_matches_golden():
+    """The launcher bench.py times, under the reference: the SAME B = 16 full-size step as above, but captured and replayed
+    by the multi-stream graph executor (csrc/graph_exec.hip) -- loss, every gradient, BatchNorm statistics and Adam deltas
+    of the replayed step against the imported reference's (tests/golden/b16_forward.npz)."""
+    fx, cfg, seed, data = fixture_setup("b16_forward", "forward")
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    _check_train_step(fx, model, train_fn, cfg, data, replay=True)
 
 
 def test_b8_full_shape_eval_matches_oracle():

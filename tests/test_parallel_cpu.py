@@ -212,3 +212,127 @@ def test_direct_grad_publication_with_flat_bucket_world2():
         assert p.exitcode == 0
     for rank, errs in res:
         assert errs["views"] < 1e-6 and errs["wrapped"] < 1e-6, (rank, errs)
+
+
+# ------------------------------------------------------------------------------------------------
+# the train harness as a data-parallel job (nsdp_amd.train.fit(dp=...)), world 2 over gloo
+# ------------------------------------------------------------------------------------------------
+class _BnToy(torch.nn.Module):
+    """A model with a BatchNorm (per-rank running statistics) in front of a decoder."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.BatchNorm1d(4))
+        self.decoder = torch.nn.Linear(4, 2)
+
+    def forward(self, x):
+        return self.decoder(torch.tanh(self.encoder(x)))
+
+
+def _toy_fns():
+    def train_on_batch(model, optimizer, sample, config):
+        optimizer.zero_grad()
+        loss = ((model(sample["x"]) - sample["y"]) ** 2).mean()
+        loss.backward()
+        optimizer.step()
+        return loss.item()
+
+    @torch.no_grad()
+    def validate_on_batch(model, sample, config):
+        return ((model(sample["x"]) - sample["y"]) ** 2).mean().item()
+    return train_on_batch, validate_on_batch
+
+
+def _toy_batches(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [{"x": torch.randn(6, 5, generator=g), "y": torch.randn(6, 2, generator=g)} for _ in range(n)]
+
+
+_FIT_CFG = {"training": {"epochs": 4, "save_frequency": 2, "optimizer": "Adam", "lr": 1e-2, "lr_step": 3, "lr_decay": 0.5,
+                         "weight_decay": 0.0},
+            "validation": {"frequency": 2}}
+
+
+def _fit_worker(rank, world, port, directory, out):
+    import argparse
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nsdp_amd import train
+        from nsdp_amd.model import optimizer_factory
+        from nsdp_amd.parallel import DataParallel
+        torch.manual_seed(1000 + rank)            # DIFFERENT initial weights per rank: the broadcast must fix that
+        model = _BnToy()
+        sched, opt = optimizer_factory(_FIT_CFG["training"], model.parameters())
+        dp = DataParallel(model, rank, world)
+        args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+        lines = []
+        hist = train.fit(model, _toy_fns(), sched, opt, _toy_batches(5, 7), _toy_batches(2, 8), _FIT_CFG, directory, args, "cpu",
+                         log=lines.append, dp=dp)
+        sync = dp.in_sync(model)
+        # (numpy, not tensors: a tensor in a Queue travels as a shared-memory handle the parent cannot open once we exit)
+        out.put((rank, hist, sync, len(lines), {k: v.numpy().copy() for k, v in model.state_dict().items()}, args.best_val_loss))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_fit_as_a_two_rank_job_keeps_ranks_identical_and_writes_one_set_of_files(tmp_path):
+    """train.fit(dp=DataParallel): per-rank batches (5 batches -> 2 steps per epoch and rank, the odd one dropped), gradient
+    mean before every optimizer step, rank-0 files only, rank-0 BatchNorm buffers in the checkpoints and on every rank at
+    validation time -- and the weights equal a single-process run over the two ranks' batches with averaged gradients."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    d = str(tmp_path)
+    procs = [ctx.Process(target=_fit_worker, args=(r, world, port, d, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=150) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    (r0, h0, s0, n0, sd0, b0), (r1, h1, s1, n1, sd1, b1) = res
+    assert s0 and s1                                         # bit-identical parameters on both ranks
+    assert h0 == h1 and b0 == b1                             # same (rank-averaged) losses, same best-model decisions
+    assert [h[0] for h in h0] == ["train", "train", "train", "val", "train"]
+    assert n0 > 0 and n1 == 0                                # only rank 0 logs
+    for k in sd0:
+        if "running" in k or "num_batches" in k:
+            continue                                         # per-rank statistics between broadcasts
+        assert (sd0[k] == sd1[k]).all(), k
+    files = sorted(os.listdir(d))
+    assert [f for f in files if f.startswith("model_")] == ["model_00000", "model_00002"]
+    assert [f for f in files if f.startswith("opt_")] == ["opt_00000", "opt_00002"]
+    assert len([f for f in files if f.startswith("modelbest_")]) == 1
+    # the checkpoint of epoch 2 holds rank 0's BatchNorm statistics -- which both ranks held when they validated
+    ck = torch.load(os.path.join(d, "model_00002"))
+    # single-process reference: same initial weights as rank 0, both ranks' batches, mean of the two gradients per step
+    import argparse
+    from nsdp_amd.model import optimizer_factory
+    torch.manual_seed(1000)
+    ref = _BnToy()
+    sched, opt = optimizer_factory(_FIT_CFG["training"], ref.parameters())
+    from nsdp_amd.model.learningrate import adjust_learning_rate
+    batches = _toy_batches(5, 7)
+    import copy
+    twin = copy.deepcopy(ref)                                # rank 1's replica (own BatchNorm statistics)
+    for epoch in range(4):
+        adjust_learning_rate(sched, opt, epoch)
+        for g in range(2):
+            grads = []
+            for m, b in ((ref, batches[2 * g]), (twin, batches[2 * g + 1])):
+                m.zero_grad()
+                ((m(b["x"]) - b["y"]) ** 2).mean().backward()
+                grads.append([p.grad.clone() for p in m.parameters()])
+            for p, g0, g1 in zip(ref.parameters(), *grads):
+                p.grad = (g0 + g1) / 2
+            opt.step()
+            with torch.no_grad():
+                for p, q in zip(ref.parameters(), twin.parameters()):
+                    q.copy_(p)
+        if epoch == 2:
+            for k, v in ref.state_dict().items():
+                assert torch.allclose(ck[k].to(v.dtype), v, rtol=1e-5, atol=1e-6), k
+    for (k, v) in ref.named_parameters():
+        assert torch.allclose(torch.from_numpy(sd0[k]), v.detach(), rtol=1e-5, atol=1e-6), k

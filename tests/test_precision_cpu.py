@@ -42,5 +42,7 @@ def test_scatter_strategy_per_level():
     assert ha._use_inverse(f32, False, 100, 100, 256)            # n < 4 N: the LDS-table kernel does not apply
     assert not ha._use_inverse(f32, False, 8192, 100, 200)       # a 100-row table with many centres: LDS table
     assert not ha._use_inverse(f32, True, 8192, 100, 200)        # the decoder (one query vector per shape): register table
-    assert ha._onehot_ok(bf, True, 100, 200) and not ha._onehot_ok(f32, True, 100, 200)
+    # the decoder's anchor tables: scatter as a GEMM in both storage types (fp32: three bf16 planes x the exact one-hot operand)
+    assert ha._onehot_ok(bf, True, 100, 200) and ha._onehot_ok(f32, True, 100, 200) == ha.ONEHOT_SCATTER_F32
     assert not ha._onehot_ok(bf, True, 130, 200) and not ha._onehot_ok(bf, False, 100, 200)
+    assert not ha._onehot_ok(f32, True, 100, 256) and not ha._onehot_ok(f32, False, 100, 200)
