@@ -105,14 +105,24 @@ def bf16_parity(workload, device):
     model.to(device).eval()
     d = {k: torch.from_numpy(v).to(device) for k, v in synth.make_batch(seed, b, ns, nq).items()}
     out = {}
-    for mode in ("f32", "bf16"):
+
+    def forward(mode, scale=1.0, round_inputs=False):
         with precision.storage(mode), torch.no_grad():
-            s_in = d["surface_samples_inputs"]
+            s_in, q = d["surface_samples_inputs"] * scale, d["space_samples_src"] * scale
+            if round_inputs:
+                s_in, q = s_in.to(torch.bfloat16).float(), q.to(torch.bfloat16).float()
+            mask = d["surface_samples_inputs"][:, :, 6:7]
             if mtype == "arbitrary":
-                o = model(d["space_samples_src"], s_in[:, :, 0:3], s_in[:, :, 3:6], s_in[:, :, 6:7])
+                o = model(q, s_in[:, :, 0:3].contiguous(), s_in[:, :, 3:6].contiguous(), mask.contiguous())
             else:
-                o = model(d["space_samples_src"], s_in)
-        out[mode] = o.float().cpu().numpy().astype(np.float64)
+                o = model(q, torch.cat([s_in[:, :, 0:6], mask], dim=-1).contiguous())
+        return o.float().cpu().numpy().astype(np.float64) / scale
+    for mode in ("f32", "bf16"):
+        out[mode] = forward(mode)
+    # chaos floor: what a bf16-SIZED perturbation of the inputs alone does to the fp32 model's output (neighbour sets flip,
+    # FPS picks other centres) -- the yardstick for the bf16 figure (tools/bf16_bisect.py, profiles/r4_bf16_bisect.txt)
+    floor_scaled = forward("f32", 1.0 + 2.0 ** -8)
+    floor_rounded = forward("f32", 1.0, True)
     stride = int(fx["meta_eval_stride"]) if "meta_eval_stride" in fx else 1
     ref = fx["eval_out"].astype(np.float64)
     # (the two worst queries per shape are left out: where a query's k-th and (k+1)-th anchor distances are bit-equal the
@@ -121,7 +131,13 @@ def bf16_parity(workload, device):
     def l2(o):
         err = ((o[:, ::stride] - ref) ** 2).sum(-1)
         return float(np.sqrt(np.sort(err, axis=1)[:, :-2].mean(-1)).max())
+    def l2_pair(a, b_):
+        err = ((a[:, ::stride] - b_[:, ::stride]) ** 2).sum(-1)
+        return float(np.sqrt(np.sort(err, axis=1)[:, :-2].mean(-1)).max())
     return {"bf16": round(l2(out["bf16"]), 6), "f32": round(l2(out["f32"]), 8), "fixture": f"tests/golden/{name}.npz",
+            "canonicalize_f32": precision.canonicalize_f32() if mtype == "arbitrary" else None,
+            "chaos_floor_fp32_inputs_x_1p2m8": round(l2_pair(floor_scaled, out["f32"]), 6),
+            "chaos_floor_fp32_inputs_rounded_to_bf16": round(l2_pair(floor_rounded, out["f32"]), 6),
             "metric": "max over shapes of sqrt(mean_q |pred - reference|^2) without the 2 worst queries, eval forward, B=%d" % b}
 
 
@@ -238,6 +254,9 @@ def main():
                     help="storage precision of the activations: f32 (default; dense layers as error-compensated bf16x3 "
                          "products, fp32 accuracy) | bf16 (BASELINE config 3: bf16 activations and saved tensors, fp32 "
                          "accumulation, fp32 master weights)")
+    ap.add_argument("--canonicalize-f32", action="store_true",
+                    help="with --dtype bf16 --workload arbitrary_train: FlowArbitrary's first network in fp32 storage (its output "
+                         "points are the second network's geometry: eval L2 against the reference 1.0e-2 instead of 1.3e-1)")
     ap.add_argument("--eager", action="store_true",
                     help="enqueue every launch of every step from Python (the reference's way).  Default: the step "
                          "(train or inference) is captured once and replayed through the multi-stream graph executor "
@@ -306,6 +325,8 @@ def main():
     from nsdp_amd import precision, profiling, synth
     from nsdp_amd.model import build_model, optimizer_factory
     precision.set_storage(args.dtype)
+    if args.canonicalize_f32:
+        precision.set_canonicalize_f32(True)
     from nsdp_amd.parallel import DataParallel
     from nsdp_amd.model.utils import compute_l2_error
 
@@ -530,7 +551,8 @@ def main():
             "config": {"workload": f"{names[1]}, "
                                    f"{args.batch} shapes/GPU, {N_SURF} surface + {n_query} query points per shape, "
                                    + ("fp32 (dense layers as bf16x3 split products)" if args.dtype == "f32" else
-                                      "bf16 storage / fp32 accumulate / fp32 master weights")
+                                      "bf16 storage / fp32 accumulate / fp32 master weights"
+                                      + (" (network 1 in fp32 storage)" if args.canonicalize_f32 else ""))
                                    + ", procedural random-init weights",
                        "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},

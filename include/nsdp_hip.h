@@ -34,7 +34,10 @@ int nsdp_abi_version(void);
 const char *nsdp_last_error(void);
 /* Tuning / ablation knobs (not part of the reference contract; timing experiments only -- several produce wrong results):
  * 1 wgrad software pipelining, 3 fp32 GEMM pipeline form, 4 fp32 GEMM ablation bits, 5 float4-operand wgrad, 6 bf16x3 GEMM
- * ablation bits, 7 bf16 wgrad phases (1 no MFMA, 2 no transposition, 4 no DMA), 8 bf16 linear phases (1 no MFMA, 2 no stores). */
+ * ablation bits, 7 bf16 wgrad phases (1 no MFMA, 2 no transposition, 4 no DMA), 8 bf16 linear phases (1 no MFMA, 2 no stores).
+ * 9 is a HOST HINT, not an ablation: the number of compute units nsdp_linear_wgrad_bf16x3_f32 leaves free (its persistent
+ * one-wave-per-SIMD workgroups otherwise hold every CU until the kernel ends); the host sets it around weight-gradient
+ * launches that run on a side stream next to the critical chain and resets it to 0 (the workspace query sees the same value). */
 void nsdp_debug_set(int key, int value);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int nsdp_device_count(void);
@@ -69,11 +72,19 @@ int nsdp_group_points_grad(const float *grad_out, const int32_t *idx, int B, int
  * idx viewed as (B,E): offsets (B,N+1), entries (B,E), lists ascending): grad_points(B,C,N)[b,c,s] = sum over the list of s
  * of grad_out(B,C,E)[b,c,entry] -- no atomics, deterministic, a stream over grad_out (the index set is shared by all C
  * channels, so one list build serves them all).  Same result as nsdp_group_points_grad (sampling_gpu.cu:34-57,
- * group_points_gpu.cu:43-75) up to the order of the fp32 sums.  Needs a row of E floats to fit LDS
- * (nsdp_scatter_cm_lists_supported: E <= 32768). */
+ * group_points_gpu.cu:43-75) up to the order of the fp32 sums.  A row of E floats that fits LDS (E <= 32768) is staged
+ * whole; longer rows in slices, with a cursor per target into its (ascending) list.  N <= 32768. */
 int nsdp_scatter_cm_lists_supported(int B, int C, int N, int E);
 int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const int32_t *entries, int B, int C, int N,
                           int E, float *grad_points, void *stream);
+
+/* three_interpolate_grad (interpolate_gpu.cu:116-143) without atomics: offsets / entries = nsdp_knn_invert of the (B, n, 3)
+ * index map flattened to E = 3 n entries per shape (entry e = 3 j + t); grad_points[b][c][s] = sum over the list of s of
+ * grad_out[b][c][e / 3] * weight[b][e], in list order (deterministic).  A row of n floats must fit LDS. */
+int nsdp_three_interpolate_grad_lists_supported(int B, int c, int n, int m);
+int nsdp_three_interpolate_grad_lists(const float *grad_out, const float *weight, const int32_t *offsets,
+                                      const int32_t *entries, int B, int c, int n, int m, float *grad_points, void *stream);
+
 
 /* ball_query(new_xyz(B,M,3), xyz(B,N,3), radius, nsample) -> (B,M,nsample) i32;
  * ball_query.cpp:8-34, ball_query_gpu.cu:9-54 */
@@ -243,7 +254,7 @@ int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, con
 
 /* Atomics-free scatter through inverse neighbour lists (csrc/segment.hip).  nsdp_knn_invert: idx (B, E) int32 with values
  * in [0, N) (E = centres x neighbours) -> offsets (B, N + 1), entries (B, E): entries[b][offsets[b][s] .. offsets[b][s+1])
- * is the ascending list of the flat positions e with idx[b][e] == s.  N <= 8192.  Built once per index set and step.
+ * is the ascending list of the flat positions e with idx[b][e] == s.  N <= 32768.  Built once per index set and step.
  * nsdp_segment_sum_rows: out[b][s][:] = scale * sum over that list of src[b][e][:]  (src (B, E, d) fp32 / bf16, out fp32) --
  * the scatter-add of the attention backward (dvf, dkf) as a deterministic gather-reduce. */
 int nsdp_knn_invert(const int32_t *idx, int B, int E, int N, int32_t *offsets, int32_t *entries, void *stream);

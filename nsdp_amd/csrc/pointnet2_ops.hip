@@ -44,6 +44,7 @@ inline int grid_for(long long work) {
 constexpr int kBig = 1024;                     // threads of the LDS-staged kernels
 constexpr int kLdsTableBytes = 64 * 1024;      // two workgroups per CU
 constexpr int kLdsTableMax = 128 * 1024;
+constexpr int kListSortMax = 1024;             // nsdp_knn_invert leaves longer lists unsorted (csrc/segment.hip kSortMax)
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -194,6 +195,175 @@ __global__ __launch_bounds__(kBig) void scatter_cm_lists_kernel(const float *__r
 #pragma unroll
     for (int c = 0; c < CH; ++c)
       if (c < cn) o0[static_cast<long long>(c) * N + s] = acc[c];
+  }
+}
+
+// three_interpolate_grad through the inverse lists of its (B, n, 3) index map (interpolate_gpu.cu:116-143: three global
+// atomics per element): entry e = 3 j + t of the list of source m contributes grad_out[b][c][j] * weight[b][j][t].  The
+// workgroup stages CH rows of grad_out (n floats each), a thread owns sources and walks its list once for all CH channels;
+// the weights (shared by all channels) come from global memory, once per entry and chunk.
+template <int CH>
+__global__ __launch_bounds__(kBig) void three_interp_lists_kernel(const float *__restrict__ grad_out,
+                                                                  const float *__restrict__ weight,
+                                                                  const int32_t *__restrict__ offsets,
+                                                                  const int32_t *__restrict__ entries, int C, int n, int m,
+                                                                  float *__restrict__ grad_points) {
+  extern __shared__ float table[];      // [CH][n]
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = C - c0 < CH ? C - c0 : CH;
+  const float *src = grad_out + (static_cast<long long>(b) * C + c0) * n;
+  if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int t = threadIdx.x * 4; t < cn * n; t += kBig * 4)
+      *reinterpret_cast<float4 *>(table + t) = *reinterpret_cast<const float4 *>(src + t);
+  } else {
+    for (int t = threadIdx.x; t < cn * n; t += kBig) table[t] = src[t];
+  }
+  __syncthreads();
+  const int32_t *off = offsets + static_cast<long long>(b) * (m + 1);
+  const int32_t *ent = entries + static_cast<long long>(b) * 3 * n;
+  const float *wb = weight + static_cast<long long>(b) * 3 * n;
+  float *o0 = grad_points + (static_cast<long long>(b) * C + c0) * m;
+  for (int s = threadIdx.x; s < m; s += kBig) {
+    const int lo = off[s], hi = off[s + 1];
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+    for (int i = lo; i < hi; ++i) {
+      const int e = ent[i];
+      const float w = wb[e];
+      const int j = e / 3;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[c] += table[(c < cn ? c : 0) * n + j] * w;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+      if (c < cn) o0[static_cast<long long>(c) * m + s] = acc[c];
+  }
+}
+
+// scatter_cm_lists for rows LONGER than LDS (E floats per (b, c) row do not fit: PointNet++ SSG shapes, 2048 x 32 entries
+// and more): the row is staged in SLICES of `slice` entries; every list is ascending, so the part of a list that falls into
+// a slice is a contiguous run -- a thread keeps a cursor per owned target (TP of them, in registers, next to TP x CH
+// accumulators), advances it through the slice and writes each target once at the end.  No atomics, one pass over grad_out.
+template <int CH, int TP, bool PREFETCH>
+__global__ __launch_bounds__(kBig) void scatter_cm_lists_sliced_kernel(const float *__restrict__ grad_out,
+                                                                       const int32_t *__restrict__ offsets,
+                                                                       const int32_t *__restrict__ entries, int C, int N, int E,
+                                                                       int slice, float *__restrict__ grad_points) {
+  extern __shared__ float table[];      // [CH][slice]
+  constexpr int kDone = 0x7fffffff;
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * CH;
+  const int cn = C - c0 < CH ? C - c0 : CH;
+  const float *src = grad_out + (static_cast<long long>(b) * C + c0) * E;
+  const int32_t *off = offsets + static_cast<long long>(b) * (N + 1);
+  const int32_t *ent = entries + static_cast<long long>(b) * E;
+  float *o0 = grad_points + (static_cast<long long>(b) * C + c0) * N;
+  for (int s0 = 0; s0 < N; s0 += kBig * TP) {      // (one round for N <= kBig * TP targets)
+    // per owned target: cursor, list end, the NEXT entry already in a register (the walk is a chain of dependent loads;
+    // with the next entry prefetched the TP chains of a thread advance in parallel)
+    int cur[TP], end[TP], nxt[TP];
+    bool unsorted[TP];
+    float acc[TP][CH];
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int s = s0 + threadIdx.x + t * kBig;
+      cur[t] = s < N ? off[s] : 0;
+      end[t] = s < N ? off[s + 1] : 0;
+      // a list longer than nsdp_knn_invert sorts (a hot source point) is in arbitrary order: every slice walks the whole
+      // list and takes what falls into it (correct; slow; its summation order is the list's)
+      unsorted[t] = end[t] - cur[t] > kListSortMax;
+      nxt[t] = (cur[t] < end[t] && !unsorted[t]) ? ent[cur[t]] : kDone;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[t][c] = 0.f;
+    }
+    // staging: every thread moves kPre float4 per channel and slice (slice = 4 * kBig * kPre entries).  With 16-byte aligned
+    // rows the NEXT slice is loaded into registers before the current one is consumed (the list walk hides the load
+    // latency) and written to LDS behind the barrier; ragged rows take the plain path.
+    // (PREFETCH is off in the 16-targets-per-thread forms: 48 cursor registers + 64 accumulators leave no room for it
+    // under the 128 registers of a 1024-thread workgroup)
+    constexpr int kPre = PREFETCH ? 8 / CH : 1;
+    const bool vec = PREFETCH && (E & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && slice == 4 * kBig * kPre;
+    float4 pre[PREFETCH ? CH : 1][kPre];
+    auto fetch = [&](int e0) {
+#pragma unroll
+      for (int c = 0; c < (PREFETCH ? CH : 1); ++c)
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) {
+          const int t = (q * kBig + threadIdx.x) * 4;
+          pre[c][q] = (c < cn && e0 + t < E) ? *reinterpret_cast<const float4 *>(src + static_cast<long long>(c) * E + e0 + t)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if constexpr (PREFETCH) {
+      if (vec) fetch(0);
+    }
+    for (int e0 = 0; e0 < E; e0 += slice) {
+      const int len = E - e0 < slice ? E - e0 : slice;
+      __syncthreads();                             // the previous slice has been consumed
+      bool staged = false;
+      if constexpr (PREFETCH) {
+        if (vec) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int q = 0; q < kPre; ++q)
+              *reinterpret_cast<float4 *>(table + c * slice + (q * kBig + threadIdx.x) * 4) = pre[c][q];
+          if (e0 + slice < E) fetch(e0 + slice);     // in flight during this slice's walk
+          staged = true;
+        }
+      }
+      if (!staged) {
+        for (int c = 0; c < cn; ++c) {
+          const float *row = src + static_cast<long long>(c) * E + e0;
+          if ((len & 3) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+            for (int t = threadIdx.x * 4; t < len; t += kBig * 4)
+              *reinterpret_cast<float4 *>(table + c * slice + t) = *reinterpret_cast<const float4 *>(row + t);
+          } else {
+            for (int t = threadIdx.x; t < len; t += kBig) table[c * slice + t] = row[t];
+          }
+        }
+      }
+      __syncthreads();
+      const int e1 = e0 + len;
+      bool more = true;
+      while (more) {                               // rounds: every target with an entry in this slice consumes ONE
+        more = false;
+#pragma unroll
+        for (int t = 0; t < TP; ++t) {
+          if (nxt[t] < e1) {
+            const int e = nxt[t] - e0;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[t][c] += table[(c < cn ? c : 0) * slice + e];
+            ++cur[t];
+            nxt[t] = cur[t] < end[t] ? ent[cur[t]] : kDone;
+            more = true;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TP; ++t) {
+        if (unsorted[t]) {
+          for (int q = cur[t]; q < end[t]; ++q) {
+            const int e = ent[q];
+            if (e >= e0 && e < e1) {
+#pragma unroll
+              for (int c = 0; c < CH; ++c) acc[t][c] += table[(c < cn ? c : 0) * slice + (e - e0)];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+      const int s = s0 + threadIdx.x + t * kBig;
+      if (s < N) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          if (c < cn) o0[static_cast<long long>(c) * N + s] = acc[t][c];
+      }
+    }
   }
 }
 
@@ -715,20 +885,39 @@ int nsdp_three_interpolate_grad(const float *grad_out, const int32_t *idx, const
 }
 
 int nsdp_scatter_cm_lists_supported(int B, int C, int N, int E) {
-  return B > 0 && B <= 65535 && C > 0 && N > 0 && E > 0 && 4LL * E <= kLdsTableMax;
+  return B > 0 && B <= 65535 && C > 0 && N > 0 && N <= 32768 && E > 0;
 }
 
 int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const int32_t *entries, int B, int C, int N,
                           int E, float *grad_points, void *stream) {
   if (static_cast<long long>(B) * C * N <= 0) return 0;
   NSDP_REQUIRE(grad_out && offsets && entries && grad_points, "scatter_cm_lists: null pointer");
-  // (rows longer than LDS were tried in slices with atomically combined partial sums: no faster than the LDS-table kernel)
-  NSDP_REQUIRE(nsdp_scatter_cm_lists_supported(B, C, N, E), "scatter_cm_lists: a row of E=%d floats must fit LDS (<= %d bytes)", E,
-               kLdsTableMax);
+  NSDP_REQUIRE(nsdp_scatter_cm_lists_supported(B, C, N, E), "scatter_cm_lists: unsupported shape (B=%d C=%d N=%d E=%d)", B, C, N, E);
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
                           4.0 * (static_cast<double>(B) * E * (1 + C) + static_cast<double>(B) * C * N));
   const long long row_bytes = 4LL * E;
+  if (row_bytes > kLdsTableMax) {
+    // rows longer than LDS: slices of the row, cursors into the ascending lists (scatter_cm_lists_sliced_kernel).  Four
+    // channels share one walk of the lists when that still leaves two workgroups per CU.
+    const bool many = N > 8 * kBig;      // 16 targets per thread: two channels only (registers)
+    const bool four = !many && static_cast<long long>(B) * ((C + 3) / 4) >= 2LL * nsdp::num_cus();
+    const int ch = four ? 4 : 2;
+    const int slice = kLdsTableMax / 4 / ch;
+    const dim3 grid((C + ch - 1) / ch, B);
+    NSDP_TRACE("scatter_cm_lists_sliced<%d,%d>", ch, many ? 16 : 8);
+#define NSDP_SCS(CH, TP, PF)                                                                                               \
+  {                                                                                                                        \
+    if (!allow_big_lds<&scatter_cm_lists_sliced_kernel<CH, TP, PF>>()) return NSDP_EINVAL;                                 \
+    hipLaunchKernelGGL((scatter_cm_lists_sliced_kernel<CH, TP, PF>), grid, dim3(kBig), static_cast<size_t>(kLdsTableMax),   \
+                       st, grad_out, offsets, entries, C, N, E, slice, grad_points);                                       \
+  }
+    if (four) NSDP_SCS(4, 8, true)
+    else if (many) NSDP_SCS(2, 16, false)
+    else NSDP_SCS(2, 8, true)
+#undef NSDP_SCS
+    return nsdp::launch_status("scatter_cm_lists_sliced_kernel");
+  }
   int ch = static_cast<int>((row_bytes <= kLdsTableBytes ? kLdsTableBytes : kLdsTableMax) / row_bytes);
   ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
   while (ch > 1 && static_cast<long long>(B) * ((C + ch - 1) / ch) < 2LL * nsdp::num_cus()) ch >>= 1;
@@ -749,6 +938,42 @@ int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const i
   }
 #undef NSDP_SCL
   return nsdp::launch_status("scatter_cm_lists_kernel");
+}
+
+int nsdp_three_interpolate_grad_lists_supported(int B, int c, int n, int m) {
+  return B > 0 && B <= 65535 && c > 0 && m > 0 && m <= 32768 && n > 0 && 4LL * n <= kLdsTableMax;
+}
+
+int nsdp_three_interpolate_grad_lists(const float *grad_out, const float *weight, const int32_t *offsets,
+                                      const int32_t *entries, int B, int c, int n, int m, float *grad_points, void *stream) {
+  if (static_cast<long long>(B) * c * m <= 0) return 0;
+  NSDP_REQUIRE(grad_out && weight && offsets && entries && grad_points, "three_interpolate_grad_lists: null pointer");
+  NSDP_REQUIRE(nsdp_three_interpolate_grad_lists_supported(B, c, n, m),
+               "three_interpolate_grad_lists: a row of n=%d floats must fit LDS (<= %d bytes), m <= 32768", n, kLdsTableMax);
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
+                          4.0 * (static_cast<double>(B) * n * (6 + c) + static_cast<double>(B) * c * m));
+  const long long row_bytes = 4LL * n;
+  int ch = static_cast<int>((row_bytes <= kLdsTableBytes ? kLdsTableBytes : kLdsTableMax) / row_bytes);
+  ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
+  while (ch > 1 && static_cast<long long>(B) * ((c + ch - 1) / ch) < 2LL * nsdp::num_cus()) ch >>= 1;
+  const dim3 grid((c + ch - 1) / ch, B);
+  const size_t lds = static_cast<size_t>(ch) * n * 4;
+  NSDP_TRACE("three_interpolate_grad_lists<%d>", ch);
+#define NSDP_TIL(CH)                                                                                                       \
+  {                                                                                                                        \
+    if (!allow_big_lds<&three_interp_lists_kernel<CH>>()) return NSDP_EINVAL;                                              \
+    hipLaunchKernelGGL((three_interp_lists_kernel<CH>), grid, dim3(kBig), lds, st, grad_out, weight, offsets, entries, c,   \
+                       n, m, grad_points);                                                                                 \
+  }
+  switch (ch) {
+    case 8: NSDP_TIL(8) break;
+    case 4: NSDP_TIL(4) break;
+    case 2: NSDP_TIL(2) break;
+    default: NSDP_TIL(1) break;
+  }
+#undef NSDP_TIL
+  return nsdp::launch_status("three_interp_lists_kernel");
 }
 
 int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int C, int S, float *out,

@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int kInvThreads = 1024;
-constexpr int kMaxSources = 8192;      // counters of one shape in LDS
+constexpr int kMaxSources = 32768;     // counters of one shape in (dynamic) LDS: 128 KiB + 4 KiB of scan scratch
 constexpr int kSortMax = 1024;         // longest list that is put into ascending order (fixed summation order)
 
 // offsets [B][N+1], entries [B][E]: entries[b][offsets[b][s] .. offsets[b][s+1]) = ascending list of e = i*k + j with
@@ -23,7 +23,7 @@ constexpr int kSortMax = 1024;         // longest list that is put into ascendin
 __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *__restrict__ idx_all, int E, int N,
                                                                  int32_t *__restrict__ offsets_all,
                                                                  int32_t *__restrict__ entries_all) {
-  __shared__ int cnt[kMaxSources + 1];
+  extern __shared__ int cnt[];           // [N + 1]
   __shared__ int part[kInvThreads];
   const int b = blockIdx.x;
   const int32_t *idx = idx_all + static_cast<long long>(b) * E;
@@ -148,7 +148,12 @@ int nsdp_knn_invert(const int32_t *idx, int B, int E, int N, int32_t *offsets, i
   NSDP_REQUIRE(N > 0 && N <= kMaxSources, "knn_invert: N=%d must be in [1, %d]", N, kMaxSources);
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kKnn, st, 0.0, static_cast<double>(B) * (12.0 * E + 4.0 * N));
-  hipLaunchKernelGGL(knn_invert_kernel, dim3(B), dim3(kInvThreads), 0, st, idx, E, N, offsets, entries);
+  const size_t lds = (static_cast<size_t>(N) + 1) * sizeof(int);
+  if (lds > 60 * 1024) {      // (per call: the attribute belongs to the current device's function object)
+    NSDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     static_cast<int>(lds)));
+  }
+  hipLaunchKernelGGL(knn_invert_kernel, dim3(B), dim3(kInvThreads), lds, st, idx, E, N, offsets, entries);
   return nsdp::launch_status("knn_invert_kernel");
 }
 

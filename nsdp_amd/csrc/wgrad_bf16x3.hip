@@ -19,6 +19,8 @@
 // global loads are issued one block ahead and its split is interleaved with the first MFMA steps.  Partial
 // results go to a workspace as fragment-ordered float4 (one partial dW per workgroup) and are summed by a
 // second kernel in fixed order (deterministic, no atomics).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -502,6 +504,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_kernel(const float *_
   }
 }
 
+int g_wg3_reserve = 0;
+
 struct X3Plan {
   int nta, ktb, kparts, grid;
   long long blocks_per_wg;
@@ -520,9 +524,17 @@ X3Plan plan_x3(long long M, int N, int K) {
     pl.kparts = (K + 127) / 128;
   }
   const long long mb_all = (M + 31) / 32;
-  long long grid = nsdp::num_cus() / pl.kparts;
+  // g_wg3_reserve (host hint, nsdp_debug_set(9, n)): compute units left free because this launch shares the chip with another
+  // stream's kernels -- see hip_linear._wgrad_deferred.  NSDP_WGRAD_MAX_BLOCKS (experiment knob, read once): cap on the 32-row
+  // blocks per workgroup (> 0: more, shorter workgroups instead of one persistent workgroup per CU; measured slower:
+  // 42.4 / 44.2 / 47.6 ms at 64 / 16 / 8 against 41.8)
+  const int reserve = g_wg3_reserve;
+  static const int max_blocks = getenv("NSDP_WGRAD_MAX_BLOCKS") ? atoi(getenv("NSDP_WGRAD_MAX_BLOCKS")) : 0;
+  long long grid = (nsdp::num_cus() - reserve) / pl.kparts;
+  if (grid < 1) grid = 1;
   if (grid > mb_all / 4) grid = mb_all / 4 > 0 ? mb_all / 4 : 1;     // at least 4 blocks per workgroup
   pl.blocks_per_wg = (mb_all + grid - 1) / grid;
+  if (max_blocks > 0 && pl.blocks_per_wg > max_blocks) pl.blocks_per_wg = max_blocks;
   pl.grid = static_cast<int>((mb_all + pl.blocks_per_wg - 1) / pl.blocks_per_wg);
   pl.ws_floats = static_cast<size_t>(pl.grid) * pl.kparts * (static_cast<size_t>(pl.nta) * pl.ktb * 256 + pl.nta * 16);
   return pl;
@@ -582,7 +594,7 @@ OneHotPlan plan_onehot(int B, long long rows, int d) {
 }  // namespace
 
 namespace nsdp {
-void debug_set_wg3(int) {}      // (knob 9 selected the retired column-wise form: accepted and ignored)
+void debug_set_wg3(int value) { g_wg3_reserve = value < 0 ? 0 : value; }      // knob 9: compute units to leave free (host hint)
 }  // namespace nsdp
 
 extern "C" {

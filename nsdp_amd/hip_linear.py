@@ -153,6 +153,11 @@ def _wgrad_x3(dy2, x2, mask, relu_x, want_db, out=None):
 _OVERLAP_WGRAD = os.environ.get("NSDP_WGRAD_STREAM", "auto")
 _OVERLAP_WGRAD = {"0": False, "1": True}.get(_OVERLAP_WGRAD, "auto")
 _OVERLAP_MIN_ROWS = 131072       # rows of dY at the model's output layer (batch x query points)
+# Compute units the side stream's bf16x3 weight-gradient kernels leave free (NSDP_WGRAD_RESERVE_CUS).  Measured at B = 32
+# (same box per comparison, two boxes): 0 -> 41.80 / 43.35 ms, 32 -> 41.30 / 42.93, 48 -> 42.90, 64 -> 42.86, 96 -> 42.99,
+# 128 -> 43.27: the critical chain's small kernels (the encoder's 100-point levels, BatchNorm, reductions) no longer wait
+# for a whole persistent kernel to end before they get a compute unit.
+SIDE_RESERVE_CUS = int(os.environ.get("NSDP_WGRAD_RESERVE_CUS", "48"))
 _overlap_now = {}                # (device index, graph task) -> decision for that backward pass
 _side = {}
 _pending = {}          # (device index, graph task) -> {id(param): [param, grad tensor living on the side stream]}
@@ -307,10 +312,17 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
                 if b_param is not None:
                     ent_b = slot[id(b_param)] = [b_param, gb0]
         out = _grad_targets(w_param, b_param, ent_w[1] if ent_w is not None else None, ent_b[1] if ent_b is not None else None)
-        if fn is None:
-            dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig, out)
-        else:
-            dw, db = fn(dy2, x2, mask, relu_x, b_param is not None, out)
+        # these launches share the chip with the critical chain on the main stream: the persistent bf16x3 weight-gradient
+        # workgroups (one 512-register wave per SIMD) leave SIDE_RESERVE_CUS compute units to it
+        L = lib()
+        L.nsdp_debug_set(_ci(9), _ci(SIDE_RESERVE_CUS))
+        try:
+            if fn is None:
+                dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig, out)
+            else:
+                dw, db = fn(dy2, x2, mask, relu_x, b_param is not None, out)
+        finally:
+            L.nsdp_debug_set(_ci(9), _ci(0))
         if out is None or dw is not out[0]:
             for param, g in ((w_param, dw), (b_param, db)):
                 if param is None:

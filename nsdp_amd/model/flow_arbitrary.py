@@ -5,6 +5,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .. import precision
 from .utils import compute_l2_error
 
 
@@ -17,8 +18,15 @@ class FlowArbitrary(nn.Module):
         self.model_deform = model_deform
 
     def forward(self, space_samples_src, surface_samples_src, surface_samples_tgt, cano_handle_sample_mask):
-        space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
-        surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
+        if precision.is_bf16() and precision.canonicalize_f32():
+            # mixed storage (see nsdp_amd/precision.py): the network whose output points feed the second network's geometry
+            # runs in fp32 storage; inputs and outputs are fp32 coordinates in either mode, so there is nothing to cast
+            with precision.storage(torch.float32):
+                space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
+                surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
+        else:
+            space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
+            surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
         deform_in = torch.cat([surf_src2cano, surface_samples_tgt, cano_handle_sample_mask], dim=-1).contiguous()
         return self.model_deform(space_src2cano, deform_in)
 

@@ -113,8 +113,8 @@ def _scatter_cm(grad_out3, idx2, N, idx_obj=None):
     the lists are short; None otherwise (the caller then uses the LDS-table / atomic entry point)."""
     B, C, E = grad_out3.shape
     L = lib()
-    if not (_SCATTER_INVERSE and 0 < N <= 8192 and E <= 64 * N and L.nsdp_scatter_cm_lists_supported(_c_int(B), _c_int(C),
-                                                                                                 _c_int(N), _c_int(E))):
+    if not (_SCATTER_INVERSE and 0 < N <= 32768 and E <= 64 * N and L.nsdp_scatter_cm_lists_supported(_c_int(B), _c_int(C),
+                                                                                                  _c_int(N), _c_int(E))):
         return None
     from . import hip_attention
     # (the cache of the lists lives on the index tensor OBJECT the caller holds across calls, not on a view of it)
@@ -204,6 +204,17 @@ class ThreeInterpolate(Function):
         n = idx.shape[1]
         grad_out = grad_out.contiguous()
         grad = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
+        L = lib()
+        if (_SCATTER_INVERSE and 3 * n <= 64 * m
+                and L.nsdp_three_interpolate_grad_lists_supported(_c_int(B), _c_int(c), _c_int(n), _c_int(m))):
+            # through the inverse lists of the 3-NN index map (cached on the index tensor): no atomics, deterministic
+            from . import hip_attention
+            offsets, entries = hip_attention.inverse_lists(idx, m)
+            with on_device(grad_out):
+                check(L.nsdp_three_interpolate_grad_lists(fptr(grad_out, "grad_out"), fptr(weight, "weight"), iptr(offsets),
+                                                          iptr(entries), _c_int(B), _c_int(c), _c_int(n), _c_int(m), fptr(grad),
+                                                          stream_ptr()), "nsdp_three_interpolate_grad_lists")
+            return grad, torch.zeros_like(idx), torch.zeros_like(weight)
         with on_device(grad_out):
             check(lib().nsdp_three_interpolate_grad(fptr(grad_out, "grad_out"), iptr(idx), fptr(weight), _c_int(B),
                                                     _c_int(c), _c_int(n), _c_int(m), fptr(grad), stream_ptr()),

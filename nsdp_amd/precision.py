@@ -51,6 +51,23 @@ class storage:
         return False
 
 
+# bf16 storage of FlowArbitrary: the first network's output POINTS are what the second network samples, groups and queries
+# at -- its ~9e-3 output error in bf16 storage is amplified ~15x by those discrete selections (tools/bf16_bisect.py,
+# profiles/r4_bf16_bisect.txt: 1.3e-1 against the reference, the same as the fp32 model's own response to bf16-rounded input
+# coordinates; 1.0e-2 with network 1 in fp32 storage).  "f32" keeps network 1 (model_canonicalize) in fp32 storage (its
+# dense layers on the bf16x3 kernels) and only network 2 in bf16: NSDP_BF16_NET1=f32 / set_canonicalize_f32(True).
+_net1_f32 = os.environ.get("NSDP_BF16_NET1", "bf16") == "f32"
+
+
+def canonicalize_f32() -> bool:
+    return _net1_f32
+
+
+def set_canonicalize_f32(flag: bool):
+    global _net1_f32
+    _net1_f32 = bool(flag)
+
+
 def to_storage(t: torch.Tensor) -> torch.Tensor:
     """Cast a feature tensor to the storage precision (no-op when it already is)."""
     return t if t.dtype is _storage else t.to(_storage)

@@ -421,10 +421,15 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
     and bounded loosely."""
     from nsdp_amd import precision
     from nsdp_amd.model import optimizer_factory
-    for name, mtype, l2_bound in (("full_forward", "forward", 5e-2), ("full_arbitrary", "arbitrary", 4e-1)):
+    # Measured (profiles/r4_bf16_bisect.txt): forward.yaml 8.7e-3 -- twice what inputs x (1 + 2^-8) do to the fp32 model
+    # (4.4e-3); arbitrary.yaml 1.3e-1 = network 1's ~9e-3 output error amplified by network 2's FPS / kNN on those points, the
+    # same as the fp32 model's response to bf16-rounded input coordinates (1.4e-1); with network 1 in fp32 storage 1.0e-2.
+    for name, mtype, l2_bound, net1_f32 in (("full_forward", "forward", 2e-2, False), ("full_arbitrary", "arbitrary", 2.5e-1, False),
+                                            ("full_arbitrary", "arbitrary", 2.5e-2, True)):
         fx, cfg, seed, data = fixture_setup(name, mtype)
         model, train_fn, _ = build_product(cfg, seed, DEV)
         s = int(fx["meta_eval_stride"]) if "meta_eval_stride" in fx else 1
+        precision.set_canonicalize_f32(net1_f32)
         with precision.storage(BF):
             model.eval()
             with torch.no_grad():
@@ -432,9 +437,10 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
             model.train()
             _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4}, model.parameters())
             loss = train_fn(model, opt, to_dev(data, DEV), cfg)
+        precision.set_canonicalize_f32(False)
         l2 = l2_err(out[:, ::s], fx["eval_out"])
         ref_loss = float(fx["train_loss"])
-        print(f"\nbf16 storage vs the reference, {name}: eval L2 {l2:.2e}, train loss {loss:.6f} (reference {ref_loss:.6f}, "
-              f"rel {abs(loss - ref_loss) / ref_loss:.2e})")
+        print(f"\nbf16 storage{' (network 1 in fp32)' if net1_f32 else ''} vs the reference, {name}: eval L2 {l2:.2e}, "
+              f"train loss {loss:.6f} (reference {ref_loss:.6f}, rel {abs(loss - ref_loss) / ref_loss:.2e})")
         assert l2 <= l2_bound, (name, l2)
         assert abs(loss - ref_loss) <= 0.05 * ref_loss, (name, loss, ref_loss)

@@ -120,7 +120,11 @@ def test_gather_and_group_ops_match_oracle():
 
 
 @pytest.mark.parametrize("B,C,N,M,NS", [(2, 8, 64, 32, 4), (3, 13, 1000, 257, 3), (2, 33, 20000, 500, 16), (1, 5, 40000, 77, 8),
-                                          (4, 128, 2048, 500, 16)])
+                                          (4, 128, 2048, 500, 16),
+                                          # rows of E = M x NS > 32768 entries do not fit LDS: the sliced list kernel
+                                          # (cursors into ascending lists; the hot point's list is longer than the list
+                                          # build sorts -> its whole-list path), N > 8192 sources, 2 / 4 channels per walk
+                                          (2, 6, 8192, 2048, 32), (1, 9, 16384, 4096, 16), (3, 200, 4096, 1100, 32)])
 def test_gather_and_group_ops_match_oracle_across_kernel_forms(B, C, N, M, NS):
     """The channel-major gathers and their gradients over the shapes that select each kernel form: 16-byte index / output
     vectors or the ragged scalar form (npoint * nsample not a multiple of 4), channel counts that are not a multiple of the

@@ -292,6 +292,29 @@ def test_b16_replayed_train_step_matches_golden():
     _check_train_step(fx, model, train_fn, cfg, data, replay=True)
 
 
+def test_b32_headline_shard_matches_golden_eager_and_replayed():
+    """The headline's own per-GPU shard -- B = 32 shapes of 2048 surface + 8192 query points, exactly what bench.py times --
+    under the reference: eval output, then one train step run EAGERLY and one run as a REPLAY of the captured step (the
+    default launcher of bench.py), each against the imported reference's loss / gradients / BatchNorm statistics / Adam
+    deltas at the same size (tests/golden/b32_forward.npz, oracle/make_golden.py --b32: ~30 GB of CPU temporaries)."""
+    fx, cfg, seed, data = fixture_setup("b32_forward", "forward")
+    assert (int(fx["meta_batch"]), int(fx["meta_ns"]), int(fx["meta_nq"])) == (32, 2048, 8192)
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    model.eval()
+    with torch.no_grad():
+        out = run_forward(model, cfg, to_dev(data, DEV)).cpu().numpy()
+    s = int(fx["meta_eval_stride"])
+    err = np.sqrt(((out[:, ::s].astype(np.float64) - fx["eval_out"]) ** 2).sum(-1))
+    l2 = float(np.sqrt((np.sort(err, axis=1)[:, :-2] ** 2).mean(-1)).max())
+    print(f"\nB = 32 full size, eval L2 vs the reference: {l2:.2e}")
+    assert l2 <= TOL_L2, l2
+    _check_train_step(fx, model, train_fn, cfg, data)
+    del model
+    torch.cuda.empty_cache()
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    _check_train_step(fx, model, train_fn, cfg, data, replay=True)
+
+
 def test_b8_full_shape_eval_matches_oracle():
     """BASELINE config 2: forward TDNet, batch = 8 synthetic shapes, 2048 / 8192 points, fp32 -- product (fused decoder
     kernel AND the layer-by-layer path) vs the CPU oracle on the same seeded inputs, <= 1e-4 L2."""
