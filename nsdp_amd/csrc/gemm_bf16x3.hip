@@ -21,6 +21,8 @@
 //     and the four lane groups of a row read 64 contiguous bytes per load instruction), one
 //     k block ahead, and split on the VALU (v_cvt_pk_bf16_f32 / v_pk_add_f32: 4.5 ops per value) during
 //     the first MFMA steps of the previous k block.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -100,6 +102,27 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
 }
 
+// helpers of the staged epilogue (immediate offsets, counted waits; see linear_bf16x3_kernel)
+template <int OFF>
+__device__ __forceinline__ void lds_read_f4(f32x4 &dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+// (stores are left to the compiler: an inline-asm ds_write / global_store is invisible to its hazard recognizer, which must
+// keep the next VALU write of the DATA registers one or two wait states away from a > 64-bit store -- the hand-written form
+// lost dword 0 of a chunk now and then)
+typedef __attribute__((address_space(3))) f32x4 *lds_f4_ptr;
+template <int OFF>
+__device__ __forceinline__ void lds_write_f4(unsigned addr, f32x4 v) {
+  *reinterpret_cast<lds_f4_ptr>(static_cast<uintptr_t>(addr + static_cast<unsigned>(OFF))) = v;
+}
+template <int CNT>
+__device__ __forceinline__ void lgkm_wait(f32x4 &v) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT));
+}
+__device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *uniform_base) {
+  *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(uniform_base) + byte_off) = v;
+}
+
 // WV waves per workgroup: 4 (one per SIMD, MT up to 4 row tiles: 512 registers per lane) or 8 (two per SIMD, MT <= 2:
 // 256 registers per lane -- the second wave of a SIMD issues MFMAs while the first splits, stores or waits)
 // XREG: raw activations through registers even without a mask (frees the 32 KiB X staging: at 13 n tiles two 4-wave
@@ -116,8 +139,33 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
   // in LDS next to the weights and keeps the register path.
   constexpr bool kXLds = PRE != 1 && !XREG;
-  __shared__ __attribute__((aligned(16))) u32x4 wbuf[KBM][NT * 3 * 64];
+  // LDS: [weight buffer 0][epilogue extension][weight buffer 1] (streaming form) + the activation staging.
+  // STAGED EPILOGUE (streaming form): the output tile of a wave goes to HBM through LDS -- accumulators (lane = row li, four
+  // columns) are written row-major into a per-wave piece of the weight buffer that the tile's last k block has just released
+  // plus the extension, read back as consecutive 16-byte chunks and stored so that one store instruction covers KiB-sized runs
+  // of the output rows instead of 16 rows x 64 B.  Ablation with contiguous (wrong) store addresses: -15 % on the 200- and
+  // 256-wide launches; WRITE_SIZE was 1.14 x the output bytes because every other row's 64-byte segment straddled two
+  // memory blocks (800-byte rows).  The extension is what the CU's LDS has left (two workgroups per CU: 80 KiB each).
+  constexpr int kWTile = NT * 3 * 64;                                        // u32x4 per weight buffer
+  constexpr int kXTile = kXLds ? 2 * WV * MT * 2 * 64 : 1;                   // u32x4 of activation staging
+  constexpr bool kTwoPerCu = XREG || (NT <= 8 && WV == 4);                   // (launch_x3: these run two workgroups per CU)
+  constexpr int kCap = (kTwoPerCu ? 80 : 160) * 64;                          // LDS budget in u32x4
+  constexpr int kBiasLds = NT * 4;                                           // u32x4: the bias vector, staged once per workgroup
+  constexpr int kExtFree = kCap - KBM * kWTile - kXTile - kBiasLds;
+  constexpr bool kStage = !WRES && kExtFree >= 0;                            // (resident weights fill the LDS: direct epilogue)
+  constexpr int kExtWant = WV * NT * 64 - kWTile;                            // whole 16-row tiles for every wave
+  constexpr int kExt = !kStage ? 0 : (kExtWant < 0 ? 0 : (kExtFree < 0 ? 0 : (kExtWant < kExtFree ? kExtWant : kExtFree)));
+  constexpr int kPerWave = (kWTile + kExt) / WV;                             // u32x4 of epilogue staging per wave
+  constexpr int kTppMax = kPerWave / 64 < NT ? kPerWave / 64 : NT;           // 16-column tiles per pass (1 KiB per tile)
+  constexpr int kPasses = kStage ? (NT + kTppMax - 1) / kTppMax : 1;
+  constexpr int kTpp = (NT + kPasses - 1) / kPasses;
+  static_assert(!kStage || kTppMax >= 1, "epilogue staging: no room for a 16 x 16 tile per wave");
+  __shared__ __attribute__((aligned(16))) u32x4 wlds[KBM * kWTile + kExt];
   __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? WV : 1][kXLds ? MT * 2 * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float bias_lds[kStage ? NT * 16 : 4];      // (zeros without a bias: read unconditionally)
+  // buffer b of the weight ring: the extension sits between buffers 0 and 1, so that whichever of the two is free forms one
+  // contiguous region with it
+  auto wbuf_at = [&](int b) -> u32x4 * { return wlds + b * kWTile + (b >= 1 ? kExt : 0); };
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, g = lane >> 4;
@@ -149,10 +197,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     const int pieces = ntiles * 3;
     for (int q = wave; q < pieces; q += WV)
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wlane + ((static_cast<long long>(kb) * pieces + q) << 10)),
-                                       (lds_ptr_t)(&wbuf[buf][q * 64]), 16, 0, 0);
+                                       (lds_ptr_t)(wbuf_at(buf) + q * 64), 16, 0, 0);
   };
-  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wbuf[0][lane])));
+  const unsigned lds0 = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wlds[lane])));
+  const unsigned ldsw = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&wlds[0])));
+  const unsigned ldsb = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&bias_lds[0])));
   constexpr unsigned kBufBytes = NT * 3 * 1024;
+  constexpr unsigned kExtBytes = kExt * 16;
 
   // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 16 half + 4 g ..)
   f32x4 raw[kXLds ? 1 : MT][2], rawm[kXLds ? 1 : MT][2];
@@ -164,7 +215,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         int ko = kb * 32 + 16 * hf + 4 * g;     // the four lane groups of a row read 64 contiguous bytes per instruction
         ko = ko < K ? ko : (K - 4);     // past the row end: re-read in-row data (the packed weights are zero there)
         if constexpr (kXLds) {
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(x[mt] + ko), (lds_ptr_t)(&xbuf[xb][wave][(mt * 2 + hf) * 64]), 16, 0, 0);
+          const float *src = x[mt] + ko;
+          // (ablation knob 1024, timing only, wrong results: every DMA instruction reads ONE contiguous KiB of the wave's rows
+          // instead of 16 rows x 64 B -- what the address pattern costs: 14 % of the 200-wide launch.  Eight rows x 128 B per
+          // instruction, built and measured in round 4, bought nothing: at an 800-byte row pitch a 128-byte run straddles two
+          // cache lines, so an instruction still touches 16 lines)
+          if (p.dbg & 1024) src = x[0] - li * K + (((kb * MT * 2 + mt * 2 + hf) * 256) % 6144) + lane * 4;
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(&xbuf[xb][wave][(mt * 2 + hf) * 64]), 16, 0, 0);
         } else {
           xload(raw[mt][hf], x[mt] + ko);
           if constexpr (PRE == 1) xload(rawm[mt][hf], m[mt] + ko);
@@ -207,6 +264,9 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   };
 
   Planes cur, nxt;
+  if constexpr (kStage) {
+    for (int c = threadIdx.x; c < NT * 16; c += WV * 64) bias_lds[c] = (p.bias && c < p.N) ? p.bias[c] : 0.f;      // visible after the prologue's barrier
+  }
   // stagger the persistent workgroups by eighths of a tile time (~640 cycles per k block): all of them run the same
   // program on the same amount of work, and without it their epilogue store bursts hit HBM at the same moments
   // (measured: -7 % time on the 1.8 M-row layers).  Only worth it when a workgroup has several tiles to go.
@@ -297,7 +357,8 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         if (x_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
-      const unsigned wl_addr = lds0 + (WRES ? static_cast<unsigned>(kb) : buf) * kBufBytes;
+      const unsigned wsel = WRES ? static_cast<unsigned>(kb) : buf;
+      const unsigned wl_addr = lds0 + wsel * kBufBytes + (wsel >= 1u ? kExtBytes : 0u);
       u32x4 wh, wm, wl;
       lds_read<0>(wh, wl_addr); lds_read<1024>(wm, wl_addr); lds_read<2048>(wl, wl_addr);
       lds_wait(wh, wm, wl);
@@ -397,7 +458,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       float4 bias4[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bias4[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) {
+      if (p.bias && (!kStage || (p.dbg & (8192 | 16384 | 32768)))) {      // (the staged form takes the bias from LDS)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int col = nt * 16 + 4 * g_e;
@@ -428,12 +489,77 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             }
           } else {
             if (p.dbg & 64) __builtin_nontemporal_store(vv, reinterpret_cast<f32x4 *>(p.Y + row * N + col));
+            else if (p.dbg & 2048)      // (ablation, timing only: one contiguous KiB per store instruction)
+              *reinterpret_cast<f32x4 *>(p.Y + row0 * N + (((mt * NT + nt) * 256) % 6144) + (li_e + 16 * g_e) * 4) = vv;
             else *reinterpret_cast<f32x4 *>(p.Y + row * N + col) = vv;
           }
         }
       };
+      // ---- staged form: accumulators -> LDS (row-major, 16 rows x tiles-of-this-pass) -> consecutive 16-byte chunks -> HBM ----
+      auto staged = [&](auto has_omask) {
+        const unsigned buf_last = (gs - 1u) & 1u;               // the weight buffer this tile's last k block read: free now
+        const unsigned ebase = ldsw + (buf_last ? kBufBytes : 0u) + static_cast<unsigned>(wave) * (kPerWave * 16u);
+        // (everything below derives from the opaque per-tile copies li_e / g_e: LICM would otherwise carry the chunk -> (row,
+        // column) arithmetic of every read-back instruction across the whole k loop, in registers the 8-wave forms do not have)
+        const unsigned lane_e = static_cast<unsigned>(li_e + 16 * g_e);
+        const unsigned rd = ebase + lane_e * 16u;                                  // chunk i of a pass: + 1024 i
+        float *ytile = p.Y + row0 * N;                                             // (wave-uniform: SGPR base of the stores)
+        const int rows_left = p.M - row0 < MT * 16 ? static_cast<int>(p.M - row0) : MT * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          static_for<0, kPasses>([&](auto PI) {
+            constexpr int pass = decltype(PI)::value;
+            constexpr int nt0 = pass * kTpp;
+            constexpr int ntn = (NT - nt0) < kTpp ? (NT - nt0) : kTpp;        // tiles of this pass = KiB staged per 16 rows
+            constexpr unsigned pitch = ntn * 64u;                              // bytes per staged row
+            const unsigned wr = ebase + static_cast<unsigned>(li_e) * pitch + static_cast<unsigned>(g_e) * 16u;
+            f32x4 bvv[ntn];
+            static_for<0, ntn>([&](auto TI) {
+              constexpr int t = decltype(TI)::value;
+              lds_read_f4<(nt0 + t) * 64>(bvv[t], ldsb + static_cast<unsigned>(16 * g_e));
+            });
+            static_for<0, ntn>([&](auto TI) {
+              constexpr int t = decltype(TI)::value;
+              constexpr int nt = nt0 + t;
+              lgkm_wait<ntn - 1 - t>(bvv[t]);
+              f32x4 v = acc[mt][nt] + bvv[t];
+              if (p.relu_out) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
+              }
+              if (decltype(has_omask)::value) {
+                long long row = row0 + mt * 16 + li_e;
+                row = row < p.M ? row : (p.M - 1);
+                const int col = nt * 16 + 4 * g_e;
+                const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + row * N + (col + 4 <= N ? col : (N - 4)));
+                v[0] = om.x > 0.f ? v[0] : 0.f; v[1] = om.y > 0.f ? v[1] : 0.f; v[2] = om.z > 0.f ? v[2] : 0.f; v[3] = om.w > 0.f ? v[3] : 0.f;
+              }
+              lds_write_f4<t * 64>(wr, v);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order)
+            f32x4 back[ntn];
+            static_for<0, ntn>([&](auto CI) {
+              constexpr int i = decltype(CI)::value;
+              lds_read_f4<i * 1024>(back[i], rd);
+            });
+            const int valid = (N - nt0 * 16) * 4 < static_cast<int>(pitch) ? (N - nt0 * 16) * 4 : static_cast<int>(pitch);   // bytes of a staged row that exist
+            static_for<0, ntn>([&](auto CI) {
+              constexpr int i = decltype(CI)::value;
+              const unsigned f = static_cast<unsigned>(i) * 1024u + lane_e * 16u;
+              const unsigned r = f / pitch, cb = f - r * pitch;
+              const unsigned off = ((static_cast<unsigned>(mt) * 16u + r) * static_cast<unsigned>(N) + static_cast<unsigned>(nt0) * 16u) * 4u + cb;
+              lgkm_wait<ntn - 1 - i>(back[i]);
+              if (static_cast<int>(cb) < valid && static_cast<int>(mt * 16 + r) < rows_left) store_f4(off, back[i], ytile);
+            });
+          });
+        }
+      };
       auto epilogue = [&](auto has_omask) {
         const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
+        if constexpr (kStage) {
+          staged(has_omask);
+          return;
+        }
         if (full_rows) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
@@ -453,6 +579,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     X3_T(t_e1);
     X3_ADD(3, t_e0, t_e1);
     if (!next_tile) break;
+    if constexpr (kStage) {
+      // the next tile's first k block stages weights into the buffer the epilogue pieces live in: every wave must have
+      // read its piece back
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
     tile += stride;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { xa[mt] = xn[mt]; ma[mt] = mn[mt]; }
@@ -803,7 +936,9 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
   // persistent workgroups, one per CU: the next tile's first k blocks are prefetched under the current tile's
   // last MFMAs and epilogue
-  const long long slots = static_cast<long long>(nsdp::num_cus()) * wgs_per_cu;
+  // (experiment knob, read once: NSDP_X3_RESERVE_CUS = compute units left free for the other stream's kernels)
+  static const int reserve = getenv("NSDP_X3_RESERVE_CUS") ? atoi(getenv("NSDP_X3_RESERVE_CUS")) : 0;
+  const long long slots = static_cast<long long>(nsdp::num_cus() - reserve) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
   NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "");
   hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, KBM>), dim3(grid), dim3(WV * 64), 0, st, p);

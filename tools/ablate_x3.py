@@ -37,7 +37,7 @@ for M, N, K in shapes:
     wp, _ = hl.pack_weight_x3(w, True, False)
     print(f"linear_bf16x3 {M} x {K} -> {N}   ({4*M*(N+K)/1e6:.0f} MB, {2*M*N*K/1e9:.0f} GFLOP)")
     x = torch.relu(x)       # (ReLU-sparse operands, as in the step)
-    for bits, name in [(0, "full"), (8, "no stores"), (1, "no weight DMA"), (9, "neither"), (64, "nontemporal stores"), (32, "one wave per SIMD"),
+    for bits, name in [(0, "full (staged epilogue)"), (8192, "direct epilogue (16 rows x 64 B stores)"), (8, "no stores"), (1, "no weight DMA"), (9, "neither"), (64, "nontemporal stores"), (32, "one wave per SIMD"),
                        (1024, "contiguous X DMA (1 KiB / instr)"), (2048, "contiguous stores (1 KiB / instr)"),
                        (1024 + 2048, "contiguous X DMA + stores"), (1024 + 2048 + 1, "contiguous X + stores, no weight DMA"),
                        (512, "1 of 3 LDS weight reads"), (512 + 1, "1 of 3 LDS reads, no weight DMA"), (512 + 9, "1 of 3 LDS reads, no DMA, no stores")]:
