@@ -406,7 +406,7 @@ def main():
             if not is_eval:
                 capturable_adam(optimizer)
             if is_eval or reducer is None:
-                graph = GraphedStep(run).capture(warmup=3)
+                graph = GraphedStep(run, weights_change=not is_eval).capture(warmup=3)      # (inference: frozen weights)
                 run = graph
                 graph_note = "graph replay, multi-stream executor: " + json.dumps(graph.info)
             else:

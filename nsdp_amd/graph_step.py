@@ -55,8 +55,13 @@ def set_lr(optimizer: torch.optim.Optimizer, value: float):
 
 
 class GraphedStep:
-    def __init__(self, fn, max_streams: int | None = None):
+    def __init__(self, fn, max_streams: int | None = None, weights_change: bool = True):
+        """``weights_change`` (default True: a train step, or any step between whose replays the parameters may be updated):
+        the weight-pack caches are declared stale before the capture -- their rebuild becomes a node of the graph -- and
+        after every replay.  False is for inference over FROZEN weights only: the packs current at capture time are used
+        by every replay (no repack per replay: 0.8 ms of a 5 ms eval step); whoever changes the weights must capture anew."""
         self.fn = fn
+        self.weights_change = bool(weights_change)
         # (NSDP_GRAPH_STREAMS: A/B knob; 1 = everything on the caller's stream.  Measured at B = 32: 1 stream 46.5 ms = the sum
         # of the isolated kernel times, 2 streams 43.6, 3-6 streams 43.9; bf16 27.5 / 25.1 / 25.4)
         self.max_streams = int(max_streams if max_streams is not None else os.environ.get("NSDP_GRAPH_STREAMS", "2"))
@@ -83,7 +88,8 @@ class GraphedStep:
         # step: a replay runs no Python -- a pack that happened to be valid at capture time (an eval forward just before)
         # would otherwise be frozen into every replay.
         from . import hip_linear
-        hip_linear.invalidate_weight_packs()
+        if self.weights_change:
+            hip_linear.invalidate_weight_packs()
         graph = torch.cuda.CUDAGraph(keep_graph=True)
         # thread_local: other threads of the process (the RCCL watchdog of a data-parallel job polls events) may keep
         # making HIP calls while this thread captures
@@ -109,8 +115,9 @@ class GraphedStep:
         # not fire, while the packs -- rebuilt at the HEAD of the replayed step -- are one optimizer step older than the
         # parameters afterwards.  Declare them stale, so that the next EAGER forward (validate_on_batch, an odd-shape batch
         # of GraphedTrainOnBatch) repacks; the next replay repacks anyway.  One integer increment.
-        from . import hip_linear
-        hip_linear.invalidate_weight_packs()
+        if self.weights_change:
+            from . import hip_linear
+            hip_linear.invalidate_weight_packs()
         return self._out
 
     def close(self):

@@ -20,6 +20,10 @@ python bench.py --workload forward_eval --no-cpu-baseline > gpurun_out/${tag}_be
 python bench.py --dtype bf16 --no-cpu-baseline > gpurun_out/${tag}_bench_forward_bf16.json 2>/dev/null
 python bench.py --dtype bf16 --workload arbitrary_train --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary_bf16.json 2>/dev/null
 python bench.py --dtype bf16 --batch 8 --no-cpu-baseline > gpurun_out/${tag}_bench_b8_bf16.json 2>/dev/null
+# config 3 with FlowArbitrary's first network in fp32 storage (eval L2 against the reference 1e-2 instead of 1.3e-1)
+python bench.py --dtype bf16 --workload arbitrary_train --canonicalize-f32 --no-cpu-baseline > gpurun_out/${tag}_bench_arbitrary_bf16_net1f32.json 2>/dev/null
+# every (shape, flags) the step sends to the dense kernels, timed in isolation: the algorithmic bytes of `roofline` are this table's
+python tools/profile_linear_shapes.py > gpurun_out/${tag}_linear_shapes.txt 2>/dev/null
 # the self-launch path: two ranks on this one GPU over gloo (the RCCL path needs a multi-GPU node: driver-run)
 python bench.py --gpus 2 --backend gloo --batch 8 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${tag}_bench_2ranks_gloo.json
 cd /tmp && export TMPDIR=/tmp

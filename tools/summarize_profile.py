@@ -116,7 +116,8 @@ if os.path.exists(sq_path):
 for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "bench_dense_inference.json",
              "bench_forward_eval.json", "bench_forward_bf16.json", "bench_arbitrary_bf16.json", "bench_b8_bf16.json",
              "bench_2ranks_gloo.json", "bench_default_eager.json", "bench_b8_eager.json", "bench_forward_bf16_eager.json",
-             "bench_arbitrary_bf16_eager.json", "bench_force_reducer_nccl.json"):
+             "bench_arbitrary_bf16_eager.json", "bench_force_reducer_nccl.json", "bench_arbitrary_bf16_net1f32.json",
+             "linear_shapes.txt"):
     src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
     if os.path.exists(src) and open(src).read().strip():
         open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
