@@ -103,22 +103,23 @@ __device__ __forceinline__ void lds_wait(u32x4 &a, u32x4 &b, u32x4 &c) {
 }
 
 // helpers of the staged epilogue (immediate offsets, counted waits; see linear_bf16x3_kernel)
+typedef __attribute__((address_space(3))) f32x4 *lds_f4_ptr;
+// (the epilogue's LDS traffic is plain C++: under register pressure the compiler parks the destination of a hand-issued
+// ds_read in an AGPR right after the asm statement -- a copy of a register whose load is still in flight -- and later restores
+// the stale copy; its own loads it waits for correctly)
 template <int OFF>
 __device__ __forceinline__ void lds_read_f4(f32x4 &dst, unsigned addr) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+  dst = *reinterpret_cast<lds_f4_ptr>(static_cast<uintptr_t>(addr + static_cast<unsigned>(OFF)));
 }
 // (stores are left to the compiler: an inline-asm ds_write / global_store is invisible to its hazard recognizer, which must
 // keep the next VALU write of the DATA registers one or two wait states away from a > 64-bit store -- the hand-written form
 // lost dword 0 of a chunk now and then)
-typedef __attribute__((address_space(3))) f32x4 *lds_f4_ptr;
 template <int OFF>
 __device__ __forceinline__ void lds_write_f4(unsigned addr, f32x4 v) {
   *reinterpret_cast<lds_f4_ptr>(static_cast<uintptr_t>(addr + static_cast<unsigned>(OFF))) = v;
 }
 template <int CNT>
-__device__ __forceinline__ void lgkm_wait(f32x4 &v) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(CNT));
-}
+__device__ __forceinline__ void lgkm_wait(f32x4 &) {}      // (the compiler waits for its own LDS loads)
 __device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *uniform_base) {
   *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(uniform_base) + byte_off) = v;
 }
@@ -504,6 +505,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         const unsigned lane_e = static_cast<unsigned>(li_e + 16 * g_e);
         const unsigned rd = ebase + lane_e * 16u;                                  // chunk i of a pass: + 1024 i
         float *ytile = p.Y + row0 * N;                                             // (wave-uniform: SGPR base of the stores)
+        const float *mtile = decltype(has_omask)::value ? p.out_mask + row0 * N : nullptr;
         const int rows_left = p.M - row0 < MT * 16 ? static_cast<int>(p.M - row0) : MT * 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -513,6 +515,23 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             constexpr int ntn = (NT - nt0) < kTpp ? (NT - nt0) : kTpp;        // tiles of this pass = KiB staged per 16 rows
             constexpr unsigned pitch = ntn * 64u;                              // bytes per staged row
             const unsigned wr = ebase + static_cast<unsigned>(li_e) * pitch + static_cast<unsigned>(g_e) * 16u;
+            const int valid = (N - nt0 * 16) * 4 < static_cast<int>(pitch) ? (N - nt0 * 16) * 4 : static_cast<int>(pitch);   // bytes of a staged row that exist
+            // chunk i of the read-back: where it goes in the output, whether it exists -- and, with an output mask, the mask
+            // chunk from the SAME offset of the mask tensor: loaded here in KiB-sized row runs, in flight during the LDS round
+            // trip (the direct epilogue fetched it as 16 rows x 64 B per tile, one wait each)
+            unsigned off[ntn];
+            bool live[ntn];
+            f32x4 om[decltype(has_omask)::value ? ntn : 1];
+            static_for<0, ntn>([&](auto CI) {
+              constexpr int i = decltype(CI)::value;
+              const unsigned f = static_cast<unsigned>(i) * 1024u + lane_e * 16u;
+              const unsigned r = f / pitch, cb = f - r * pitch;
+              off[i] = ((static_cast<unsigned>(mt) * 16u + r) * static_cast<unsigned>(N) + static_cast<unsigned>(nt0) * 16u) * 4u + cb;
+              live[i] = static_cast<int>(cb) < valid && static_cast<int>(mt * 16 + r) < rows_left;
+              if constexpr (decltype(has_omask)::value) {
+                om[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(mtile) + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+            });
             f32x4 bvv[ntn];
             static_for<0, ntn>([&](auto TI) {
               constexpr int t = decltype(TI)::value;
@@ -527,13 +546,6 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
               }
-              if (decltype(has_omask)::value) {
-                long long row = row0 + mt * 16 + li_e;
-                row = row < p.M ? row : (p.M - 1);
-                const int col = nt * 16 + 4 * g_e;
-                const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + row * N + (col + 4 <= N ? col : (N - 4)));
-                v[0] = om.x > 0.f ? v[0] : 0.f; v[1] = om.y > 0.f ? v[1] : 0.f; v[2] = om.z > 0.f ? v[2] : 0.f; v[3] = om.w > 0.f ? v[3] : 0.f;
-              }
               lds_write_f4<t * 64>(wr, v);
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations complete in order)
@@ -542,14 +554,15 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
               constexpr int i = decltype(CI)::value;
               lds_read_f4<i * 1024>(back[i], rd);
             });
-            const int valid = (N - nt0 * 16) * 4 < static_cast<int>(pitch) ? (N - nt0 * 16) * 4 : static_cast<int>(pitch);   // bytes of a staged row that exist
             static_for<0, ntn>([&](auto CI) {
               constexpr int i = decltype(CI)::value;
-              const unsigned f = static_cast<unsigned>(i) * 1024u + lane_e * 16u;
-              const unsigned r = f / pitch, cb = f - r * pitch;
-              const unsigned off = ((static_cast<unsigned>(mt) * 16u + r) * static_cast<unsigned>(N) + static_cast<unsigned>(nt0) * 16u) * 4u + cb;
               lgkm_wait<ntn - 1 - i>(back[i]);
-              if (static_cast<int>(cb) < valid && static_cast<int>(mt * 16 + r) < rows_left) store_f4(off, back[i], ytile);
+              f32x4 v = back[i];
+              if constexpr (decltype(has_omask)::value) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = om[i][c] > 0.f ? v[c] : 0.f;
+              }
+              if (live[i]) store_f4(off[i], v, ytile);
             });
           });
         }

@@ -45,6 +45,11 @@ X3_CASES = [  # (M, K, N, bias, residual, mask, out_mask, relu_in, relu_out)
     (256 * 256 * 3 + 77, 200, 200, False, False, False, False, True, False),     # no bias, ReLU prologue
     (256 * 192 * 3 + 5, 256, 256, True, False, False, False, False, False),      # 16 n tiles, 4 waves x 3 row tiles
     (256 * 256 * 3 + 31, 96, 104, True, False, False, False, False, True),       # resident-weight form (<= 128 wide)
+    # the masked (register-path) forms with several row blocks per workgroup, and the output mask through the staged epilogue
+    (128 * 512 * 2 + 50, 128, 128, False, False, True, True, False, False),      # dX of a relu_in layer: mask + out_mask, 8 tiles
+    (192 * 256 * 2 + 77, 200, 200, False, True, True, False, False, False),      # mask + residual, 13 tiles, 3 row tiles per wave
+    (128 * 256 * 3 + 9, 256, 256, True, False, True, True, False, False),        # 16 tiles, mask + out_mask
+    (256 * 256 * 2 + 33, 200, 200, False, False, False, True, False, False),     # out_mask alone, 8-wave form
 ]
 
 
