@@ -42,10 +42,21 @@ def _defines(line, reg):
     return bool(m) and int(m.group(1)) <= reg <= int(m.group(2))
 
 
-def _parked_loads(body, lo, hi):
+def _parked_loads(body, lo, hi, hand_issued_only=False):
     """v_accvgpr_write instructions in body[lo:hi] whose source VGPR was last written by a hand-issued load
     (global_load / ds_read): a register the compiler must not copy before the matching s_waitcnt.  Accumulator
-    shuffles (v_accvgpr_read -> v_accvgpr_write) are the compiler's own business and are fine."""
+    shuffles (v_accvgpr_read -> v_accvgpr_write) are the compiler's own business and are fine.
+    ``hand_issued_only``: count only loads inside an inline-asm block (;;#ASMSTART .. ;;#ASMEND) -- outside the MFMA region
+    the compiler's OWN loads may be parked (it waits for them first); a parked asm load is how the staged epilogue of
+    round 4 once used bias values that had not arrived."""
+    in_asm, flag = False, []
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        flag.append(in_asm)
     bad = []
     for i in range(lo, hi):
         m = re.match(r"\s*v_accvgpr_write_b32 a\d+, v(\d+)", body[i])
@@ -54,8 +65,11 @@ def _parked_loads(body, lo, hi):
         reg = int(m.group(1))
         for j in range(i - 1, -1, -1):
             if _defines(body[j], reg):
-                if body[j].strip().startswith(("global_load", "ds_read")):
-                    bad.append(body[i].strip() + "   <- " + body[j].strip())
+                if body[j].strip().startswith(("global_load", "ds_read")) and (flag[j] or not hand_issued_only):
+                    # (parked AFTER its wait is fine: look for the s_waitcnt between the load and the copy)
+                    waited = any("s_waitcnt" in body[k] and ("lgkmcnt(0)" in body[k] or "vmcnt(0)" in body[k]) for k in range(j + 1, i))
+                    if not (hand_issued_only and waited):
+                        bad.append(body[i].strip() + "   <- " + body[j].strip())
                 break
     return bad
 
@@ -93,6 +107,8 @@ def test_nothing_is_spilled_inside_the_mfma_regions():
                 # legitimate VGPR -> AGPR moves)
                 bad += [l.strip() for l in region if "scratch_store" in l]
                 bad += _parked_loads(body, mf[0], mf[-1])
+                # ... and hand-issued loads anywhere else in the kernel (prologue, epilogue)
+                bad += _parked_loads(body, 0, mf[0], hand_issued_only=True) + _parked_loads(body, mf[-1], len(body), hand_issued_only=True)
             assert not bad, (src, lines[a][:80], bad[:3])
             checked += 1
     assert checked >= 20
