@@ -80,7 +80,8 @@ int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const i
 
 /* three_interpolate_grad (interpolate_gpu.cu:116-143) without atomics: offsets / entries = nsdp_knn_invert of the (B, n, 3)
  * index map flattened to E = 3 n entries per shape (entry e = 3 j + t); grad_points[b][c][s] = sum over the list of s of
- * grad_out[b][c][e / 3] * weight[b][e], in list order (deterministic).  A row of n floats must fit LDS. */
+ * grad_out[b][c][e / 3] * weight[b][e], in list order (deterministic).  Rows of up to 8192 targets are staged whole, longer
+ * ones in slices (cursors into the ascending lists); m <= 32768 sources. */
 int nsdp_three_interpolate_grad_lists_supported(int B, int c, int n, int m);
 int nsdp_three_interpolate_grad_lists(const float *grad_out, const float *weight, const int32_t *offsets,
                                       const int32_t *entries, int B, int c, int n, int m, float *grad_points, void *stream);

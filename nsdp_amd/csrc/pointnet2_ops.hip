@@ -246,19 +246,25 @@ __global__ __launch_bounds__(kBig) void three_interp_lists_kernel(const float *_
 // and more): the row is staged in SLICES of `slice` entries; every list is ascending, so the part of a list that falls into
 // a slice is a contiguous run -- a thread keeps a cursor per owned target (TP of them, in registers, next to TP x CH
 // accumulators), advances it through the slice and writes each target once at the end.  No atomics, one pass over grad_out.
-template <int CH, int TP, bool PREFETCH>
+// W3 (three_interpolate_grad for rows longer than LDS): the lists index the (n, 3) weight / index map flattened to 3 E entries --
+// entry e = 3 j + t contributes grad_out[.., j] * weight[e]; the staged rows hold E = n floats and a slice of `slice` of them
+// covers entries [3 e0, 3 (e0 + len)).
+template <int CH, int TP, bool PREFETCH, bool W3 = false>
 __global__ __launch_bounds__(kBig) void scatter_cm_lists_sliced_kernel(const float *__restrict__ grad_out,
                                                                        const int32_t *__restrict__ offsets,
                                                                        const int32_t *__restrict__ entries, int C, int N, int E,
-                                                                       int slice, float *__restrict__ grad_points) {
+                                                                       int slice, float *__restrict__ grad_points,
+                                                                       const float *__restrict__ weight = nullptr) {
   extern __shared__ float table[];      // [CH][slice]
   constexpr int kDone = 0x7fffffff;
+  constexpr int kMul = W3 ? 3 : 1;      // list entries per staged element
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * CH;
   const int cn = C - c0 < CH ? C - c0 : CH;
   const float *src = grad_out + (static_cast<long long>(b) * C + c0) * E;
   const int32_t *off = offsets + static_cast<long long>(b) * (N + 1);
-  const int32_t *ent = entries + static_cast<long long>(b) * E;
+  const int32_t *ent = entries + static_cast<long long>(b) * E * kMul;
+  const float *wb = W3 ? weight + static_cast<long long>(b) * E * kMul : nullptr;
   float *o0 = grad_points + (static_cast<long long>(b) * C + c0) * N;
   for (int s0 = 0; s0 < N; s0 += kBig * TP) {      // (one round for N <= kBig * TP targets)
     // per owned target: cursor, list end, the NEXT entry already in a register (the walk is a chain of dependent loads;
@@ -326,16 +332,17 @@ __global__ __launch_bounds__(kBig) void scatter_cm_lists_sliced_kernel(const flo
         }
       }
       __syncthreads();
-      const int e1 = e0 + len;
+      const int e1 = (e0 + len) * kMul;
       bool more = true;
       while (more) {                               // rounds: every target with an entry in this slice consumes ONE
         more = false;
 #pragma unroll
         for (int t = 0; t < TP; ++t) {
           if (nxt[t] < e1) {
-            const int e = nxt[t] - e0;
+            const int e = nxt[t] / kMul - e0;
+            const float w = W3 ? wb[nxt[t]] : 1.f;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) acc[t][c] += table[(c < cn ? c : 0) * slice + e];
+            for (int c = 0; c < CH; ++c) acc[t][c] += W3 ? table[(c < cn ? c : 0) * slice + e] * w : table[(c < cn ? c : 0) * slice + e];
             ++cur[t];
             nxt[t] = cur[t] < end[t] ? ent[cur[t]] : kDone;
             more = true;
@@ -347,9 +354,10 @@ __global__ __launch_bounds__(kBig) void scatter_cm_lists_sliced_kernel(const flo
         if (unsorted[t]) {
           for (int q = cur[t]; q < end[t]; ++q) {
             const int e = ent[q];
-            if (e >= e0 && e < e1) {
+            if (e >= e0 * kMul && e < e1) {
+              const float w = W3 ? wb[e] : 1.f;
 #pragma unroll
-              for (int c = 0; c < CH; ++c) acc[t][c] += table[(c < cn ? c : 0) * slice + (e - e0)];
+              for (int c = 0; c < CH; ++c) acc[t][c] += table[(c < cn ? c : 0) * slice + (e / kMul - e0)] * w;
             }
           }
         }
@@ -941,19 +949,37 @@ int nsdp_scatter_cm_lists(const float *grad_out, const int32_t *offsets, const i
 }
 
 int nsdp_three_interpolate_grad_lists_supported(int B, int c, int n, int m) {
-  return B > 0 && B <= 65535 && c > 0 && m > 0 && m <= 32768 && n > 0 && 4LL * n <= kLdsTableMax;
+  return B > 0 && B <= 65535 && c > 0 && m > 0 && m <= 32768 && n > 0 && n <= (1 << 28);
 }
 
 int nsdp_three_interpolate_grad_lists(const float *grad_out, const float *weight, const int32_t *offsets,
                                       const int32_t *entries, int B, int c, int n, int m, float *grad_points, void *stream) {
   if (static_cast<long long>(B) * c * m <= 0) return 0;
   NSDP_REQUIRE(grad_out && weight && offsets && entries && grad_points, "three_interpolate_grad_lists: null pointer");
-  NSDP_REQUIRE(nsdp_three_interpolate_grad_lists_supported(B, c, n, m),
-               "three_interpolate_grad_lists: a row of n=%d floats must fit LDS (<= %d bytes), m <= 32768", n, kLdsTableMax);
+  NSDP_REQUIRE(nsdp_three_interpolate_grad_lists_supported(B, c, n, m), "three_interpolate_grad_lists: unsupported shape (m <= 32768)");
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kScatterRows, st, 0.0,
                           4.0 * (static_cast<double>(B) * n * (6 + c) + static_cast<double>(B) * c * m));
   const long long row_bytes = 4LL * n;
+  // rows that leave room for < 4 channels per workgroup (n > 8192): the sliced form -- the list entries and weights of a walk are
+  // shared by 4 (m <= 8192) or 2 channels, the rows pass through LDS in slices
+  if (row_bytes > kLdsTableBytes / 2) {
+    const bool many = m > 8 * kBig;
+    const int ch = many ? 2 : 4;
+    const int slice = kLdsTableMax / 4 / ch;
+    const dim3 grid((c + ch - 1) / ch, B);
+    NSDP_TRACE("three_interpolate_grad_sliced<%d,%d>", ch, many ? 16 : 8);
+    if (many) {
+      if (!allow_big_lds<&scatter_cm_lists_sliced_kernel<2, 16, false, true>>()) return NSDP_EINVAL;
+      hipLaunchKernelGGL((scatter_cm_lists_sliced_kernel<2, 16, false, true>), grid, dim3(kBig), static_cast<size_t>(kLdsTableMax), st,
+                         grad_out, offsets, entries, c, m, n, slice, grad_points, weight);
+    } else {
+      if (!allow_big_lds<&scatter_cm_lists_sliced_kernel<4, 8, true, true>>()) return NSDP_EINVAL;
+      hipLaunchKernelGGL((scatter_cm_lists_sliced_kernel<4, 8, true, true>), grid, dim3(kBig), static_cast<size_t>(kLdsTableMax), st,
+                         grad_out, offsets, entries, c, m, n, slice, grad_points, weight);
+    }
+    return nsdp::launch_status("scatter_cm_lists_sliced_kernel<w3>");
+  }
   int ch = static_cast<int>((row_bytes <= kLdsTableBytes ? kLdsTableBytes : kLdsTableMax) / row_bytes);
   ch = ch >= 8 ? 8 : ch >= 4 ? 4 : ch >= 2 ? 2 : 1;
   while (ch > 1 && static_cast<long long>(B) * ((c + ch - 1) / ch) < 2LL * nsdp::num_cus()) ch >>= 1;

@@ -83,3 +83,20 @@ def restore_model(model, snap, optimizer=None):
                     if torch.is_tensor(v):
                         v.zero_()
     hip_linear.invalidate_weight_packs()      # (weights rewritten behind the optimizer's back)
+
+
+def nondeterministic_knobs():
+    """Variant knobs of the library that put floating-point atomics back into the train step (A/B forms kept for comparison):
+    under them two runs of a step differ in rounding, and the tests that hold the replay EQUAL to the eager step do not apply."""
+    from nsdp_amd import hip_attention, pointnet2_utils
+    out = []
+    if not hip_attention.ONEHOT_SCATTER_F32:
+        out.append("NSDP_ONEHOT_SCATTER_F32=0")
+    if hip_attention.INVERSE_LISTS == "0":
+        out.append("NSDP_INVERSE_LISTS=0")
+    if not pointnet2_utils._SCATTER_INVERSE:
+        out.append("NSDP_SCATTER_ROWS=atomic")
+    from nsdp_amd.model import ops
+    if not ops.FUSE_DPOS:           # (d(pos) summed by the atomic form of attn_pre_bwd)
+        out.append("NSDP_FUSE_DPOS=0")
+    return out

@@ -150,7 +150,9 @@ def test_gather_and_group_ops_match_oracle_across_kernel_forms(B, C, N, M, NS):
     np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * max(1.0, float(np.abs(want).max())))
 
 
-@pytest.mark.parametrize("B,c,m,n", [(2, 9, 1300, 700), (3, 16, 100, 501), (1, 3, 40000, 1000)])
+@pytest.mark.parametrize("B,c,m,n", [(2, 9, 1300, 700), (3, 16, 100, 501), (1, 3, 40000, 1000),
+                                     # rows of n > 8192 targets: the sliced list form (4 / 2 channels per walk of the lists)
+                                     (2, 6, 4096, 16384), (1, 5, 16384, 20000)])
 def test_three_interpolate_kernel_forms(B, c, m, n):
     from nsdp_amd import pointnet2_utils as pu
     feats = synth.normal(51, "f", (B, c, m))
