@@ -179,6 +179,18 @@ int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, co
                            const float *mask, const float *out_mask, float *Y, long long M, int N, int K,
                            int relu_in, int relu_out, void *stream);
 
+/* nsdp_linear_bf16x3_f32 plus a GATHERED difference of two small tables, added in the kernel's epilogue:
+ *   Y[r] = post( X[r] W^T + b + (gq[r / g_div] - gk[(r / g_rows_per_shape) * g_nsrc + gidx[r]]) )
+ * gq (.., N), gk (shapes * g_nsrc, N) fp32, gidx (M) int32 in [0, g_nsrc).  With X = the hidden layer of a position-encoding
+ * MLP, gq = the queries, gk = the key table and gidx = the flattened neighbour indices this IS the logits' input
+ * u = q_i - k_j + delta(rel_ij) of a vector-attention block (reference model/encoder/blocks.py:104-116, decoder/blocks.py:72-84)
+ * -- the attn_pre pass (read pos, write u) and the pos tensor itself disappear.  The sum is rounded exactly like the separate
+ * pass rounds it: fl(fl(X W^T + b) + fl(gq - gk)).  M and both tables' element counts < 2^31; relu_in must be 0. */
+int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *bias, const float *gq, int g_div, const float *gk,
+                                  const int32_t *gidx, int g_rows_per_shape, int g_nsrc, float *Y, long long M, int N, int K,
+                                  int relu_in, int relu_out, void *stream);
+
+
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.
  * Deterministic (two-stage
@@ -320,6 +332,15 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        const int32_t *idx, const float *a_g, const float *v_g, const float *y,
                        const float *residual, const float *lse, int B, int n, int N, int k, int d,
                        float *da, float *dpos, float *dvf, float *da_g, float *dv_g, void *stream);
+
+/* nsdp_attn_post_fwd / _bwd for a block whose `pos` was never materialised: `u` = q_i - k_j + pos (the output of
+ * nsdp_linear_bf16x3_gather_f32), `vk` = the table v + k, qsub (B, n, d) = the queries: values = u + vk[idx] - qsub_i.
+ * Gradients are those of the original graph: dpos (= w dy) and dvf (= its scatter, or NULL: the caller scatters). */
+int nsdp_attn_post_fwd_q(const float *a, const float *vk, const float *u, const int32_t *idx, const float *qsub,
+                         const float *residual, int B, int n, int N, int k, int d, float *y, float *lse, void *stream);
+int nsdp_attn_post_bwd_q(const float *dy, const float *a, const float *vk, const float *u, const int32_t *idx, const float *qsub,
+                         const float *y, const float *residual, const float *lse, int B, int n, int N, int k, int d,
+                         float *da, float *dpos, float *dvf, void *stream);
 
 /* nsdp_attn_post_bwd for a block whose value scatter (dvf) is done by the caller (nsdp_scatter_rows_onehot_*): da, dpos and
  * the global-token gradients with NO atomics -- a workgroup owns centres of one shape, partial sums are combined in a

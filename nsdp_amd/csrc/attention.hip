@@ -246,7 +246,8 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const T
                                                             const T *__restrict__ a_g,
                                                             const T *__restrict__ v_g,
                                                             const T *__restrict__ residual,
-                                                            T *__restrict__ y, float *__restrict__ lse) {
+                                                            T *__restrict__ y, float *__restrict__ lse,
+                                                            const T *__restrict__ qsub = nullptr) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const long long total = static_cast<long long>(s.B) * s.n;
@@ -258,6 +259,9 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const T
     const T *vfb = HAS_V ? vf + static_cast<long long>(b) * s.N * s.d + 4 * L.cq : nullptr;
     const int32_t *ip = idx + pt * s.k;
     const long long e0 = pt * s.k * s.d + 4 * L.cq;
+    // (qsub: `pos` holds u = q_i - k_j + pos and `vf` the table v + k -- the values are then u + (v + k)[idx] - q_i; see
+    // nsdp_linear_bf16x3_gather_f32)
+    const float4 qs = (HAS_V && qsub) ? ld4(qsub + pt * s.d + 4 * L.cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 m, l, acc;
     if (has_g) {
       m = ld4(a_g + static_cast<long long>(b) * s.d + 4 * L.cq);
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_post_fwd_kernel(AttnShape s, const T
       float4 sv = ld4(pos + e0 + static_cast<long long>(j) * s.d);
       if (HAS_V) {
         const float4 vv = ld4(vfb + static_cast<long long>(ip[j]) * s.d);
-        sv.x += vv.x; sv.y += vv.y; sv.z += vv.z; sv.w += vv.w;
+        sv.x += vv.x - qs.x; sv.y += vv.y - qs.y; sv.z += vv.z - qs.z; sv.w += vv.w - qs.w;
       }
       NSDP_ONLINE_STEP(x) NSDP_ONLINE_STEP(y) NSDP_ONLINE_STEP(z) NSDP_ONLINE_STEP(w)
     }
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
     const T *__restrict__ pos, const int32_t *__restrict__ idx, const T *__restrict__ a_g,
     const T *__restrict__ v_g, const T *__restrict__ y, const T *__restrict__ residual,
     const float *__restrict__ lse, T *__restrict__ da, T *__restrict__ dpos,
-    float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g) {
+    float *__restrict__ dvf, float *__restrict__ da_g, float *__restrict__ dv_g, const T *__restrict__ qsub = nullptr) {
   const Lane L = lane_setup(s);
   if (!L.active) return;
   const int lpp = s.d >> 2, cq = L.cq;
@@ -326,6 +330,10 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
       yb.x -= r.x; yb.y -= r.y; yb.z -= r.z; yb.w -= r.w;
     }
     const Quad Lse = ldQ<ST>(lse + pt * s.d, cq, lpp);
+    if (HAS_V && qsub) {      // the attention output without the "- q_i" of the values (see attn_post_fwd_kernel): yb + q_i
+      const Quad qs = ldQ<ST>(qsub + pt * s.d, cq, lpp);
+      yb.x += qs.x; yb.y += qs.y; yb.z += qs.z; yb.w += qs.w;
+    }
 #pragma unroll 2
     for (int j = 0; j < s.k; ++j) {
       const long long rj = r0 + static_cast<long long>(j) * s.d;
@@ -837,7 +845,8 @@ int attn_pre_bwd_t(const T *du, const int32_t *idx, int B, int n, int N, int k, 
 
 template <typename T>
 int attn_post_fwd_t(const T *a, const T *vf, const T *pos, const int32_t *idx, const T *a_g, const T *v_g,
-                    const T *residual, int B, int n, int N, int k, int d, T *y, float *lse, void *stream) {
+                    const T *residual, int B, int n, int N, int k, int d, T *y, float *lse, void *stream,
+                    const T *qsub = nullptr) {
   constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   if (static_cast<long long>(B) * n * d <= 0) return 0;
@@ -848,14 +857,15 @@ int attn_post_fwd_t(const T *a, const T *vf, const T *pos, const int32_t *idx, c
   nsdp::prof::Scope scope(nsdp::prof::kAttnFwd, st, 0.0,
                           kEl * (rows(s) * (2.0 * d + 1) + static_cast<double>(B) * (2.0 * n + (vf ? N : 0)) * d));
   const bool has_v = vf != nullptr;
-  NSDP_ATTN_LAUNCH_V(attn_post_fwd_kernel, has_v, s, a, vf, pos, idx, a_g, v_g, residual, y, lse);
+  NSDP_REQUIRE(!qsub || (has_v && !a_g), "attn_post_fwd: qsub goes with a value table and no global token");
+  NSDP_ATTN_LAUNCH_V(attn_post_fwd_kernel, has_v, s, a, vf, pos, idx, a_g, v_g, residual, y, lse, qsub);
   return nsdp::launch_status("attn_post_fwd_kernel");
 }
 
 template <typename T>
 int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const int32_t *idx, const T *a_g, const T *v_g,
                     const T *y, const T *residual, const float *lse, int B, int n, int N, int k, int d, T *da, T *dpos,
-                    float *dvf, float *da_g, float *dv_g, void *stream) {
+                    float *dvf, float *da_g, float *dv_g, void *stream, const T *qsub = nullptr) {
   constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, 0, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
@@ -876,7 +886,8 @@ int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const in
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
                           kEl * (rows(s) * (4.0 * d + 1) + static_cast<double>(B) * (3.0 * n + (vf ? 2.0 * N : 0)) * d));
   const bool has_v = vf != nullptr;
-  if (lds_table_fits(s) && has_v && dvf) {
+  NSDP_REQUIRE(!qsub || (has_v && !a_g), "attn_post_bwd: qsub goes with a value table and no global token");
+  if (lds_table_fits(s) && has_v && dvf && !qsub) {
     const size_t lds = static_cast<size_t>(N) * d * 4;
     if (const int rc = allow_big_lds(attn_post_bwd_lds_kernel<T, true>, lds, "attn_post_bwd_lds_kernel")) return rc;
     AttnShape sl = s;
@@ -890,12 +901,12 @@ int attn_post_bwd_t(const T *dy, const T *a, const T *vf, const T *pos, const in
   if (has_v && !dvf) {
     NSDP_TRACE("attn_post_bwd_stream");
     hipLaunchKernelGGL((attn_post_bwd_kernel<T, true, false>), attn_grid(s), dim3(256), 0, st, s, dy, a, vf, pos, idx, a_g, v_g,
-                       y, residual, lse, da, dpos, dvf, da_g, dv_g);
+                       y, residual, lse, da, dpos, dvf, da_g, dv_g, qsub);
     return nsdp::launch_status("attn_post_bwd_kernel");
   }
   NSDP_TRACE("attn_post_bwd_atomic");
   NSDP_ATTN_LAUNCH_V(attn_post_bwd_kernel, has_v, s, dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, da, dpos,
-                     dvf, da_g, dv_g);
+                     dvf, da_g, dv_g, qsub);
   return nsdp::launch_status("attn_post_bwd_kernel");
 }
 
@@ -984,6 +995,20 @@ int nsdp_attn_post_bwd(const float *dy, const float *a, const float *vf, const f
                        float *dvf, float *da_g, float *dv_g, void *stream) {
   return attn_post_bwd_t<float>(dy, a, vf, pos, idx, a_g, v_g, y, residual, lse, B, n, N, k, d, da, dpos, dvf, da_g, dv_g,
                                 stream);
+}
+
+// The same two with `pos` holding u = q_i - k_j + pos (the output of nsdp_linear_bf16x3_gather_f32: pos itself is never
+// materialised) and `vf` holding the table v + k: the values are u + (v + k)[idx] - qsub_i.  qsub (B, n, d).  No global token
+// (the decoder's one-query-per-shape form folds q into the table on the host instead).
+int nsdp_attn_post_fwd_q(const float *a, const float *vk, const float *u, const int32_t *idx, const float *qsub,
+                         const float *residual, int B, int n, int N, int k, int d, float *y, float *lse, void *stream) {
+  return attn_post_fwd_t<float>(a, vk, u, idx, nullptr, nullptr, residual, B, n, N, k, d, y, lse, stream, qsub);
+}
+int nsdp_attn_post_bwd_q(const float *dy, const float *a, const float *vk, const float *u, const int32_t *idx, const float *qsub,
+                         const float *y, const float *residual, const float *lse, int B, int n, int N, int k, int d,
+                         float *da, float *dpos, float *dvf, void *stream) {
+  return attn_post_bwd_t<float>(dy, a, vk, u, idx, nullptr, nullptr, y, residual, lse, B, n, N, k, d, da, dpos, dvf, nullptr,
+                                nullptr, stream, qsub);
 }
 
 // bf16-storage variants: every activation tensor (q, kf, vf, pos, u, a, y, residual, a_g, v_g and the gradients du, dy,

@@ -62,6 +62,12 @@ struct X3Params {
   int relu_in, relu_out;
   int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores, bit 9 one LDS weight
             // read per step instead of three -- wrong results, timing only
+  // gathered accumulator init (nsdp_linear_bf16x3_gather_f32): Y[r] starts from gq[r / g_div] - gk[(r / g_rps) * g_nsrc + gidx[r]]
+  // (rows of two small L2-resident tables) -- the "q_i - k_j" of a vector-attention block added by the position-encoding MLP's
+  // last layer itself, so that u = q - k + pos comes out of the GEMM and the attn_pre pass (read pos, write u) disappears
+  const float *gq, *gk;
+  const int32_t *gidx;
+  int g_div, g_rps, g_nsrc;
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -133,8 +139,9 @@ __device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *unif
 // drift apart and one wave's epilogue stores sit under the other waves' MFMA steps (the streaming form re-fetches the
 // planes L2 -> LDS for every 256-row tile: as many bytes as the HBM traffic, and its per-k-block barrier keeps all waves
 // in the same phase).
-template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, bool GATHER = false>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
+  static_assert(!GATHER || PRE == 0, "the gathered addend belongs to the plain-prologue forms");
   constexpr bool WRES = KBM > 2;
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
@@ -319,7 +326,23 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     f32x4 acc[MT][NT];
     // TRANSPOSED product D = W X^T: lane (li, g) of accumulator (mt, nt) holds row row0 + 16 mt + li, columns
     // 16 nt + 4 g .. + 3 -- four consecutive floats of Y, so residual / bias / out_mask / Y move as float4
-    if (p.residual) {  // residual add fused as the accumulator's initial value
+    // GATHER: Y[r] += gq[r / g_div] - gk[(r / g_rps) * g_nsrc + gidx[r]], added in the EPILOGUE (an accumulator that started
+    // from q - k, a few units, would round each of the ~40 small MFMA addends of the position encoding at the difference's
+    // ulp: measured 7x the rms error of the separate pass).  Only the two row offsets (floats) of this lane's rows are
+    // fetched here -- the index load is the head of a dependent chain -- and ride through the k loop.
+    unsigned gqo[GATHER ? MT : 1], gko[GATHER ? MT : 1];
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        long long row = row0 + mt * 16 + li_t;
+        row = row < p.M ? row : (p.M - 1);
+        const unsigned r32 = static_cast<unsigned>(row);                       // (host contract: M, table elements < 2^31)
+        gqo[mt] = (r32 / static_cast<unsigned>(p.g_div)) * static_cast<unsigned>(N);
+        gko[mt] = ((r32 / static_cast<unsigned>(p.g_rps)) * static_cast<unsigned>(p.g_nsrc) + static_cast<unsigned>(p.gidx[row])) *
+                  static_cast<unsigned>(N);
+      }
+    }
+    if (!GATHER && p.residual) {  // residual add fused as the accumulator's initial value
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         long long row = row0 + mt * 16 + li_t;
@@ -466,7 +489,19 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           bias4[nt] = *reinterpret_cast<const float4 *>(p.bias + (col + 4 <= N ? col : (N - 4)));
         }
       }
-      auto otile = [&](int nt, auto has_omask, auto guarded) {
+      // GATHER: the addend fragments of n tile nt (this lane's rows, its four columns)
+      auto gload = [&](int nt, f32x4 *ga, f32x4 *gb) {
+        if constexpr (GATHER) {
+          int col = nt * 16 + 4 * g_e;
+          col = col + 4 <= N ? col : (N - 4);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            ga[mt] = *reinterpret_cast<const f32x4 *>(p.gq + gqo[mt] + col);
+            gb[mt] = *reinterpret_cast<const f32x4 *>(p.gk + gko[mt] + col);
+          }
+        }
+      };
+      auto otile = [&](int nt, auto has_omask, auto guarded, const f32x4 *ga = nullptr, const f32x4 *gb = nullptr) {
         const int col = nt * 16 + 4 * g_e;
         const bool cv = col + 4 <= N;
         const int colc = cv ? col : (N - 4);
@@ -477,6 +512,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           const bool rv = !decltype(guarded)::value || row < p.M;
           const long long rowc = rv ? row : (p.M - 1);
           float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
+          if constexpr (GATHER) {
+            const f32x4 d = ga[mt] - gb[mt];
+            v.x += d[0]; v.y += d[1]; v.z += d[2]; v.w += d[3];
+          }
           if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
           if (decltype(has_omask)::value) {
             const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
@@ -532,6 +571,16 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
                 om[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(mtile) + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
               }
             });
+            f32x4 gav[GATHER ? ntn : 1], gbv[GATHER ? ntn : 1];      // gathered addend, fragment layout: in flight over the bias reads
+            if constexpr (GATHER) {
+              static_for<0, ntn>([&](auto TI) {
+                constexpr int t = decltype(TI)::value;
+                int col = (nt0 + t) * 16 + 4 * g_e;
+                col = col + 4 <= N ? col : (N - 4);
+                gav[t] = *reinterpret_cast<const f32x4 *>(p.gq + gqo[mt] + col);
+                gbv[t] = *reinterpret_cast<const f32x4 *>(p.gk + gko[mt] + col);
+              });
+            }
             f32x4 bvv[ntn];
             static_for<0, ntn>([&](auto TI) {
               constexpr int t = decltype(TI)::value;
@@ -542,6 +591,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
               constexpr int nt = nt0 + t;
               lgkm_wait<ntn - 1 - t>(bvv[t]);
               f32x4 v = acc[mt][nt] + bvv[t];
+              if constexpr (GATHER) v += gav[t] - gbv[t];
               if (p.relu_out) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -571,6 +621,20 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
         if constexpr (kStage) {
           staged(has_omask);
+          return;
+        }
+        if constexpr (GATHER) {      // the next n tile's addend loads fly while this one is stored
+          f32x4 ga[2][MT], gb[2][MT];
+          gload(0, ga[0], gb[0]);
+          static_for<0, NT>([&](auto I) {
+            constexpr int nt = decltype(I)::value;
+            if (nt * 16 < N) {
+              if constexpr (nt + 1 < NT) {
+                if ((nt + 1) * 16 < N) gload(nt + 1, ga[(nt + 1) & 1], gb[(nt + 1) & 1]);
+              }
+              otile(nt, has_omask, std::true_type{}, ga[nt & 1], gb[nt & 1]);
+            }
+          });
           return;
         }
         if (full_rows) {
@@ -943,7 +1007,7 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   nsdp::pack::x3_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
-template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, bool GATHER = false>
 void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
@@ -953,12 +1017,13 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   static const int reserve = getenv("NSDP_X3_RESERVE_CUS") ? atoi(getenv("NSDP_X3_RESERVE_CUS")) : 0;
   const long long slots = static_cast<long long>(nsdp::num_cus() - reserve) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
-  NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "");
-  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, KBM>), dim3(grid), dim3(WV * 64), 0, st, p);
+  NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "",
+             GATHER ? " gather" : "");
+  hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, KBM, GATHER>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
 // (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
-template <int NT>
+template <int NT, bool GATHER = false>
 int launch_x3(const X3Params &p, hipStream_t st) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
@@ -976,23 +1041,23 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   // (96 KiB + 64 KiB of activation staging = the CU's 160 KiB): one 8-wave workgroup per CU, no barrier in the k loop.
   // nsdp_debug_set(6, 256) switches back to the streaming two-workgroup form (A/B).
   if (pre != 1 && NT <= 8 && p.K <= 128 && !(g_x3_dbg & 256)) {
-    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 8, false, 4>(p, st);
+    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 8, false, 4, GATHER>(p, st);
     else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 8, false, 4>(p, st);
   } else if (pre == 1 && NT <= 8 && two_waves) launch_x3_pre<2, (NT <= 8 ? NT : 8), 1, 4, true>(p, st, 2);
   else if (pre == 1) launch_x3_pre<MT1, NT, 1, 4>(p, st);
   else if (NT <= 8 && two_waves) {
-    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4>(p, st, 2);
+    if (pre == 0) launch_x3_pre<2, (NT <= 8 ? NT : 8), 0, 4, false, 2, GATHER>(p, st, 2);
     else launch_x3_pre<2, (NT <= 8 ? NT : 8), 2, 4>(p, st, 2);
   } else if (NT == 13 && two_waves && p.M <= (1 << 19)) {
     // 13 n tiles, up to ~0.5 M rows: the same two-workgroups-per-CU form, made to fit (2 x 78 KiB) by taking the raw
     // activations through registers instead of the 32 KiB LDS staging: 8-19 % faster there, on par at 1.8 M rows
-    if (pre == 0) launch_x3_pre<2, 13, 0, 4, true>(p, st, 2);
+    if (pre == 0) launch_x3_pre<2, 13, 0, 4, true, 2, GATHER>(p, st, 2);
     else launch_x3_pre<2, 13, 2, 4, true>(p, st, 2);
   } else if (two_waves) {
-    if (g_x3_dbg & 128) {
+    if ((g_x3_dbg & 128) && !GATHER) {
       if (pre == 0) launch_x3_ap<13, 0>(p, st);
       else launch_x3_ap<13, 2>(p, st);
-    } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8>(p, st);
+    } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8, false, 2, GATHER>(p, st);
     else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
   } else {
     constexpr int MT0 = NT >= 16 ? 3 : 4;
@@ -1007,9 +1072,9 @@ int launch_x3(const X3Params &p, hipStream_t st) {
       narrow = !(g_x3_dbg & 4096) && r2 * 108 < r3 * 100;
     }
     if (narrow) {
-      if (pre == 0) launch_x3_pre<2, NT, 0, 4>(p, st);
+      if (pre == 0) launch_x3_pre<2, NT, 0, 4, false, 2, GATHER>(p, st);
       else launch_x3_pre<2, NT, 2, 4>(p, st);
-    } else if (pre == 0) launch_x3_pre<MT0, NT, 0, 4>(p, st);
+    } else if (pre == 0) launch_x3_pre<MT0, NT, 0, 4, false, 2, GATHER>(p, st);
     else launch_x3_pre<MT0, NT, 2, 4>(p, st);
   }
   return nsdp::launch_status("linear_bf16x3_kernel");
@@ -1066,6 +1131,31 @@ int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, co
   if (nt <= 8) return launch_x3<8>(p, st);
   if (nt <= 13) return launch_x3<13>(p, st);
   return launch_x3<16>(p, st);
+}
+
+int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *bias, const float *gq, int g_div, const float *gk,
+                                  const int32_t *gidx, int g_rows_per_shape, int g_nsrc, float *Y, long long M, int N, int K,
+                                  int relu_in, int relu_out, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X && Wp && Y && gq && gk && gidx, "linear_bf16x3_gather: null pointer");
+  NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3_gather: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
+  NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3_gather: N=%d must be a multiple of 4 and <= 256", N);
+  NSDP_REQUIRE(M < (1LL << 31) && g_div > 0 && g_rows_per_shape > 0 && g_nsrc > 0, "linear_bf16x3_gather: bad row maps");
+  NSDP_REQUIRE(!relu_in, "linear_bf16x3_gather: no input ReLU (the addend belongs to the plain-prologue kernels)");
+  {   // the kernel addresses both tables with 32-bit element offsets
+    const long long q_rows = (M + g_div - 1) / g_div, k_rows = ((M + g_rows_per_shape - 1) / g_rows_per_shape) * g_nsrc;
+    NSDP_REQUIRE(q_rows * N < (1LL << 31) && k_rows * N < (1LL << 31), "linear_bf16x3_gather: tables beyond 2^31 elements");
+  }
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
+                 reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gq) | reinterpret_cast<uintptr_t>(gk)) & 15) == 0,
+               "linear_bf16x3_gather: all operands must be 16-byte aligned");
+  X3Params p{X, Wp, bias, nullptr, nullptr, nullptr, Y, M, N, K, relu_in, relu_out, g_x3_dbg, gq, gk, gidx, g_div, g_rows_per_shape, g_nsrc};
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 4) return launch_x3<4, true>(p, st);
+  if (nt <= 8) return launch_x3<8, true>(p, st);
+  if (nt <= 13) return launch_x3<13, true>(p, st);
+  return launch_x3<16, true>(p, st);
 }
 
 }  // extern "C"

@@ -227,10 +227,24 @@ class _AttnPost(torch.autograd.Function):
     """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
 
     @staticmethod
-    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None, pre=None):
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None, pre=None, sub=None):
+        # sub = (kf, q), constants of this node: `pos` holds u = q_i - k_j + pos (hip_linear's init_gather: pos itself was never
+        # materialised).  The values v_j + pos_ij are then u + (v + k)[idx] - q_i: the kernels get the table v + k (minus q
+        # when it is one vector per shape) in place of vf and, for per-point queries, q as `qsub`.  Gradients are the original
+        # graph's: d(pos) = w dy, d(vf) = its scatter, nothing for k / q from this node.
         ctx.link = link
         ctx.inv = inv
         a, pos = _c(a), _c(pos)
+        qsub = None
+        if sub is not None:
+            kf_c, q_c = sub
+            if vf is None or a.dtype is not torch.float32:
+                raise ValueError("attn_post(sub=): needs a value table and fp32 storage")
+            per_shape = q_c.shape[1] == 1 and a.shape[1] != 1
+            vf = vf + kf_c - q_c if per_shape else vf + kf_c
+            qsub = None if per_shape else _c(q_c)
+            if qsub is not None and a_g is not None:
+                raise ValueError("attn_post(sub=): per-point queries and a global token do not combine")
         vf = None if vf is None else _c(vf)
         a_g = None if a_g is None else _c(a_g)
         v_g = None if v_g is None else _c(v_g)
@@ -244,17 +258,22 @@ class _AttnPost(torch.autograd.Function):
             y = torch.empty((B, n, d), dtype=dt, device=a.device)
             lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
             with on_device(a):
-                check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
-                                                    _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
-                                                    _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse),
-                                                    stream_ptr()), "nsdp_attn_post_fwd")
-        ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse)
+                if qsub is not None:
+                    check(lib().nsdp_attn_post_fwd_q(fptr(a, "a"), fptr(vf, "vk"), fptr(pos, "u"), iptr(idx, "idx"), fptr(qsub, "q"),
+                                                     optptr(residual), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), fptr(y), fptr(lse),
+                                                     stream_ptr()), "nsdp_attn_post_fwd_q")
+                else:
+                    check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
+                                                        _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
+                                                        _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse),
+                                                        stream_ptr()), "nsdp_attn_post_fwd")
+        ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse, qsub)
         ctx.dims = (B, n, N, k, d)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, vf, pos, idx, a_g, v_g, y, residual, lse = ctx.saved_tensors
+        a, vf, pos, idx, a_g, v_g, y, residual, lse, qsub = ctx.saved_tensors
         B, n, N, k, d = ctx.dims
         dy = _c(dy)
         dev = dy.device
@@ -282,6 +301,11 @@ class _AttnPost(torch.autograd.Function):
                                                         _ci(n), _ci(N), _ci(k), _ci(d), _p(da, dt), _p(dpos, dt), optptr(da_g),
                                                         optptr(dv_g), fptr(ws), ctypes.c_size_t(nbytes), stream_ptr()),
                       "nsdp_attn_post_bwd_det")
+        elif qsub is not None:
+            with on_device(dy):
+                check(lib().nsdp_attn_post_bwd_q(fptr(dy, "dy"), fptr(a), fptr(vf), fptr(pos), iptr(idx), fptr(qsub), fptr(y),
+                                                 optptr(residual), fptr(lse), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), fptr(da),
+                                                 fptr(dpos), optptr(dvf), stream_ptr()), "nsdp_attn_post_bwd_q")
         else:
             with on_device(dy):
                 check(_fn("nsdp_attn_post_bwd", dt)(_p(dy, dt, "dy"), _p(a, dt), _p(vf, dt), _p(pos, dt), iptr(idx),
@@ -306,7 +330,7 @@ class _AttnPost(torch.autograd.Function):
             dpos = None                               # travels as the dX GEMM's residual; attn_pre reports the total
         elif link is not None and ctx.needs_input_grad[2]:
             link.dpos, dpos = dpos, None              # attn_pre's backward adds d(u) and reports the sum
-        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None, None
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None, None, None
 
 
 def pos_grad_link():
@@ -342,7 +366,7 @@ def attn_pre(q, kf, pos, idx, link=None, inv=None, precomputed=None):
     return _AttnPre.apply(q, kf, pos, idx, link, inv, precomputed)
 
 
-def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None, precomputed=None):
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None, precomputed=None, sub=None):
     if a.dtype is torch.bfloat16 and not NATIVE_BF16:
         return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link, inv).to(torch.bfloat16)
-    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv, precomputed)
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv, precomputed, sub)

@@ -85,6 +85,28 @@ def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
     return y
 
 
+def _fwd_x3_gather(x2, wp, N, b, gather, relu_in, relu_out):
+    """_fwd_x3 plus gq[r / g_div] - gk[(r / rows_per_shape) * nsrc + gidx[r]], added in the kernel's epilogue
+    (nsdp_linear_bf16x3_gather_f32); gather = (gq [., N], g_div, gk [shapes * nsrc, N], gidx [M] int32, rows_per_shape, nsrc)."""
+    gq, g_div, gk, gidx, rps, nsrc = gather
+    M, K = x2.shape
+    if gq.shape[-1] != N or gk.shape[-1] != N or gidx.numel() != M:
+        raise ValueError("init_gather: table width / index count do not match the layer")
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_bf16x3_gather_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), fptr(gq, "gq"),
+                                                  _ci(int(g_div)), fptr(gk, "gk"), ctypes.c_void_p(gidx.data_ptr()),
+                                                  _ci(int(rps)), _ci(int(nsrc)), fptr(y), _ll(M), _ci(N), _ci(K),
+                                                  _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),
+              "nsdp_linear_bf16x3_gather_f32")
+    return y
+
+
+def gather_init_ok(M, N, K):
+    """Can a layer of this shape take ``init_gather`` (it needs the bf16x3 kernel)?"""
+    return _x3_ok(M, N, K) and M < 2 ** 31 and not precision.is_bf16()
+
+
 def wgrad_out(out, N, K, want_db, device):
     """(dw, db, accumulate) for a weight-gradient launch: fresh tensors, or -- `out` = (dW [N,K], db [N] or None) of a
     matching shape -- those buffers with the kernel's accumulate flag (the sum lands in them, no add kernel)."""
@@ -494,7 +516,9 @@ class InputGradSum:
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                pre=None):
+                pre=None, init_gather=None):
+        # init_gather: (gq, g_div, gk, gidx, rows_per_shape, nsrc), constants of this node -- a gathered difference of two small
+        # tables joins the output in the epilogue (see _fwd_x3_gather); whoever owns the tables accounts for their gradients
         # pre: this layer's output, already computed by a fused forward kernel (hip_decoder.attn_train_forward): the node
         # only records what its backward needs -- no launch
         # bw (backward contract of a Linear -> ReLU -> Linear pair whose middle tensor has no other reader):
@@ -530,6 +554,10 @@ class _LinearFn(torch.autograd.Function):
         wpt = _packs(w, owner, kind_t, True)[1] if want_t else None
         if pre is not None:
             y = pre.reshape(M, N)
+        elif init_gather is not None:
+            if kind != "x3" or res2 is not None:
+                raise ValueError("init_gather needs a layer on the bf16x3 kernel (gather_init_ok) without a residual")
+            y = _fwd_x3_gather(x2, wp, N, b, init_gather, relu_in, relu_out)
         else:
             y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
@@ -581,7 +609,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -615,7 +643,7 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False, premasked=False, mask_dx=False, precomputed=None):
+           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -635,8 +663,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
-        if precomputed is not None:
-            raise ValueError("precomputed outputs belong to fp32 storage")
+        if precomputed is not None or init_gather is not None:
+            raise ValueError("precomputed outputs / init_gather belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -662,5 +690,6 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed)
+                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather)
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed,
+                           init_gather)

@@ -111,13 +111,14 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # dense layers
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
-           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None) -> torch.Tensor:
+           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None,
+           init_gather=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
-                             precomputed=precomputed)
+                             precomputed=precomputed, init_gather=init_gather)
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -163,6 +164,21 @@ def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = Fa
 # point-transformer vector attention
 # ---------------------------------------------------------------------------------------------
 FUSE_DPOS = os.environ.get("NSDP_FUSE_DPOS", "1") != "0"     # (A/B knob: 0 = attn_pre_bwd accumulates d(pos) itself)
+# u = q_i - k_j + delta(rel_ij) straight out of the position-encoding MLP's last GEMM (its accumulators start from the
+# gathered q - k rows: hip_linear's init_gather): no attn_pre pass, and `pos` is never materialised -- the values
+# v_j + pos_ij are rebuilt from u inside attn_post (hip_attention._AttnPost, sub=).  fp32 storage, layers on the bf16x3
+# kernel.  NSDP_FUSE_PRE=0: the separate attn_pre pass (A/B knob).
+FUSE_PRE = os.environ.get("NSDP_FUSE_PRE", "1") != "0"
+
+
+class PosAsU:
+    """What vector_attention hands back as `pos` when it never materialised it: y = q1_i - k1_j + pos (the values the first
+    attention's GEMM produced; autograd-wise y IS pos) and the constants (q1, k1) that turn it back into pos."""
+    __slots__ = ("y", "q", "kf")
+
+    def __init__(self, y, q, kf):
+        self.y, self.q, self.kf = y, q, kf
+
 
 def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None):
     """sum_j softmax_j[gamma(q_i - kf[idx_ij] + delta(rel_ij))] * (vf[idx_ij] + delta(rel_ij)) (+ residual),
@@ -178,6 +194,37 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         from .. import hip_decoder
         if hip_decoder.TRAIN_FUSED and hip_decoder.attn_train_supported(rel, q, kf, a_g, fc_delta, fc_gamma):
             return _vector_attention_fused_forward(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual, a_g, v_g)
+    if isinstance(pos, PosAsU):
+        # second attention over the same index set (set abstraction): pos = y - q1_i + k1_j, so
+        # u2 = q2_i - k2_j + pos = (q2 - q1)_i - (k2 - k1)_j + y, and the values are y + (v2 + k1)_j - q1_i
+        y, q1, k1 = pos.y, pos.q, pos.kf
+        link = hip_attention.pos_grad_link() if y.requires_grad else None
+        if link is not None and FUSE_DPOS:
+            link.grad_sum = hip_linear.InputGradSum()
+        inv = hip_attention.backward_lists(idx, y.shape[1], kf.shape[1], y.shape[-1])
+        u = hip_attention.attn_pre(q - q1, kf - k1, y, idx, link, inv)
+        logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
+        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv, sub=(k1, q1))
+        return out, pos
+    if (pos is None and q is not None and FUSE_PRE and not precision.is_bf16() and not PAIR_MASK
+            and hip_linear.gather_init_ok(rel.shape[0] * rel.shape[1] * rel.shape[2], fc_delta[2].weight.shape[0],
+                                          fc_delta[2].weight.shape[1])):
+        B, n, k = idx.shape
+        d = fc_delta[2].weight.shape[0]
+        per_shape = q.shape[1] == 1 and n != 1
+        qd, kd = q.detach(), kf.detach()
+        gather = (qd.reshape(-1, d).contiguous(), (n * k) if per_shape else k, kd.reshape(-1, d).contiguous(),
+                  idx.reshape(-1), n * k, kf.shape[1])
+        h = linear(rel, fc_delta[0], relu=True)
+        y = linear(h, fc_delta[2], init_gather=gather)            # values: u; for autograd this node is `pos`
+        link = hip_attention.pos_grad_link() if y.requires_grad else None
+        if link is not None and FUSE_DPOS:
+            link.grad_sum = hip_linear.InputGradSum()
+        inv = hip_attention.backward_lists(idx, n, kf.shape[1], d, qb=per_shape)
+        u = hip_attention.attn_pre(q, kf, y, idx, link, inv, precomputed=y.detach())      # records the backward, launches nothing
+        logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
+        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv, sub=(kd, qd))
+        return out, PosAsU(y, qd, kd)
     if pos is None:
         pos = mlp2(rel, fc_delta)                              # 2 dense layers on [B*n*k] rows
     if q is None:

@@ -237,3 +237,85 @@ def test_decoder_attention_backward_is_bit_reproducible_and_matches_the_atomic_p
     for x, e in zip(r1, ra):
         assert x.shape == e.shape
         assert float((x - e).abs().max()) <= 3e-5 * (float(e.abs().max()) + 1.0)
+
+
+@pytest.mark.parametrize("B,n,N,k,d,per_shape,has_res,has_g", [
+    (2, 300, 300, 16, 200, False, True, False),       # transformer block: per-point queries, residual
+    (2, 130, 500, 10, 120, False, False, False),      # set abstraction
+    (1, 640, 100, 16, 64, False, True, False),        # n >= 4 N (the plain path's LDS-table kernel; qsub takes the generic one)
+    (3, 4096, 100, 7, 200, True, False, True),        # decoder: one query per shape folds into the table, global token
+])
+def test_attn_post_rebuilds_the_values_from_u(B, n, N, k, d, per_shape, has_res, has_g):
+    """attn_post(sub=(k, q)) reads u = q_i - k_j + pos where the plain call reads pos: same output, same gradients for the
+    logits, the value table and pos (k and q are constants of that node)."""
+    from nsdp_amd.hip_attention import attn_post
+    g = torch.Generator().manual_seed(B * 31 + n + d)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    a0, vf0, pos0, kf, q = mk(B, n, k, d), mk(B, N, d), mk(B, n, k, d), mk(B, N, d), mk(B, 1 if per_shape else n, d)
+    res = mk(B, n, d) if has_res else None
+    a_g, v_g = (mk(B, d), mk(B, d)) if has_g else (None, None)
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    go = mk(B, n, d)
+    u0 = _ref_pre(q.expand(B, n, d), kf, pos0, idx)
+
+    def run(p0, sub):
+        a, vf, p = (t.clone().requires_grad_(True) for t in (a0, vf0, p0))
+        out = attn_post(a, vf, p, idx, a_g=a_g, v_g=v_g, residual=res, sub=sub)
+        return (out,) + torch.autograd.grad(out, [a, vf, p], go)
+
+    plain, fused = run(pos0, None), run(u0, (kf, q))
+    for name, a_, e_ in zip(("out", "da", "dvf", "dpos"), fused, plain):
+        assert a_.shape == e_.shape
+        # u - q + (v + k) against v + pos: two more fp32 roundings on values of a few units
+        assert float((a_ - e_).abs().max()) <= 1e-5 * (float(e_.abs().max()) + 1.0), name
+
+
+@pytest.mark.parametrize("B,n,N,k,d,second", [(4, 1024, 1024, 16, 200, False), (8, 512, 2048, 16, 200, True)])
+def test_vector_attention_without_the_attn_pre_pass(B, n, N, k, d, second, monkeypatch):
+    """ops.vector_attention with u coming straight out of the position-encoding GEMM (FUSE_PRE) against the layered
+    attn_pre pass: outputs and every gradient (inputs and the two MLPs' weights); `second`: a second attention reusing the
+    first one's position encoding through PosAsU (the set-abstraction pair)."""
+    from torch import nn
+    from nsdp_amd.model import ops
+    if ops.PAIR_MASK or not ops.FUSE_PRE:
+        pytest.skip("knob run: the fused path is off")
+    g = torch.Generator().manual_seed(n + N)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    torch.manual_seed(3)
+    fc_delta = nn.Sequential(nn.Linear(3, d), nn.ReLU(), nn.Linear(d, d)).to(DEV)
+    fc_gamma = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, d)).to(DEV)
+    fc_gamma2 = nn.Sequential(nn.Linear(d, d), nn.ReLU(), nn.Linear(d, d)).to(DEV)
+    rel0, q0, kf0, vf0 = mk(B, n, k, 3) * 0.1, mk(B, n, d), mk(B, N, d), mk(B, N, d)
+    q20, kf20, vf20 = mk(B, n, d), mk(B, N, d), mk(B, N, d)
+    idx = torch.randint(0, N, (B, n, k), generator=g).to(DEV).int()
+    go = mk(B, n, d)
+    params = [p for m in (fc_delta, fc_gamma, fc_gamma2) for p in m.parameters()]
+
+    def run(fuse):
+        monkeypatch.setattr(ops, "FUSE_PRE", fuse)
+        for p in params:
+            p.grad = None
+        ins = [t.clone().requires_grad_(True) for t in (rel0, q0, kf0, vf0, q20, kf20, vf20)]
+        rel, q, kf, vf, q2, kf2, vf2 = ins
+        out, pos = ops.vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma)
+        assert isinstance(pos, ops.PosAsU) == fuse
+        if second:
+            out2, _ = ops.vector_attention(rel, q2, kf2, vf2, idx, fc_delta, fc_gamma2, residual=out, pos=pos)
+            out = out2
+        else:
+            ins = ins[:4]
+        (out * go).sum().backward()
+        torch.cuda.synchronize()
+        return [out.detach()] + [t.grad for t in ins] + [p.grad.clone() for p in params if p.grad is not None]
+
+    layered, fused = run(False), run(True)
+    assert len(layered) == len(fused)
+    for i, (a_, e_) in enumerate(zip(fused, layered)):
+        assert a_.shape == e_.shape
+        # u may differ in its last bit between the two paths (one more rounding of q - k + pos in the layered one), so among
+        # the 10^7 hidden activations of fc_gamma a ReLU can sit on the other side of zero (measured: none, 2.4e-6 norm-wise):
+        # a norm-wise bound, and a loose element-wise one a wrong term would still break
+        # (absolute floors: the last bias of fc_gamma has NO gradient in exact arithmetic -- softmax is shift invariant -- and
+        # both paths deliver 4e-5 of rounding noise there)
+        assert float((a_ - e_).norm()) <= 1e-4 * float(e_.norm()) + 2e-4, i
+        assert float((a_ - e_).abs().max()) <= 1e-2 * float(e_.abs().max()) + 1e-4, i

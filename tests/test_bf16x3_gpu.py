@@ -186,3 +186,37 @@ def test_linear_bf16x3_antiphase_variant_matches_fp64(M, K, N, res, relu_in, rel
     scale = float(ref.abs().max())
     assert float((y_ap[idx].double() - ref).abs().max()) / scale <= 1.5e-6
     assert float((y_ap - y_std).abs().max()) / scale <= 3e-6
+
+
+@pytest.mark.parametrize("B,n,k,nsrc,K,N,per_shape,bias,relu_in", [
+    (2, 1100, 16, 300, 200, 200, False, True, False),      # per-point rows (set abstraction / transformer block), 13 n tiles
+    (3, 4099, 7, 100, 200, 200, True, True, False),        # one query per shape (decoder), ragged row count
+    (2, 1024, 16, 512, 128, 128, False, False, False),     # resident-weight form (direct epilogue), no bias
+    (4, 2048, 16, 2048, 120, 120, False, True, False),     # ... ragged last n tile (the set-abstraction layers)
+    (1, 70000, 10, 2048, 256, 256, False, True, False),    # 16 n tiles, several row blocks per workgroup
+])
+def test_linear_bf16x3_gathered_addend(B, n, k, nsrc, K, N, per_shape, bias, relu_in):
+    """nsdp_linear_bf16x3_gather_f32: y[r] = x[r] @ W^T + b + (gq[r / g_div] - gk[(r / rows_per_shape) * nsrc + gidx[r]]) -- the
+    position-encoding MLP's last layer producing u = q_i - k_j + pos directly.  The addend joins in the epilogue, so the
+    result carries the plain kernel's error plus one rounding of the sum (an accumulator STARTED from q - k would round
+    every small product at the difference's ulp)."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(B + n + 7 * k + N)
+    M = B * n * k
+    x, w = _rand(g, M, K, scale=0.3), _rand(g, N, K, scale=K ** -0.5)       # pos of a fraction of a unit under q - k of a few
+    b = _rand(g, N) if bias else None
+    gq = _rand(g, B if per_shape else B * n, N, scale=2.0)
+    gk = _rand(g, B * nsrc, N, scale=2.0)
+    gidx = torch.randint(0, nsrc, (M,), generator=g).int().to(DEV)
+    assert hip_linear.gather_init_ok(M, N, K)
+    wp = hip_linear.pack_weight_x3(w)[0]
+    y = hip_linear._fwd_x3_gather(x, wp, N, b, (gq, n * k if per_shape else k, gk, gidx, n * k, nsrc), relu_in, False)
+    rows = torch.arange(M, device=DEV)
+    add = gq[rows // (n * k if per_shape else k)] - gk[(rows // (n * k)) * nsrc + gidx.long()]      # one fp32 subtraction
+    ref = _ref64(x, w, b, add, None, None, relu_in, False)
+    plain = hip_linear._fwd_x3(x, wp, N, b, None, None, None, relu_in, False)
+    err = float((y.double() - ref).abs().max())
+    # fl(plain + add): half an ulp of the sum on top of the plain kernel's own error
+    sum_ulp = float(ref.abs().max()) * 2.0 ** -23
+    assert err <= float((plain.double() - _ref64(x, w, b, None, None, None, relu_in, False)).abs().max()) + 0.5 * sum_ulp + 1e-9
+    assert torch.equal(y, plain + add)      # exactly that: the epilogue adds the two fp32 values
