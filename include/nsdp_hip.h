@@ -190,6 +190,12 @@ int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *b
                                   const int32_t *gidx, int g_rows_per_shape, int g_nsrc, float *Y, long long M, int N, int K,
                                   int relu_in, int relu_out, void *stream);
 
+/* nsdp_linear_bf16x3_f32 with a SIGNED residual: Y = post( pre(X) W^T + b + residual_sign * residual ), residual_sign = +1 or -1.
+ * -1 turns a projection into "minus a table" in the GEMM itself: the differences q2 - q1, k2 - k1 a set abstraction's second
+ * attention needs when it re-uses the first one's u as its position encoding (reference model/encoder/blocks.py:303-308). */
+int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *bias, const float *residual, float residual_sign,
+                                  float *Y, long long M, int N, int K, int relu_in, int relu_out, void *stream);
+
 
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.

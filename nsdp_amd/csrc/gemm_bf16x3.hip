@@ -62,12 +62,13 @@ struct X3Params {
   int relu_in, relu_out;
   int dbg;  // experiment knob (nsdp_debug_set(6, v)): bit 0 no weight DMA in the loop, bit 3 no stores, bit 9 one LDS weight
             // read per step instead of three -- wrong results, timing only
-  // gathered accumulator init (nsdp_linear_bf16x3_gather_f32): Y[r] starts from gq[r / g_div] - gk[(r / g_rps) * g_nsrc + gidx[r]]
+  // gathered addend (nsdp_linear_bf16x3_gather_f32, GATHER forms): Y[r] += gq[r / g_div] - gk[(r / g_rps) * g_nsrc + gidx[r]]
   // (rows of two small L2-resident tables) -- the "q_i - k_j" of a vector-attention block added by the position-encoding MLP's
   // last layer itself, so that u = q - k + pos comes out of the GEMM and the attn_pre pass (read pos, write u) disappears
   const float *gq, *gk;
   const int32_t *gidx;
   int g_div, g_rps, g_nsrc;
+  float res_sign = 1.f;   // the residual enters as res_sign * residual (nsdp_linear_bf16x3_signed_f32: -1 = "minus a table")
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           int col = nt * 16 + 4 * g_t;
           col = col + 4 <= N ? col : (N - 4);
           const float4 v = *reinterpret_cast<const float4 *>(p.residual + row * N + col);
-          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w};
+          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w} * p.res_sign;
         }
       }
     } else {
@@ -1054,7 +1055,7 @@ int launch_x3(const X3Params &p, hipStream_t st) {
     if (pre == 0) launch_x3_pre<2, 13, 0, 4, true, 2, GATHER>(p, st, 2);
     else launch_x3_pre<2, 13, 2, 4, true>(p, st, 2);
   } else if (two_waves) {
-    if ((g_x3_dbg & 128) && !GATHER) {
+    if ((g_x3_dbg & 128) && !GATHER && p.res_sign == 1.f) {
       if (pre == 0) launch_x3_ap<13, 0>(p, st);
       else launch_x3_ap<13, 2>(p, st);
     } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8, false, 2, GATHER>(p, st);
@@ -1156,6 +1157,26 @@ int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *b
   if (nt <= 8) return launch_x3<8, true>(p, st);
   if (nt <= 13) return launch_x3<13, true>(p, st);
   return launch_x3<16, true>(p, st);
+}
+
+int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *bias, const float *residual, float residual_sign,
+                                  float *Y, long long M, int N, int K, int relu_in, int relu_out, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X && Wp && Y && residual, "linear_bf16x3_signed: null pointer");
+  NSDP_REQUIRE(residual_sign == 1.f || residual_sign == -1.f, "linear_bf16x3_signed: the residual's sign is +1 or -1");
+  NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3_signed: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
+  NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3_signed: N=%d must be a multiple of 4 and <= 256", N);
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
+                 reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0,
+               "linear_bf16x3_signed: all operands must be 16-byte aligned");
+  X3Params p{X, Wp, bias, residual, nullptr, nullptr, Y, M, N, K, relu_in, relu_out, g_x3_dbg};
+  p.res_sign = residual_sign;
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 4) return launch_x3<4>(p, st);
+  if (nt <= 8) return launch_x3<8>(p, st);
+  if (nt <= 13) return launch_x3<13>(p, st);
+  return launch_x3<16>(p, st);
 }
 
 }  // extern "C"

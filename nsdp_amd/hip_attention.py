@@ -241,7 +241,11 @@ class _AttnPost(torch.autograd.Function):
             if vf is None or a.dtype is not torch.float32:
                 raise ValueError("attn_post(sub=): needs a value table and fp32 storage")
             per_shape = q_c.shape[1] == 1 and a.shape[1] != 1
-            vf = vf + kf_c - q_c if per_shape else vf + kf_c
+            if kf_c is None:                      # the caller's table already holds v + k (ops.vector_attention, combined=)
+                if per_shape:
+                    raise ValueError("attn_post(sub=(None, q)): per-point queries only")
+            else:
+                vf = vf + kf_c - q_c if per_shape else vf + kf_c
             qsub = None if per_shape else _c(q_c)
             if qsub is not None and a_g is not None:
                 raise ValueError("attn_post(sub=): per-point queries and a global token do not combine")

@@ -73,10 +73,20 @@ def pack_weight_x3(w, fwd=True, transposed=False):
     return wp, wpt
 
 
-def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
-    """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack."""
+def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0):
+    """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack.
+    res_sign = -1: the residual is SUBTRACTED (nsdp_linear_bf16x3_signed_f32; no masks)."""
     M, K = x2.shape
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    if res_sign != 1.0:
+        if residual is None or mask is not None or out_mask is not None:
+            raise ValueError("a signed residual needs a residual and no masks")
+        with on_device(x2):
+            check(lib().nsdp_linear_bf16x3_signed_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b),
+                                                      fptr(residual, "residual"), ctypes.c_float(res_sign), fptr(y), _ll(M),
+                                                      _ci(N), _ci(K), _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),
+                  "nsdp_linear_bf16x3_signed_f32")
+        return y
     with on_device(x2):
         check(lib().nsdp_linear_bf16x3_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
                                            optptr(mask), optptr(out_mask), fptr(y), _ll(M), _ci(N), _ci(K),
@@ -493,7 +503,11 @@ def _packs(w, owner, kind, want_t):
     return ent
 
 
-def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out):
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0):
+    if res_sign != 1.0:
+        if kind == "x3":
+            return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign)
+        residual = -residual          # (the small-M exact-fp32 kernel adds: one elementwise launch on a small tensor)
     fn = _fwd_x3 if kind == "x3" else _fwd_wp
     return fn(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out)
 
@@ -516,7 +530,8 @@ class InputGradSum:
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                pre=None, init_gather=None):
+                pre=None, init_gather=None, res_sign=1.0):
+        # res_sign: -1 = the residual is subtracted (a projection "minus a table" in one launch)
         # init_gather: (gq, g_div, gk, gidx, rows_per_shape, nsrc), constants of this node -- a gathered difference of two small
         # tables joins the output in the epilogue (see _fwd_x3_gather); whoever owns the tables accounts for their gradients
         # pre: this layer's output, already computed by a fused forward kernel (hip_decoder.attn_train_forward): the node
@@ -559,7 +574,8 @@ class _LinearFn(torch.autograd.Function):
                 raise ValueError("init_gather needs a layer on the bf16x3 kernel (gather_init_ok) without a residual")
             y = _fwd_x3_gather(x2, wp, N, b, init_gather, relu_in, relu_out)
         else:
-            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out)
+            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, res_sign)
+        ctx.res_sign = res_sign
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
@@ -609,7 +625,9 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None
+            if ctx.res_sign != 1.0:
+                dres = -dres
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -643,7 +661,7 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None):
+           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None, residual_sign=1.0):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -663,8 +681,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
-        if precomputed is not None or init_gather is not None:
-            raise ValueError("precomputed outputs / init_gather belong to fp32 storage")
+        if precomputed is not None or init_gather is not None or residual_sign != 1.0:
+            raise ValueError("precomputed outputs / init_gather / signed residuals belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -690,6 +708,7 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather)
+                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather,
+                               float(residual_sign))
     return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed,
-                           init_gather)
+                           init_gather, float(residual_sign))

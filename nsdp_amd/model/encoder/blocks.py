@@ -52,8 +52,11 @@ class TransformerBlock(nn.Module):
             fan = ops.input_grad_sum(feats)
             q = ops.linear(feats, self.w_qs, grad_sum=fan)
             kf = ops.linear(feats, self.w_ks, grad_sum=fan)
-            vf = ops.linear(feats, self.w_vs, grad_sum=fan)
-            res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats)
+            # where u = q - k + pos comes straight out of the position-encoding GEMM the values are rebuilt from u and the
+            # table v + k: the value projection adds k itself (as its residual, a constant of that node)
+            fused = ops.fused_pre_applies(idx, feats.shape[-1])
+            vf = ops.linear(feats, self.w_vs, grad_sum=fan, residual=kf.detach() if fused else None)
+            res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats, combined=fused)
         return ops.batch_norm(res, self.bn)
 
 
@@ -112,17 +115,27 @@ class TransformerSetAbstraction(nn.Module):
         # is the same values with N/npoint fewer rows through the GEMM
         q1 = ops.linear(ops.index_points(points, fps_idx), self.w_qs)
         fan = ops.input_grad_sum(points)          # four projections of `points`: one running sum through their dX GEMMs
-        res1, pos = ops.vector_attention(rel, q1, ops.linear(points, self.w_ks, grad_sum=fan),
-                                         ops.linear(points, self.w_vs, grad_sum=fan), idx, self.fc_delta1, self.fc_gamma1)
+        fused = ops.fused_pre_applies(idx, points.shape[-1])        # (see TransformerBlock: then the value table is v + k)
+        k1 = ops.linear(points, self.w_ks, grad_sum=fan)
+        v1 = ops.linear(points, self.w_vs, grad_sum=fan, residual=k1.detach() if fused else None)
+        res1, pos = ops.vector_attention(rel, q1, k1, v1, idx, self.fc_delta1, self.fc_gamma1, combined=fused)
         res1 = ops.linear(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1), self.conv2, relu_in=True,
                           residual=res1)
         res1 = ops.batch_norm(res1, self.bnorm0)
 
-        q2 = ops.linear(res1, self.w_qs2)
         # second attention re-uses pos; "res1 + res2" is fused as the kernel's residual add
-        res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2, grad_sum=fan),
-                                        ops.linear(points, self.w_vs2, grad_sum=fan), idx,
-                                        None, self.fc_gamma2, residual=res1, pos=pos)
+        if isinstance(pos, ops.PosAsU):
+            # pos exists only as u1 = q1 - k1 + pos: u2 = u1 + (q2 - q1) - (k2 - k1), values = u1 + (v2 + k1) - q1; the three
+            # projections deliver those differences / sums themselves (signed residuals: constants of their nodes)
+            q2 = ops.linear(res1, self.w_qs2, residual=pos.q, residual_sign=-1.0)
+            k2 = ops.linear(points, self.w_ks2, grad_sum=fan, residual=pos.kf, residual_sign=-1.0)
+            v2 = ops.linear(points, self.w_vs2, grad_sum=fan, residual=pos.kf)
+            res12, _ = ops.vector_attention(None, q2, k2, v2, idx, None, self.fc_gamma2, residual=res1, pos=pos, combined=True)
+        else:
+            q2 = ops.linear(res1, self.w_qs2)
+            res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2, grad_sum=fan),
+                                            ops.linear(points, self.w_vs2, grad_sum=fan), idx,
+                                            None, self.fc_gamma2, residual=res1, pos=pos)
 
         new_points = ops.batch_norm(res12, self.bnorm1)
         return new_xyz, ops.batch_norm(new_points, self.bnorm2, addend=ops.index_points(points, fps_idx))

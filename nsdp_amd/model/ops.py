@@ -112,13 +112,13 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
            out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None,
-           init_gather=None) -> torch.Tensor:
+           init_gather=None, residual_sign: float = 1.0) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
-                             precomputed=precomputed, init_gather=init_gather)
+                             precomputed=precomputed, init_gather=init_gather, residual_sign=residual_sign)
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -180,7 +180,17 @@ class PosAsU:
         self.y, self.q, self.kf = y, q, kf
 
 
-def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None):
+COMBINE_TABLES = os.environ.get("NSDP_COMBINE_TABLES", "1") != "0"     # (A/B knob: 0 = vector_attention forms v + k etc. itself)
+
+
+def fused_pre_applies(idx, d) -> bool:
+    """Will vector_attention (per-point queries, pos=None) take u straight out of the position-encoding GEMM for this index set
+    [B, n, k] and width?  Callers that know can hand it COMBINED tables (see there) and save the elementwise passes."""
+    B, n, k = idx.shape
+    return bool(FUSE_PRE and COMBINE_TABLES and not precision.is_bf16() and not PAIR_MASK and hip_linear.gather_init_ok(B * n * k, d, d))
+
+
+def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None, combined=False):
     """sum_j softmax_j[gamma(q_i - kf[idx_ij] + delta(rel_ij))] * (vf[idx_ij] + delta(rel_ij)) (+ residual),
     softmax over the neighbour axis independently per channel (vector attention).
 
@@ -197,14 +207,16 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
     if isinstance(pos, PosAsU):
         # second attention over the same index set (set abstraction): pos = y - q1_i + k1_j, so
         # u2 = q2_i - k2_j + pos = (q2 - q1)_i - (k2 - k1)_j + y, and the values are y + (v2 + k1)_j - q1_i
+        # `combined`: the caller's projections already produced q2 - q1, k2 - k1 and v2 + k1 (signed residuals of their GEMMs)
         y, q1, k1 = pos.y, pos.q, pos.kf
         link = hip_attention.pos_grad_link() if y.requires_grad else None
         if link is not None and FUSE_DPOS:
             link.grad_sum = hip_linear.InputGradSum()
         inv = hip_attention.backward_lists(idx, y.shape[1], kf.shape[1], y.shape[-1])
-        u = hip_attention.attn_pre(q - q1, kf - k1, y, idx, link, inv)
+        u = hip_attention.attn_pre(q, kf, y, idx, link, inv) if combined else hip_attention.attn_pre(q - q1, kf - k1, y, idx, link, inv)
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
-        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv, sub=(k1, q1))
+        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv,
+                                      sub=(None if combined else k1, q1))
         return out, pos
     if (pos is None and q is not None and FUSE_PRE and not precision.is_bf16() and not PAIR_MASK
             and hip_linear.gather_init_ok(rel.shape[0] * rel.shape[1] * rel.shape[2], fc_delta[2].weight.shape[0],
@@ -223,8 +235,12 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         inv = hip_attention.backward_lists(idx, n, kf.shape[1], d, qb=per_shape)
         u = hip_attention.attn_pre(q, kf, y, idx, link, inv, precomputed=y.detach())      # records the backward, launches nothing
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
-        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv, sub=(kd, qd))
+        # (`combined`: vf is already v + k -- the value projection took k as its residual)
+        out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv,
+                                      sub=(None if combined else kd, qd))
         return out, PosAsU(y, qd, kd)
+    if combined:
+        raise ValueError("combined tables were prepared for the fused path (fused_pre_applies), which this call does not take")
     if pos is None:
         pos = mlp2(rel, fc_delta)                              # 2 dense layers on [B*n*k] rows
     if q is None:

@@ -270,14 +270,15 @@ def test_attn_post_rebuilds_the_values_from_u(B, n, N, k, d, per_shape, has_res,
         assert float((a_ - e_).abs().max()) <= 1e-5 * (float(e_.abs().max()) + 1.0), name
 
 
-@pytest.mark.parametrize("B,n,N,k,d,second", [(4, 1024, 1024, 16, 200, False), (8, 512, 2048, 16, 200, True)])
-def test_vector_attention_without_the_attn_pre_pass(B, n, N, k, d, second, monkeypatch):
+@pytest.mark.parametrize("B,n,N,k,d,second,combined", [(4, 1024, 1024, 16, 200, False, False), (8, 512, 2048, 16, 200, True, False),
+                                                        (8, 512, 2048, 16, 200, True, True)])
+def test_vector_attention_without_the_attn_pre_pass(B, n, N, k, d, second, combined, monkeypatch):
     """ops.vector_attention with u coming straight out of the position-encoding GEMM (FUSE_PRE) against the layered
     attn_pre pass: outputs and every gradient (inputs and the two MLPs' weights); `second`: a second attention reusing the
     first one's position encoding through PosAsU (the set-abstraction pair)."""
     from torch import nn
     from nsdp_amd.model import ops
-    if ops.PAIR_MASK or not ops.FUSE_PRE:
+    if ops.PAIR_MASK or not ops.FUSE_PRE or (combined and not ops.COMBINE_TABLES):
         pytest.skip("knob run: the fused path is off")
     g = torch.Generator().manual_seed(n + N)
     mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
@@ -297,10 +298,16 @@ def test_vector_attention_without_the_attn_pre_pass(B, n, N, k, d, second, monke
             p.grad = None
         ins = [t.clone().requires_grad_(True) for t in (rel0, q0, kf0, vf0, q20, kf20, vf20)]
         rel, q, kf, vf, q2, kf2, vf2 = ins
-        out, pos = ops.vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma)
+        comb = combined and fuse      # the encoder blocks' form: the projections deliver v + k, q2 - q1, k2 - k1, v2 + k1 themselves
+        assert ops.fused_pre_applies(idx, d) == (fuse and ops.COMBINE_TABLES)
+        out, pos = ops.vector_attention(rel, q, kf, vf + kf.detach() if comb else vf, idx, fc_delta, fc_gamma, combined=comb)
         assert isinstance(pos, ops.PosAsU) == fuse
         if second:
-            out2, _ = ops.vector_attention(rel, q2, kf2, vf2, idx, fc_delta, fc_gamma2, residual=out, pos=pos)
+            if comb:
+                out2, _ = ops.vector_attention(None, q2 - pos.q, kf2 - pos.kf, vf2 + pos.kf, idx, None, fc_gamma2, residual=out,
+                                               pos=pos, combined=True)
+            else:
+                out2, _ = ops.vector_attention(rel, q2, kf2, vf2, idx, fc_delta, fc_gamma2, residual=out, pos=pos)
             out = out2
         else:
             ins = ins[:4]

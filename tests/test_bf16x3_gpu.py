@@ -220,3 +220,26 @@ def test_linear_bf16x3_gathered_addend(B, n, k, nsrc, K, N, per_shape, bias, rel
     sum_ulp = float(ref.abs().max()) * 2.0 ** -23
     assert err <= float((plain.double() - _ref64(x, w, b, None, None, None, relu_in, False)).abs().max()) + 0.5 * sum_ulp + 1e-9
     assert torch.equal(y, plain + add)      # exactly that: the epilogue adds the two fp32 values
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(40000, 128, 128, False), (33000, 120, 120, True), (70001, 200, 200, True),
+                                        (50000, 256, 256, False)])
+def test_linear_bf16x3_signed_residual(M, K, N, bias):
+    """nsdp_linear_bf16x3_signed_f32 with sign -1 == the plain kernel fed the negated residual, bit for bit (the projections
+    "minus a table" of a set abstraction's second attention); through hip_linear.linear the residual's gradient is -dy."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    x, w, r = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5), _rand(g, M, N)
+    b = _rand(g, N) if bias else None
+    wp = hip_linear.pack_weight_x3(w)[0]
+    y = hip_linear._fwd_x3(x, wp, N, b, r, None, None, False, False, res_sign=-1.0)
+    assert torch.equal(y, hip_linear._fwd_x3(x, wp, N, b, -r, None, None, False, False))
+    ref = _ref64(x, w, b, -r, None, None, False, False)
+    assert float((y.double() - ref).abs().max()) / float(ref.abs().max()) <= 1.5e-6
+    xr, rr = x[:4096].clone().requires_grad_(True), r[:4096].clone().requires_grad_(True)      # (small M: the exact-fp32 kernel's route)
+    out = hip_linear.linear(xr, w, b, residual=rr, residual_sign=-1.0)
+    go = _rand(g, 4096, N)
+    dx, dr = torch.autograd.grad(out, [xr, rr], go)
+    assert torch.equal(dr, -go)
+    assert float((out.double() - _ref64(x[:4096], w, b, -r[:4096], None, None, False, False)).abs().max()) <= 2e-5
+    assert float((dx.double() - go.double() @ w.double()).abs().max()) <= 2e-5 * float(go.abs().max()) * K ** 0.5
