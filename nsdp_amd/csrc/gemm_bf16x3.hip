@@ -353,7 +353,8 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           int col = nt * 16 + 4 * g_t;
           col = col + 4 <= N ? col : (N - 4);
           const float4 v = *reinterpret_cast<const float4 *>(p.residual + row * N + col);
-          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w} * p.res_sign;
+          acc[mt][nt] = f32x4{v.x, v.y, v.z, v.w};
+          if constexpr (PRE == 0) acc[mt][nt] *= p.res_sign;      // (signed residuals come without masks / input ReLU)
         }
       }
     } else {
@@ -1164,6 +1165,7 @@ int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *b
   if (M <= 0 || N <= 0) return 0;
   NSDP_REQUIRE(X && Wp && Y && residual, "linear_bf16x3_signed: null pointer");
   NSDP_REQUIRE(residual_sign == 1.f || residual_sign == -1.f, "linear_bf16x3_signed: the residual's sign is +1 or -1");
+  NSDP_REQUIRE(!relu_in, "linear_bf16x3_signed: no input ReLU (the sign lives in the plain-prologue kernels)");
   NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3_signed: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
   NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3_signed: N=%d must be a multiple of 4 and <= 256", N);
   NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
