@@ -196,6 +196,14 @@ int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *b
 int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *bias, const float *residual, float residual_sign,
                                   float *Y, long long M, int N, int K, int relu_in, int relu_out, void *stream);
 
+/* Y = out_mask_gate( post( (X gated by mask) W^T + b + residual ) ) + addend: the masked form of nsdp_linear_bf16x3_f32 with one more
+ * operand added AFTER the output mask.  It is dX of the first layer of a pre-activation residual block x + fc_1(relu(fc_0(relu(x))))
+ * (reference model/decoder/blocks.py:99-142): X = d(h), mask = h, out_mask = x, addend = the gradient arriving over the skip
+ * connection -- the block's input gradient in one launch instead of a GEMM and an elementwise add. */
+int nsdp_linear_bf16x3_addend_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,
+                                  const float *out_mask, const float *addend, float *Y, long long M, int N, int K,
+                                  int relu_out, void *stream);
+
 
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.

@@ -69,6 +69,9 @@ struct X3Params {
   const int32_t *gidx;
   int g_div, g_rps, g_nsrc;
   float res_sign = 1.f;   // the residual enters as res_sign * residual (nsdp_linear_bf16x3_signed_f32: -1 = "minus a table")
+  // added AFTER the output mask (nsdp_linear_bf16x3_addend_f32, masked-prologue forms with an out_mask): the gradient arriving
+  // over the skip connection of x + f(relu(x)), which the ReLU's mask must not touch
+  const float *addend = nullptr;
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -523,6 +526,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             const float4 om = *reinterpret_cast<const float4 *>(p.out_mask + rowc * N + colc);
             v.x = om.x > 0.f ? v.x : 0.f; v.y = om.y > 0.f ? v.y : 0.f; v.z = om.z > 0.f ? v.z : 0.f; v.w = om.w > 0.f ? v.w : 0.f;
           }
+          if constexpr (decltype(has_omask)::value == 2) {      // (has_omask = 2: out_mask, then the skip-connection addend)
+            const float4 ad = *reinterpret_cast<const float4 *>(p.addend + rowc * N + colc);
+            v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+          }
           const f32x4 vv = {v.x, v.y, v.z, v.w};
           if (decltype(guarded)::value) {
             if (cv && rv) {
@@ -547,6 +554,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         const unsigned rd = ebase + lane_e * 16u;                                  // chunk i of a pass: + 1024 i
         float *ytile = p.Y + row0 * N;                                             // (wave-uniform: SGPR base of the stores)
         const float *mtile = decltype(has_omask)::value ? p.out_mask + row0 * N : nullptr;
+        const float *atile = decltype(has_omask)::value == 2 ? p.addend + row0 * N : nullptr;
         const int rows_left = p.M - row0 < MT * 16 ? static_cast<int>(p.M - row0) : MT * 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -563,6 +571,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             unsigned off[ntn];
             bool live[ntn];
             f32x4 om[decltype(has_omask)::value ? ntn : 1];
+            f32x4 ad[decltype(has_omask)::value == 2 ? ntn : 1];
             static_for<0, ntn>([&](auto CI) {
               constexpr int i = decltype(CI)::value;
               const unsigned f = static_cast<unsigned>(i) * 1024u + lane_e * 16u;
@@ -571,6 +580,9 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
               live[i] = static_cast<int>(cb) < valid && static_cast<int>(mt * 16 + r) < rows_left;
               if constexpr (decltype(has_omask)::value) {
                 om[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(mtile) + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
+              if constexpr (decltype(has_omask)::value == 2) {
+                ad[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(atile) + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
               }
             });
             f32x4 gav[GATHER ? ntn : 1], gbv[GATHER ? ntn : 1];      // gathered addend, fragment layout: in flight over the bias reads
@@ -614,6 +626,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = om[i][c] > 0.f ? v[c] : 0.f;
               }
+              if constexpr (decltype(has_omask)::value == 2) v += ad[i];
               if (live[i]) store_f4(off[i], v, ytile);
             });
           });
@@ -651,8 +664,16 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             if (nt * 16 < N) otile(nt, has_omask, std::true_type{});
         }
       };
-      if (p.out_mask) epilogue(std::true_type{});
-      else epilogue(std::false_type{});
+      if (p.out_mask) {
+        if constexpr (PRE == 1) {
+          if (p.addend) epilogue(std::integral_constant<int, 2>{});
+          else epilogue(std::true_type{});
+        } else {
+          epilogue(std::true_type{});
+        }
+      } else {
+        epilogue(std::false_type{});
+      }
     }
 
     X3_T(t_e1);
@@ -1056,7 +1077,7 @@ int launch_x3(const X3Params &p, hipStream_t st) {
     if (pre == 0) launch_x3_pre<2, 13, 0, 4, true, 2, GATHER>(p, st, 2);
     else launch_x3_pre<2, 13, 2, 4, true>(p, st, 2);
   } else if (two_waves) {
-    if ((g_x3_dbg & 128) && !GATHER && p.res_sign == 1.f) {
+    if ((g_x3_dbg & 128) && !GATHER && p.res_sign == 1.f && !p.addend) {
       if (pre == 0) launch_x3_ap<13, 0>(p, st);
       else launch_x3_ap<13, 2>(p, st);
     } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8, false, 2, GATHER>(p, st);
@@ -1173,6 +1194,27 @@ int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *b
                "linear_bf16x3_signed: all operands must be 16-byte aligned");
   X3Params p{X, Wp, bias, residual, nullptr, nullptr, Y, M, N, K, relu_in, relu_out, g_x3_dbg};
   p.res_sign = residual_sign;
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (nt <= 4) return launch_x3<4>(p, st);
+  if (nt <= 8) return launch_x3<8>(p, st);
+  if (nt <= 13) return launch_x3<13>(p, st);
+  return launch_x3<16>(p, st);
+}
+
+int nsdp_linear_bf16x3_addend_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,
+                                  const float *out_mask, const float *addend, float *Y, long long M, int N, int K,
+                                  int relu_out, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X && Wp && Y && mask && out_mask && addend, "linear_bf16x3_addend: null pointer (mask, out_mask and addend are required)");
+  NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3_addend: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
+  NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3_addend: N=%d must be a multiple of 4 and <= 256", N);
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
+                 reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(mask) |
+                 reinterpret_cast<uintptr_t>(out_mask) | reinterpret_cast<uintptr_t>(addend)) & 15) == 0,
+               "linear_bf16x3_addend: all operands must be 16-byte aligned");
+  X3Params p{X, Wp, bias, residual, mask, out_mask, Y, M, N, K, 0, relu_out, g_x3_dbg};
+  p.addend = addend;
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
   if (nt <= 4) return launch_x3<4>(p, st);

@@ -73,11 +73,21 @@ def pack_weight_x3(w, fwd=True, transposed=False):
     return wp, wpt
 
 
-def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0):
+def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None):
     """_fwd on the bf16 matrix pipe (3-way split, 6 products): weight given as its bf16x3 pack.
-    res_sign = -1: the residual is SUBTRACTED (nsdp_linear_bf16x3_signed_f32; no masks)."""
+    res_sign = -1: the residual is SUBTRACTED (nsdp_linear_bf16x3_signed_f32; no masks).
+    addend: added AFTER the output mask (nsdp_linear_bf16x3_addend_f32; needs mask and out_mask, no input ReLU)."""
     M, K = x2.shape
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    if addend is not None:
+        if mask is None or out_mask is None or relu_in or res_sign != 1.0:
+            raise ValueError("a post-mask addend needs mask and out_mask, no input ReLU, an unsigned residual")
+        with on_device(x2):
+            check(lib().nsdp_linear_bf16x3_addend_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
+                                                      fptr(mask, "mask"), fptr(out_mask, "out_mask"), fptr(addend, "addend"),
+                                                      fptr(y), _ll(M), _ci(N), _ci(K), _ci(int(relu_out)), stream_ptr()),
+                  "nsdp_linear_bf16x3_addend_f32")
+        return y
     if res_sign != 1.0:
         if residual is None or mask is not None or out_mask is not None:
             raise ValueError("a signed residual needs a residual and no masks")
@@ -503,7 +513,11 @@ def _packs(w, owner, kind, want_t):
     return ent
 
 
-def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0):
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None):
+    if addend is not None:
+        if kind == "x3" and mask is not None and out_mask is not None and not relu_in:
+            return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, addend=addend)
+        return _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign).add_(addend)
     if res_sign != 1.0:
         if kind == "x3":
             return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign)
@@ -527,10 +541,38 @@ class InputGradSum:
         self.buf = None
 
 
+class SkipGrad:
+    """Hand-over of the skip connection's gradient inside a pre-activation residual block y = x + fc_1(relu(fc_0(relu(x)))):
+    fc_1 (``skip_src``: the layer whose `residual` operand is x) deposits d(residual) = dy here instead of reporting it, fc_0
+    (``skip_dst``: the layer whose input is x) adds it to its dX behind the input ReLU's mask -- in the dX GEMM's epilogue
+    (nsdp_linear_bf16x3_addend_f32) where that kernel runs, with one add otherwise -- and reports the block's whole input
+    gradient.  Autograd would add the two [rows, d] tensors with an elementwise kernel per block.  fc_0's forward arms the
+    link (only if its input needs a gradient); fc_1's backward always runs before fc_0's (it consumes fc_0's output)."""
+    __slots__ = ("armed", "buf")
+
+    def __init__(self):
+        self.armed = False
+        self.buf = None
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                pre=None, init_gather=None, res_sign=1.0):
+                pre=None, init_gather=None, res_sign=1.0, skip=None):
+        # skip: (SkipGrad, is_src) -- see SkipGrad
+        ctx.skip_src = ctx.skip_dst = None
+        if skip is not None:
+            link, is_src = skip
+            if is_src:
+                if residual is None or relu_out:
+                    raise ValueError("skip_src: the layer that adds x as its residual, without an output ReLU")
+                if link.armed and ctx.needs_input_grad[3]:
+                    ctx.skip_src = link
+            elif ctx.needs_input_grad[0]:
+                if grad_sum is not None:
+                    raise ValueError("skip_dst and InputGradSum do not combine")
+                link.armed = True
+                ctx.skip_dst = link
         # res_sign: -1 = the residual is subtracted (a projection "minus a table" in one launch)
         # init_gather: (gq, g_div, gk, gidx, rows_per_shape, nsrc), constants of this node -- a gathered difference of two small
         # tables joins the output in the epilogue (see _fwd_x3_gather); whoever owns the tables accounts for their gradients
@@ -613,8 +655,13 @@ class _LinearFn(torch.autograd.Function):
                 mk = _pad_cols(y) if y is not None else None
             # dX = dY' @ W == linear(dY', W^T): W^T [K, N] as its fragment-major pack (rows >= K are zero)
             link = ctx.grad_sum
+            addend = None
+            if ctx.skip_dst is not None:
+                addend, ctx.skip_dst.buf = ctx.skip_dst.buf, None
+                if addend is not None and addend.shape[1] != x2.shape[1]:
+                    raise RuntimeError("SkipGrad: the skip gradient does not have the layer's input width")
             dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
-                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False)
+                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False, addend=addend)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
             if link is not None:         # running sum over the layers that share this input
                 link.pending -= 1
@@ -622,12 +669,14 @@ class _LinearFn(torch.autograd.Function):
                     link.buf, dx = dx.reshape(-1, ctx.k_orig), None
                 else:
                     link.buf, link.pending = None, link.total      # (re-armed for a second pass over a retained graph)
-        if ctx.has_res and ctx.needs_input_grad[3]:
+        if ctx.skip_src is not None:
+            ctx.skip_src.buf = dy2            # (no output ReLU on this layer: d(residual) IS dy)
+        elif ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2 if y is None else dy2 * (y > 0)
             dres = dres.reshape(dy.shape)
             if ctx.res_sign != 1.0:
                 dres = -dres
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -661,7 +710,8 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None, residual_sign=1.0):
+           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None, residual_sign=1.0,
+           skip_src=None, skip_dst=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -681,8 +731,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
-        if precomputed is not None or init_gather is not None or residual_sign != 1.0:
-            raise ValueError("precomputed outputs / init_gather / signed residuals belong to fp32 storage")
+        if precomputed is not None or init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst:
+            raise ValueError("precomputed outputs / init_gather / signed residuals / SkipGrad belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -705,10 +755,13 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
         else:
             y = _LinearFn.apply(xf, w2, bias, rf, bool(relu_in), bool(relu_out), None, None, grad_sum, owner)
         return y if out_f32 else y.to(torch.bfloat16)
+    if skip_src is not None and skip_dst is not None:
+        raise ValueError("a layer is either end of a SkipGrad link")
+    skip = (skip_src, True) if skip_src is not None else (skip_dst, False) if skip_dst is not None else None
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
                                bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather,
-                               float(residual_sign))
+                               float(residual_sign), skip)
     return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed,
-                           init_gather, float(residual_sign))
+                           init_gather, float(residual_sign), skip)

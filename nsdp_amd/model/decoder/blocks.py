@@ -66,5 +66,7 @@ class ResnetBlockFC(nn.Module):
             h = ops.linear(x, self.fc_0, relu_in=True)
             return ops.linear(h, self.fc_1, relu_in=True, residual=x_s)
         pair = ops.PAIR_MASK and torch.is_grad_enabled()                 # backward mask contract of ops.mlp2
-        h = ops.linear(x, self.fc_0, relu_in=True, relu=True, premasked=pair)      # relu(fc_0(relu(x)))
-        return ops.linear(h, self.fc_1, residual=x_s, mask_dx=pair)       # x_s + fc_1(h), fused epilogue
+        # identity shortcut: the skip connection's gradient joins fc_0's dX inside that GEMM (hip_linear.SkipGrad)
+        skip = ops.skip_grad(x) if self.shortcut is None else None
+        h = ops.linear(x, self.fc_0, relu_in=True, relu=True, premasked=pair, skip_dst=skip)      # relu(fc_0(relu(x)))
+        return ops.linear(h, self.fc_1, residual=x_s, mask_dx=pair, skip_src=skip)       # x_s + fc_1(h), fused epilogue

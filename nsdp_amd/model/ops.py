@@ -112,13 +112,14 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
            out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None,
-           init_gather=None, residual_sign: float = 1.0) -> torch.Tensor:
+           init_gather=None, residual_sign: float = 1.0, skip_src=None, skip_dst=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
-                             precomputed=precomputed, init_gather=init_gather, residual_sign=residual_sign)
+                             precomputed=precomputed, init_gather=init_gather, residual_sign=residual_sign,
+                             skip_src=skip_src, skip_dst=skip_dst)
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -163,6 +164,16 @@ def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = Fa
 # ---------------------------------------------------------------------------------------------
 # point-transformer vector attention
 # ---------------------------------------------------------------------------------------------
+SKIP_GRAD = os.environ.get("NSDP_SKIP_GRAD", "1") != "0"       # (A/B knob: 0 = autograd adds the skip connection's gradient)
+
+
+def skip_grad(x):
+    """hip_linear.SkipGrad for a residual block whose input is ``x`` (None when nothing is to be handed over)."""
+    if SKIP_GRAD and torch.is_grad_enabled() and x.requires_grad and not precision.is_bf16():
+        return hip_linear.SkipGrad()
+    return None
+
+
 FUSE_DPOS = os.environ.get("NSDP_FUSE_DPOS", "1") != "0"     # (A/B knob: 0 = attn_pre_bwd accumulates d(pos) itself)
 # u = q_i - k_j + delta(rel_ij) straight out of the position-encoding MLP's last GEMM (its accumulators start from the
 # gathered q - k rows: hip_linear's init_gather): no attn_pre pass, and `pos` is never materialised -- the values

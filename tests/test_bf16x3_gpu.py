@@ -243,3 +243,21 @@ def test_linear_bf16x3_signed_residual(M, K, N, bias):
     assert torch.equal(dr, -go)
     assert float((out.double() - _ref64(x[:4096], w, b, -r[:4096], None, None, False, False)).abs().max()) <= 2e-5
     assert float((dx.double() - go.double() @ w.double()).abs().max()) <= 2e-5 * float(go.abs().max()) * K ** 0.5
+
+
+@pytest.mark.parametrize("M,K,N,res", [(128 * 512 * 2 + 50, 128, 128, False), (192 * 256 * 2 + 77, 200, 200, True),
+                                       (40000, 256, 256, False), (33001, 120, 120, False)])
+def test_linear_bf16x3_addend_after_the_output_mask(M, K, N, res):
+    """nsdp_linear_bf16x3_addend_f32: gate(out_mask) of the masked GEMM, THEN + addend -- bit for bit the masked kernel's output
+    plus the addend (one fp32 add), i.e. dX of a residual block's first layer with the skip gradient joined in the epilogue."""
+    from nsdp_amd import hip_linear
+    g = torch.Generator(device="cpu").manual_seed(M + 3 * N)
+    x, w = _rand(g, M, K), _rand(g, N, K, scale=K ** -0.5)
+    m, o, a = _rand(g, M, K), _rand(g, M, N), _rand(g, M, N)
+    r = _rand(g, M, N) if res else None
+    wp = hip_linear.pack_weight_x3(w)[0]
+    y = hip_linear._fwd_x3(x, wp, N, None, r, m, o, False, False, addend=a)
+    plain = hip_linear._fwd_x3(x, wp, N, None, r, m, o, False, False)
+    assert torch.equal(y, plain + a)
+    ref = _ref64(x, w, None, r, m, o, False, False) + a.double()
+    assert float((y.double() - ref).abs().max()) / float(ref.abs().max()) <= 1.5e-6

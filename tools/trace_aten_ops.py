@@ -53,7 +53,13 @@ def main():
         t = ev.self_device_time_total
         if t <= 0:
             continue
-        site = "no Python frame; shapes " + str(ev.input_shapes)[:90]
+        # no Python frame in the backward pass: name the autograd node the op runs under instead
+        par, node = ev.cpu_parent, ""
+        while par is not None:
+            if "evaluate_function" in par.name or par.name.endswith("Backward") or "Backward" in par.name:
+                node = par.name.replace("autograd::engine::evaluate_function: ", "")
+            par = par.cpu_parent
+        site = (node or "forward") + "  " + str(ev.input_shapes)[:70]
         for fr in ev.stack or ():
             if "nsdp_amd" in fr and "torch/" not in fr:
                 site = fr.split("nsdp_amd/")[-1]
@@ -62,6 +68,17 @@ def main():
         by_site[(ev.name, site)][1] += 1
         by_op[ev.name][0] += t
         by_op[ev.name][1] += 1
+    if os.environ.get("TRACE_SEQUENCE"):
+        # the backward pass as the engine ran it: every node, and the accumulations (aten::add*) it performed
+        tops = sorted((e for e in prof.events() if "evaluate_function" in e.name), key=lambda e: e.time_range.start)
+        for i, e in enumerate(tops):
+            kids, stack = [], list(e.cpu_children)
+            while stack:
+                c = stack.pop()
+                if c.name in ("aten::add", "aten::add_") and c.self_device_time_total > 20:
+                    kids.append(f"{c.name}{str(c.input_shapes[0])} {c.self_device_time_total:.0f}us")
+                stack.extend(c.cpu_children)
+            print(f"  {i:4d} {e.name.replace('autograd::engine::evaluate_function: ', ''):32s} {' | '.join(kids)}")
     print("per op (device us, calls):")
     for k, (t, c) in sorted(by_op.items(), key=lambda kv: -kv[1][0])[:20]:
         print(f"  {k:32s} {t:9.1f} {c:5d}")
