@@ -185,7 +185,9 @@ int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, co
  * MLP, gq = the queries, gk = the key table and gidx = the flattened neighbour indices this IS the logits' input
  * u = q_i - k_j + delta(rel_ij) of a vector-attention block (reference model/encoder/blocks.py:104-116, decoder/blocks.py:72-84)
  * -- the attn_pre pass (read pos, write u) and the pos tensor itself disappear.  The sum is rounded exactly like the separate
- * pass rounds it: fl(fl(X W^T + b) + fl(gq - gk)).  M and both tables' element counts < 2^31; relu_in must be 0. */
+ * pass rounds it: fl(fl(X W^T + b) + fl(gq - gk)).  M and both tables' element counts < 2^31; relu_in must be 0.
+ * gq == NULL: gk is the ready difference table (one query per shape: q_b - k_bj, shapes * g_nsrc rows), its rows are ADDED;
+ * (half the loads).  relu_out must be 0 as well. */
 int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *bias, const float *gq, int g_div, const float *gk,
                                   const int32_t *gidx, int g_rows_per_shape, int g_nsrc, float *Y, long long M, int N, int K,
                                   int relu_in, int relu_out, void *stream);

@@ -143,7 +143,7 @@ __device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *unif
 // drift apart and one wave's epilogue stores sit under the other waves' MFMA steps (the streaming form re-fetches the
 // planes L2 -> LDS for every 256-row tile: as many bytes as the HBM traffic, and its per-k-block barrier keeps all waves
 // in the same phase).
-template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, bool GATHER = false>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, int GATHER = 0>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
   static_assert(!GATHER || PRE == 0, "the gathered addend belongs to the plain-prologue forms");
   constexpr bool WRES = KBM > 2;
@@ -334,14 +334,15 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     // from q - k, a few units, would round each of the ~40 small MFMA addends of the position encoding at the difference's
     // ulp: measured 7x the rms error of the separate pass).  Only the two row offsets (floats) of this lane's rows are
     // fetched here -- the index load is the head of a dependent chain -- and ride through the k loop.
-    unsigned gqo[GATHER ? MT : 1], gko[GATHER ? MT : 1];
+    // GATHER == 2: ONE table that already holds the difference (p.gk = q - k per shape and source, p.gq unused): half the loads
+    unsigned gqo[GATHER == 1 ? MT : 1], gko[GATHER ? MT : 1];
     if constexpr (GATHER) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         long long row = row0 + mt * 16 + li_t;
         row = row < p.M ? row : (p.M - 1);
         const unsigned r32 = static_cast<unsigned>(row);                       // (host contract: M, table elements < 2^31)
-        gqo[mt] = (r32 / static_cast<unsigned>(p.g_div)) * static_cast<unsigned>(N);
+        if constexpr (GATHER == 1) gqo[mt] = (r32 / static_cast<unsigned>(p.g_div)) * static_cast<unsigned>(N);
         gko[mt] = ((r32 / static_cast<unsigned>(p.g_rps)) * static_cast<unsigned>(p.g_nsrc) + static_cast<unsigned>(p.gidx[row])) *
                   static_cast<unsigned>(N);
       }
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           col = col + 4 <= N ? col : (N - 4);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
-            ga[mt] = *reinterpret_cast<const f32x4 *>(p.gq + gqo[mt] + col);
+            if constexpr (GATHER == 1) ga[mt] = *reinterpret_cast<const f32x4 *>(p.gq + gqo[mt] + col);
             gb[mt] = *reinterpret_cast<const f32x4 *>(p.gk + gko[mt] + col);
           }
         }
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           const long long rowc = rv ? row : (p.M - 1);
           float4 v = make_float4(acc[mt][nt][0] + bv.x, acc[mt][nt][1] + bv.y, acc[mt][nt][2] + bv.z, acc[mt][nt][3] + bv.w);
           if constexpr (GATHER) {
-            const f32x4 d = ga[mt] - gb[mt];
+            const f32x4 d = GATHER == 2 ? gb[mt] : ga[mt] - gb[mt];
             v.x += d[0]; v.y += d[1]; v.z += d[2]; v.w += d[3];
           }
           if (p.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -556,8 +557,8 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         const float *mtile = decltype(has_omask)::value ? p.out_mask + row0 * N : nullptr;
         const float *atile = decltype(has_omask)::value == 2 ? p.addend + row0 * N : nullptr;
         const int rows_left = p.M - row0 < MT * 16 ? static_cast<int>(p.M - row0) : MT * 16;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        static_for<0, MT>([&](auto MI) {
+          constexpr int mt = decltype(MI)::value;
           static_for<0, kPasses>([&](auto PI) {
             constexpr int pass = decltype(PI)::value;
             constexpr int nt0 = pass * kTpp;
@@ -572,6 +573,12 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             bool live[ntn];
             f32x4 om[decltype(has_omask)::value ? ntn : 1];
             f32x4 ad[decltype(has_omask)::value == 2 ? ntn : 1];
+            // GATHER == 2 (one table, a row per output row): the addend in the READ-BACK layout -- row runs of the table, 2-3
+            // segments per instruction (in the fragment layout, 16 rows x 64 B per instruction, this gather cost the 13-tile form
+            // +330 us on 1.8 M rows, here +200).  The table row of chunk i's output row comes from the lane that owns that row in
+            // the fragment layout (ds_bpermute).  GATHER == 1 (per-point queries: the q rows are broadcasts) stays in the fragment
+            // layout below: measured 0 / +55 us on 320 000 x 256 x 256 against the read-back form.
+            f32x4 gka[GATHER == 2 ? ntn : 1];
             static_for<0, ntn>([&](auto CI) {
               constexpr int i = decltype(CI)::value;
               const unsigned f = static_cast<unsigned>(i) * 1024u + lane_e * 16u;
@@ -584,9 +591,14 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
               if constexpr (decltype(has_omask)::value == 2) {
                 ad[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(atile) + off[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
               }
+              if constexpr (GATHER == 2) {
+                const unsigned cbytes = static_cast<unsigned>(nt0) * 64u + cb;       // byte offset of the chunk within a table row
+                const unsigned ko = static_cast<unsigned>(__builtin_amdgcn_ds_bpermute(static_cast<int>(r * 4u), static_cast<int>(gko[mt])));
+                gka[i] = live[i] ? *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(p.gk + ko) + cbytes) : f32x4{0.f, 0.f, 0.f, 0.f};
+              }
             });
-            f32x4 gav[GATHER ? ntn : 1], gbv[GATHER ? ntn : 1];      // gathered addend, fragment layout: in flight over the bias reads
-            if constexpr (GATHER) {
+            f32x4 gav[GATHER == 1 ? ntn : 1], gbv[GATHER == 1 ? ntn : 1];      // two tables, fragment layout: in flight over the bias reads
+            if constexpr (GATHER == 1) {
               static_for<0, ntn>([&](auto TI) {
                 constexpr int t = decltype(TI)::value;
                 int col = (nt0 + t) * 16 + 4 * g_e;
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
               constexpr int nt = nt0 + t;
               lgkm_wait<ntn - 1 - t>(bvv[t]);
               f32x4 v = acc[mt][nt] + bvv[t];
-              if constexpr (GATHER) v += gav[t] - gbv[t];
+              if constexpr (GATHER == 1) v += gav[t] - gbv[t];
               if (p.relu_out) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -627,10 +639,11 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
                 for (int c = 0; c < 4; ++c) v[c] = om[i][c] > 0.f ? v[c] : 0.f;
               }
               if constexpr (decltype(has_omask)::value == 2) v += ad[i];
+              if constexpr (GATHER == 2) v += gka[i];
               if (live[i]) store_f4(off[i], v, ytile);
             });
           });
-        }
+        });
       };
       auto epilogue = [&](auto has_omask) {
         const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
@@ -1030,7 +1043,7 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float *__restric
   nsdp::pack::x3_body(W, N, K, Wp, WpT, static_cast<long long>(blockIdx.x) * 256 + threadIdx.x);
 }
 
-template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, bool GATHER = false>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, int GATHER = 0>
 void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
   const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
@@ -1041,12 +1054,12 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   const long long slots = static_cast<long long>(nsdp::num_cus() - reserve) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
   NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "",
-             GATHER ? " gather" : "");
+             GATHER == 2 ? " gather1" : GATHER ? " gather" : "");
   hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, PRE, WV, XREG, KBM, GATHER>), dim3(grid), dim3(WV * 64), 0, st, p);
 }
 
 // (the hand-issued loads of this file must never be spilled while in flight: every variant is built spill-free)
-template <int NT, bool GATHER = false>
+template <int NT, int GATHER = 0>
 int launch_x3(const X3Params &p, hipStream_t st) {
   const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
@@ -1160,13 +1173,13 @@ int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *b
                                   const int32_t *gidx, int g_rows_per_shape, int g_nsrc, float *Y, long long M, int N, int K,
                                   int relu_in, int relu_out, void *stream) {
   if (M <= 0 || N <= 0) return 0;
-  NSDP_REQUIRE(X && Wp && Y && gq && gk && gidx, "linear_bf16x3_gather: null pointer");
+  NSDP_REQUIRE(X && Wp && Y && gk && gidx, "linear_bf16x3_gather: null pointer");
   NSDP_REQUIRE(K > 32 && K % 4 == 0, "linear_bf16x3_gather: K=%d must be a multiple of 4 and > 32 (two k blocks)", K);
   NSDP_REQUIRE(N <= 256 && N % 4 == 0, "linear_bf16x3_gather: N=%d must be a multiple of 4 and <= 256", N);
   NSDP_REQUIRE(M < (1LL << 31) && g_div > 0 && g_rows_per_shape > 0 && g_nsrc > 0, "linear_bf16x3_gather: bad row maps");
-  NSDP_REQUIRE(!relu_in, "linear_bf16x3_gather: no input ReLU (the addend belongs to the plain-prologue kernels)");
+  NSDP_REQUIRE(!relu_in && !relu_out, "linear_bf16x3_gather: no fused ReLU on either side");
   {   // the kernel addresses both tables with 32-bit element offsets
-    const long long q_rows = (M + g_div - 1) / g_div, k_rows = ((M + g_rows_per_shape - 1) / g_rows_per_shape) * g_nsrc;
+    const long long q_rows = gq ? (M + g_div - 1) / g_div : 0, k_rows = ((M + g_rows_per_shape - 1) / g_rows_per_shape) * g_nsrc;
     NSDP_REQUIRE(q_rows * N < (1LL << 31) && k_rows * N < (1LL << 31), "linear_bf16x3_gather: tables beyond 2^31 elements");
   }
   NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
@@ -1175,10 +1188,16 @@ int nsdp_linear_bf16x3_gather_f32(const float *X, const void *Wp, const float *b
   X3Params p{X, Wp, bias, nullptr, nullptr, nullptr, Y, M, N, K, relu_in, relu_out, g_x3_dbg, gq, gk, gidx, g_div, g_rows_per_shape, g_nsrc};
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
-  if (nt <= 4) return launch_x3<4, true>(p, st);
-  if (nt <= 8) return launch_x3<8, true>(p, st);
-  if (nt <= 13) return launch_x3<13, true>(p, st);
-  return launch_x3<16, true>(p, st);
+  if (!gq) {      // one table holding the difference already (queries per shape): the look-ahead form
+    if (nt <= 4) return launch_x3<4, 2>(p, st);
+    if (nt <= 8) return launch_x3<8, 2>(p, st);
+    if (nt <= 13) return launch_x3<13, 2>(p, st);
+    return launch_x3<16, 2>(p, st);
+  }
+  if (nt <= 4) return launch_x3<4, 1>(p, st);
+  if (nt <= 8) return launch_x3<8, 1>(p, st);
+  if (nt <= 13) return launch_x3<13, 1>(p, st);
+  return launch_x3<16, 1>(p, st);
 }
 
 int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *bias, const float *residual, float residual_sign,

@@ -108,13 +108,13 @@ def _fwd_x3(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=
 def _fwd_x3_gather(x2, wp, N, b, gather, relu_in, relu_out):
     """_fwd_x3 plus gq[r / g_div] - gk[(r / rows_per_shape) * nsrc + gidx[r]], added in the kernel's epilogue
     (nsdp_linear_bf16x3_gather_f32); gather = (gq [., N], g_div, gk [shapes * nsrc, N], gidx [M] int32, rows_per_shape, nsrc)."""
-    gq, g_div, gk, gidx, rps, nsrc = gather
+    gq, g_div, gk, gidx, rps, nsrc = gather            # gq None: gk holds the difference itself (one table, added)
     M, K = x2.shape
-    if gq.shape[-1] != N or gk.shape[-1] != N or gidx.numel() != M:
+    if (gq is not None and gq.shape[-1] != N) or gk.shape[-1] != N or gidx.numel() != M:
         raise ValueError("init_gather: table width / index count do not match the layer")
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
     with on_device(x2):
-        check(lib().nsdp_linear_bf16x3_gather_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), fptr(gq, "gq"),
+        check(lib().nsdp_linear_bf16x3_gather_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(gq),
                                                   _ci(int(g_div)), fptr(gk, "gk"), ctypes.c_void_p(gidx.data_ptr()),
                                                   _ci(int(rps)), _ci(int(nsrc)), fptr(y), _ll(M), _ci(N), _ci(K),
                                                   _ci(int(relu_in)), _ci(int(relu_out)), stream_ptr()),

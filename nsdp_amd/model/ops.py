@@ -236,8 +236,10 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         d = fc_delta[2].weight.shape[0]
         per_shape = q.shape[1] == 1 and n != 1
         qd, kd = q.detach(), kf.detach()
-        gather = (qd.reshape(-1, d).contiguous(), (n * k) if per_shape else k, kd.reshape(-1, d).contiguous(),
-                  idx.reshape(-1), n * k, kf.shape[1])
+        if per_shape:      # one query per shape: the kernel gathers rows of the small table q - k (its look-ahead form)
+            gather = (None, 1, (qd - kd).reshape(-1, d), idx.reshape(-1), n * k, kf.shape[1])
+        else:
+            gather = (qd.reshape(-1, d).contiguous(), k, kd.reshape(-1, d).contiguous(), idx.reshape(-1), n * k, kf.shape[1])
         h = linear(rel, fc_delta[0], relu=True)
         y = linear(h, fc_delta[2], init_gather=gather)            # values: u; for autograd this node is `pos`
         link = hip_attention.pos_grad_link() if y.requires_grad else None

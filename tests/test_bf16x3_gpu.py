@@ -191,6 +191,8 @@ def test_linear_bf16x3_antiphase_variant_matches_fp64(M, K, N, res, relu_in, rel
 @pytest.mark.parametrize("B,n,k,nsrc,K,N,per_shape,bias,relu_in", [
     (2, 1100, 16, 300, 200, 200, False, True, False),      # per-point rows (set abstraction / transformer block), 13 n tiles
     (3, 4099, 7, 100, 200, 200, True, True, False),        # one query per shape (decoder), ragged row count
+    (2, 9000, 7, 100, 256, 256, True, False, False),       # ... 16 n tiles
+    (4, 3000, 7, 100, 128, 128, True, True, False),        # ... resident-weight form (direct epilogue)
     (2, 1024, 16, 512, 128, 128, False, False, False),     # resident-weight form (direct epilogue), no bias
     (4, 2048, 16, 2048, 120, 120, False, True, False),     # ... ragged last n tile (the set-abstraction layers)
     (1, 70000, 10, 2048, 256, 256, False, True, False),    # 16 n tiles, several row blocks per workgroup
@@ -210,9 +212,14 @@ def test_linear_bf16x3_gathered_addend(B, n, k, nsrc, K, N, per_shape, bias, rel
     gidx = torch.randint(0, nsrc, (M,), generator=g).int().to(DEV)
     assert hip_linear.gather_init_ok(M, N, K)
     wp = hip_linear.pack_weight_x3(w)[0]
-    y = hip_linear._fwd_x3_gather(x, wp, N, b, (gq, n * k if per_shape else k, gk, gidx, n * k, nsrc), relu_in, False)
     rows = torch.arange(M, device=DEV)
-    add = gq[rows // (n * k if per_shape else k)] - gk[(rows // (n * k)) * nsrc + gidx.long()]      # one fp32 subtraction
+    if per_shape:      # the one-table form: q_b - k_bj prepared by the caller
+        table = (gq.view(B, 1, N) - gk.view(B, nsrc, N)).reshape(-1, N)
+        y = hip_linear._fwd_x3_gather(x, wp, N, b, (None, 1, table, gidx, n * k, nsrc), relu_in, False)
+        add = table[(rows // (n * k)) * nsrc + gidx.long()]
+    else:
+        y = hip_linear._fwd_x3_gather(x, wp, N, b, (gq, k, gk, gidx, n * k, nsrc), relu_in, False)
+        add = gq[rows // k] - gk[(rows // (n * k)) * nsrc + gidx.long()]      # one fp32 subtraction
     ref = _ref64(x, w, b, add, None, None, relu_in, False)
     plain = hip_linear._fwd_x3(x, wp, N, b, None, None, None, relu_in, False)
     err = float((y.double() - ref).abs().max())
