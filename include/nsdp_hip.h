@@ -206,6 +206,20 @@ int nsdp_linear_bf16x3_addend_f32(const float *X, const void *Wp, const float *b
                                   const float *out_mask, const float *addend, float *Y, long long M, int N, int K,
                                   int relu_out, void *stream);
 
+/* dX GEMM of a position-encoding MLP's SECOND layer that takes the FIRST (K = 4) layer's weight gradient along.
+ * fc_delta = Linear(3, d) -> ReLU -> Linear(d, d) on relative coordinates (reference model/encoder/blocks.py:86-90, :281-285,
+ * model/decoder/blocks.py:30-34); the coordinates need no gradient, so Y = dY W2 -- the gradient of h0 = relu(X4 W0^T + b0) -- has
+ * one reader: dW0 = (Y o [h0 > 0])^T X4, db0 = column sums of (Y o [h0 > 0]).  This entry runs the GEMM (WpT = bf16x3 pack of W2^T,
+ * dY [M, K], N = width of h0) and forms both in its epilogue: Y is never written (and never read back by a weight-gradient
+ * launch), the ReLU mask is recomputed from the 16-byte input rows X4 [M, 4] (zero-padded coordinates) with the forward kernel's
+ * own expression (W0 [N, 4] row-major, zero-padded; b0 [N] or NULL).  dW0 is [N, k_out] (k_out = 3 or 4: the layer's real input
+ * width), db0 [N] or NULL; accumulate != 0 adds to them.  Deterministic.  Shapes: nsdp_linear_bf16x3_k4tail_ok. */
+int nsdp_linear_bf16x3_k4tail_ok(long long M, int N, int K);
+size_t nsdp_linear_bf16x3_k4tail_workspace_bytes(long long M, int N);
+int nsdp_linear_bf16x3_k4tail_f32(const float *dY, const void *WpT, const float *X4, const float *W0, const float *b0,
+                                  float *dW0, float *db0, long long M, int N, int K, int k_out, int accumulate, float *ws,
+                                  size_t ws_bytes, void *stream);
+
 
 /* Weight/bias gradient of the layer above: dW[N,K] (+)= pre(dY)[M,N]^T * pre(X)[M,K], db[N] (+)= colsum(pre(dY));
  * pre(dY) = dY * (mask[M,N] > 0) when mask != NULL; pre(X) = relu(X) when relu_x.  db may be NULL.

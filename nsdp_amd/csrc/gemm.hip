@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "k4.h"
 #include "pack_bodies.h"
 #include "prof.h"
 
@@ -475,9 +476,7 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 // row lives (fragment-major pack: row n of the only k block is float4 number (n / 16) * 64 + n % 16).
 // pre-activation of a K = 4 layer: ONE expression for the forward kernel and for the weight-gradient kernel that
 // recomputes the layer's ReLU mask from its 16-byte input rows instead of reading the [M, N] output back
-__device__ __forceinline__ float k4_preact(float4 xv, float4 w, float b) {
-  return b + (xv.x * w.x + xv.y * w.y + xv.z * w.z + xv.w * w.w);
-}
+using nsdp::k4_preact;      // (k4.h)
 
 template <bool WP>
 __global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
@@ -972,6 +971,7 @@ void debug_set_x3(int value);   // gemm_bf16x3.hip
 void debug_set_wg16(int value);  // gemm_bf16.hip
 void debug_set_lin16(int value);
 void debug_set_wg3(int value);   // wgrad_bf16x3.hip
+void debug_set_x3_reserve(int value);   // gemm_bf16x3.hip
 }
 
 extern "C" {
@@ -984,7 +984,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 6) nsdp::debug_set_x3(value);
   if (key == 7) nsdp::debug_set_wg16(value);
   if (key == 8) nsdp::debug_set_lin16(value);
-  if (key == 9) nsdp::debug_set_wg3(value);
+  if (key == 9) { nsdp::debug_set_wg3(value); nsdp::debug_set_x3_reserve(value); }
 }
 
 static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,

@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "k4.h"
 #include "pack_bodies.h"
 #include "prof.h"
 
@@ -41,6 +42,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 int g_x3_dbg = 0;
+int g_x3_side_reserve = 0;      // compute units a K = 4 tail launch leaves free (host hint 9: it runs on the weight-gradient side stream)
 
 #ifdef NSDP_X3_TIMING
 // phase timers (s_memtime ticks summed over waves): 0 steps, 1 bottom wait, 2 barrier, 3 epilogue, 4 tile prologue, 5 total
@@ -72,6 +74,12 @@ struct X3Params {
   // added AFTER the output mask (nsdp_linear_bf16x3_addend_f32, masked-prologue forms with an out_mask): the gradient arriving
   // over the skip connection of x + f(relu(x)), which the ReLU's mask must not touch
   const float *addend = nullptr;
+  // TAIL forms (nsdp_linear_bf16x3_k4tail_f32): Y = dY W2 is the gradient of h0 = relu(x4 W0^T + b0), the hidden layer of a
+  // position-encoding MLP whose input (relative coordinates) needs no gradient -- so the only reader of Y is the K = 4 layer's
+  // weight gradient dW0 = (Y o [h0 > 0])^T x4, db0 = its column sums.  The epilogue forms them itself: Y is never stored, the
+  // ReLU mask is recomputed from the 16-byte input rows (k4.h), every wave writes ONE partial (80 floats per n tile) per row tile to t_ws
+  const float *t_x4 = nullptr, *t_w0 = nullptr, *t_b0 = nullptr;
+  float *t_ws = nullptr;
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -94,6 +102,52 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for<I + 1, N>(f);
   }
 }
+
+// Sums over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15) of 20 values at once, the totals in every lane; fixed order:
+// pairs, quads, halves, row.  One v_add_f32 with a DPP operand per value and step -- left to the compiler this became
+// v_mov 0 / v_mov_dpp / v_pk_add (2.5 instructions per step).  Written as four blocks of 20 independent instructions: the
+// two wait states a DPP read needs after a VALU write of the same register are covered by the s_nop at the head of a block
+// (the compiler's hazard recognizer does not look inside inline asm) and by the 19 other instructions within it.
+#define NSDP_DPP4(CTRL, A, B, C, D)                                                                                              \
+  asm("s_nop 1\n\t"                                                                                                              \
+      "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\t"            \
+      "v_add_f32_dpp %3, %3, %3 " CTRL "\n\ts_nop 1"                                                                              \
+      : "+v"(A), "+v"(B), "+v"(C), "+v"(D))
+#define NSDP_DPP16(CTRL, T)                                                                                                      \
+  asm("s_nop 1\n\t"                                                                                                              \
+      "v_add_f32_dpp %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\tv_add_f32_dpp %2, %2, %2 " CTRL "\n\t"            \
+      "v_add_f32_dpp %3, %3, %3 " CTRL "\n\tv_add_f32_dpp %4, %4, %4 " CTRL "\n\tv_add_f32_dpp %5, %5, %5 " CTRL "\n\t"            \
+      "v_add_f32_dpp %6, %6, %6 " CTRL "\n\tv_add_f32_dpp %7, %7, %7 " CTRL "\n\tv_add_f32_dpp %8, %8, %8 " CTRL "\n\t"            \
+      "v_add_f32_dpp %9, %9, %9 " CTRL "\n\tv_add_f32_dpp %10, %10, %10 " CTRL "\n\tv_add_f32_dpp %11, %11, %11 " CTRL "\n\t"      \
+      "v_add_f32_dpp %12, %12, %12 " CTRL "\n\tv_add_f32_dpp %13, %13, %13 " CTRL "\n\tv_add_f32_dpp %14, %14, %14 " CTRL "\n\t"   \
+      "v_add_f32_dpp %15, %15, %15 " CTRL "\n\ts_nop 1"                                                                           \
+      : "+v"(T[0]), "+v"(T[1]), "+v"(T[2]), "+v"(T[3]), "+v"(T[4]), "+v"(T[5]), "+v"(T[6]), "+v"(T[7]), "+v"(T[8]), "+v"(T[9]),   \
+        "+v"(T[10]), "+v"(T[11]), "+v"(T[12]), "+v"(T[13]), "+v"(T[14]), "+v"(T[15]))
+// t[0 .. 15]: the products d * x4[k] (index 4 c + k), t[16 .. 19]: the column sums.  K3: x4[3] is zero padding -- the products
+// 4 c + 3 are zeros and stay out of it (16 values instead of 20)
+template <bool K3>
+__device__ __forceinline__ void row16_sum20(float (&t)[20]) {
+  if constexpr (K3) {
+    float u[16] = {t[0], t[1], t[2], t[4], t[5], t[6], t[8], t[9], t[10], t[12], t[13], t[14], t[16], t[17], t[18], t[19]};
+    NSDP_DPP16("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", u);
+    NSDP_DPP16("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", u);
+    NSDP_DPP16("row_half_mirror row_mask:0xf bank_mask:0xf", u);
+    NSDP_DPP16("row_mirror row_mask:0xf bank_mask:0xf", u);
+    t[0] = u[0]; t[1] = u[1]; t[2] = u[2]; t[4] = u[3]; t[5] = u[4]; t[6] = u[5]; t[8] = u[6]; t[9] = u[7]; t[10] = u[8];
+    t[12] = u[9]; t[13] = u[10]; t[14] = u[11]; t[16] = u[12]; t[17] = u[13]; t[18] = u[14]; t[19] = u[15];
+  } else {
+    NSDP_DPP16("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", t);
+    NSDP_DPP4("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", t[16], t[17], t[18], t[19]);
+    NSDP_DPP16("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", t);
+    NSDP_DPP4("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf", t[16], t[17], t[18], t[19]);
+    NSDP_DPP16("row_half_mirror row_mask:0xf bank_mask:0xf", t);
+    NSDP_DPP4("row_half_mirror row_mask:0xf bank_mask:0xf", t[16], t[17], t[18], t[19]);
+    NSDP_DPP16("row_mirror row_mask:0xf bank_mask:0xf", t);
+    NSDP_DPP4("row_mirror row_mask:0xf bank_mask:0xf", t[16], t[17], t[18], t[19]);
+  }
+}
+#undef NSDP_DPP16
+#undef NSDP_DPP4
 
 // hand-issued activation loads (the compiler would sink them to their first use, see decoder_fused.hip)
 __device__ __forceinline__ void xload(f32x4 &dst, const float *lane_ptr) {
@@ -143,9 +197,10 @@ __device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *unif
 // drift apart and one wave's epilogue stores sit under the other waves' MFMA steps (the streaming form re-fetches the
 // planes L2 -> LDS for every 256-row tile: as many bytes as the HBM traffic, and its per-k-block barrier keeps all waves
 // in the same phase).
-template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, int GATHER = 0>
+template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, int GATHER = 0, int TAIL = 0>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
   static_assert(!GATHER || PRE == 0, "the gathered addend belongs to the plain-prologue forms");
+  static_assert(!TAIL || (PRE == 0 && !GATHER), "the K = 4 tail belongs to the plain-prologue forms");
   constexpr bool WRES = KBM > 2;
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
@@ -164,7 +219,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr int kCap = (kTwoPerCu ? 80 : 160) * 64;                          // LDS budget in u32x4
   constexpr int kBiasLds = NT * 4;                                           // u32x4: the bias vector, staged once per workgroup
   constexpr int kExtFree = kCap - KBM * kWTile - kXTile - kBiasLds;
-  constexpr bool kStage = !WRES && kExtFree >= 0;                            // (resident weights fill the LDS: direct epilogue)
+  constexpr bool kStage = !WRES && kExtFree >= 0 && !TAIL;                   // (resident weights fill the LDS: direct epilogue; the K = 4 tail stores no tile)
   constexpr int kExtWant = WV * NT * 64 - kWTile;                            // whole 16-row tiles for every wave
   constexpr int kExt = !kStage ? 0 : (kExtWant < 0 ? 0 : (kExtFree < 0 ? 0 : (kExtWant < kExtFree ? kExtWant : kExtFree)));
   constexpr int kPerWave = (kWTile + kExt) / WV;                             // u32x4 of epilogue staging per wave
@@ -174,7 +229,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   static_assert(!kStage || kTppMax >= 1, "epilogue staging: no room for a 16 x 16 tile per wave");
   __shared__ __attribute__((aligned(16))) u32x4 wlds[KBM * kWTile + kExt];
   __shared__ __attribute__((aligned(16))) u32x4 xbuf[kXLds ? 2 : 1][kXLds ? WV : 1][kXLds ? MT * 2 * 64 : 1];
-  __shared__ __attribute__((aligned(16))) float bias_lds[kStage ? NT * 16 : 4];      // (zeros without a bias: read unconditionally)
+  __shared__ __attribute__((aligned(16))) float bias_lds[(kStage || TAIL) ? NT * 16 : 4];      // (zeros without a bias: read unconditionally)
+  // K = 4 tail: the K = 4 layer's weight rows [n][4] and (in bias_lds) its bias, staged once per workgroup; the 16-byte input rows
+  // of the wave's current tile, DMA'd at the tile's start (one KiB per wave: lane l holds row min(l, MT * 16 - 1))
+  __shared__ __attribute__((aligned(16))) f32x4 t_w0lds[TAIL ? NT * 16 : 1];
+  __shared__ __attribute__((aligned(16))) f32x4 t_x4lds[TAIL ? WV * 64 : 1];
+  static_assert(!TAIL || !WRES, "the K = 4 tail needs 1 KiB of LDS per wave and 272 B per n tile next to the weight buffers");
+  static_assert(!TAIL || MT * 16 <= 64, "the K = 4 tail stages one input row per lane");
   // buffer b of the weight ring: the extension sits between buffers 0 and 1, so that whichever of the two is free forms one
   // contiguous region with it
   auto wbuf_at = [&](int b) -> u32x4 * { return wlds + b * kWTile + (b >= 1 ? kExt : 0); };
@@ -279,6 +340,12 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   if constexpr (kStage) {
     for (int c = threadIdx.x; c < NT * 16; c += WV * 64) bias_lds[c] = (p.bias && c < p.N) ? p.bias[c] : 0.f;      // visible after the prologue's barrier
   }
+  if constexpr (TAIL) {
+    for (int c = threadIdx.x; c < NT * 16; c += WV * 64) {
+      bias_lds[c] = (p.t_b0 && c < p.N) ? p.t_b0[c] : 0.f;
+      t_w0lds[c] = c < p.N ? *reinterpret_cast<const f32x4 *>(p.t_w0 + static_cast<long long>(c) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   // stagger the persistent workgroups by eighths of a tile time (~640 cycles per k block): all of them run the same
   // program on the same amount of work, and without it their epilogue store bursts hit HBM at the same moments
   // (measured: -7 % time on the 1.8 M-row layers).  Only worth it when a workgroup has several tiles to go.
@@ -323,6 +390,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     X3_T(t_tile0);
     const long long row0 = (tile * WV + wave) * (MT * 16);
     const bool next_tile = tile + stride < wg_tiles;
+    if constexpr (TAIL) {
+      // this tile's 16-byte input rows of the K = 4 layer: global -> LDS by DMA, no registers; older than every load the k loop
+      // issues and waits for, so it has landed when the epilogue reads it (vector memory operations return in order)
+      long long r = row0 + (lane < MT * 16 ? lane : MT * 16 - 1);
+      r = r < p.M ? r : p.M - 1;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.t_x4 + r * 4), (lds_ptr_t)(&t_x4lds[wave * 64]), 16, 0, 0);
+    }
     // (opaque per-tile copies of the lane coordinates: everything the prologue / epilogue derives from them is
     // tile-invariant, and LICM would otherwise keep ~60 such values live across the whole k loop)
     int li_t = li, g_t = g;
@@ -645,8 +719,61 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           });
         });
       };
+      // ---- K = 4 tail: nothing is stored but one partial per wave tile.  In the accumulator layout lane (li, g) holds row li and the
+      // columns 16 nt + 4 g .. + 3 of every n tile: d = y * [pre-activation of the K = 4 layer > 0] (recomputed from the lane's own
+      // 16-byte input row, k4.h), the 16 products d * x4 and the 4 column sums are added up over the wave's row tiles in the lane,
+      // then over the 16 lanes of the row group by four DPP steps (fixed order); lane li = 0 of each g writes 5 float4.
+      auto direct_tail = [&]() __attribute__((always_inline)) {      // (as a CALL it would spill the accumulators)
+        f32x4 xr[MT];
+        bool rvm[MT];
+        const unsigned x4a = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&t_x4lds[wave * 64]))) + static_cast<unsigned>(li_e) * 16u;
+        const unsigned w0a = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&t_w0lds[0]))) + static_cast<unsigned>(g_e) * 64u;
+        static_for<0, MT>([&](auto MI) {
+          constexpr int mt = decltype(MI)::value;
+          rvm[mt] = row0 + mt * 16 + li_e < p.M;
+          lds_read_f4<mt * 256>(xr[mt], x4a);
+        });
+        float *wsp = p.t_ws + (tile * WV + wave) * static_cast<long long>(NT * 80) + g_e * 20;
+        static_for<0, NT>([&](auto NI) {
+          constexpr int nt = decltype(NI)::value;
+          const int col = nt * 16 + 4 * g_e;
+          const bool cv = col < N;                                      // (N % 4 == 0: a column quad exists or does not)
+          f32x4 w0[4], b0;
+          static_for<0, 4>([&](auto CI) {
+            constexpr int c = decltype(CI)::value;
+            lds_read_f4<(nt * 16 + c) * 16>(w0[c], w0a);      // rows 16 nt + 4 g + c (zeros beyond N)
+          });
+          lds_read_f4<nt * 64>(b0, ldsb + static_cast<unsigned>(16 * g_e));
+          float ta[20];
+#pragma unroll
+          for (int v = 0; v < 20; ++v) ta[v] = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const float4 xq = make_float4(xr[mt][0], xr[mt][1], xr[mt][2], xr[mt][3]);
+            const bool ok = rvm[mt] && cv;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float pre = nsdp::k4_preact(xq, make_float4(w0[c][0], w0[c][1], w0[c][2], w0[c][3]), b0[c]);
+              const float d = (ok && pre > 0.f) ? acc[mt][nt][c] : 0.f;
+              ta[16 + c] += d;
+#pragma unroll
+              for (int k = 0; k < (TAIL == 2 ? 3 : 4); ++k) ta[4 * c + k] += d * xr[mt][k];
+            }
+          }
+          row16_sum20<TAIL == 2>(ta);
+          if (li_e == 0) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+              *reinterpret_cast<f32x4 *>(wsp + nt * 80 + j * 4) = f32x4{ta[4 * j], ta[4 * j + 1], ta[4 * j + 2], ta[4 * j + 3]};
+          }
+        });
+      };
       auto epilogue = [&](auto has_omask) {
         const int full_tiles = N >> 4;  // tiles whose 16 columns are all valid
+        if constexpr (TAIL) {
+          direct_tail();
+          return;
+        }
         if constexpr (kStage) {
           staged(has_omask);
           return;
@@ -709,6 +836,47 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   if (lane == 0)
     for (int i = 0; i < 6; ++i) atomicAdd(&g_x3_timers[i], t_acc[i]);
 #endif
+}
+
+// K = 4 tail, reduction of the per-wave-tile partials [n tile][g][20] (16 products c * 4 + k, then 4 column sums).  Stage 1:
+// workgroup b sums the tiles b, b + grid, ... float4-wise (the layout is the same for every tile) -> part[b]; fixed order.
+__global__ __launch_bounds__(512) void x3_tail_sum_tiles_kernel(const f32x4 *__restrict__ ws, long long tiles, int quads,
+                                                                f32x4 *__restrict__ part) {
+  const int q = threadIdx.x;
+  if (q >= quads) return;
+  f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  long long t = blockIdx.x;
+  const long long g = gridDim.x;
+  for (; t + 3 * g < tiles; t += 4 * g) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] += ws[(t + u * g) * quads + q];
+  }
+  for (; t < tiles; t += g) a[0] += ws[t * quads + q];
+  part[static_cast<long long>(blockIdx.x) * quads + q] = (a[0] + a[1]) + (a[2] + a[3]);
+}
+// Stage 2: partials [S][n tiles][4][20] -> dW [N][k_out] (the layer's own input width: 3 or 4), db [N]
+__global__ __launch_bounds__(256) void x3_tail_reduce_kernel(const float *__restrict__ part, int S, int N, int ntiles, int k_out,
+                                                             float *__restrict__ dW, float *__restrict__ db, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;      // e < 4 N: dW[n][k], n = e / 4; else db[e - 4 N]
+  if (e >= 5 * N) return;
+  const int n = e < 4 * N ? (e >> 2) : (e - 4 * N);
+  const int v = e < 4 * N ? 4 * (n & 3) + (e & 3) : 16 + (n & 3);
+  const long long stride = static_cast<long long>(ntiles) * 80;
+  const float *src = part + (n >> 2) * 20 + v;      // ((n / 16) * 4 + (n % 16) / 4) * 20
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 loads in flight per lane
+  int i = 0;
+  for (; i + 8 <= S; i += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += src[(i + u) * stride];
+  }
+  for (; i < S; ++i) acc[0] += src[i * stride];
+  const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  if (e < 4 * N) {
+    const int k = e & 3;
+    if (k < k_out) dW[n * k_out + k] = accumulate ? dW[n * k_out + k] + s : s;
+  } else if (db) {
+    db[n] = accumulate ? db[n] + s : s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1116,6 +1284,34 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   return nsdp::launch_status("linear_bf16x3_kernel");
 }
 
+// K = 4 tail: the forms the position-encoding MLPs of the TDNet step take at scale (their dX GEMMs have square weights)
+constexpr int kTailGrid = 256;      // stage-1 partials
+template <int MT, int NT, int WV, int KBM = 2>
+struct TailForm {
+  static constexpr int kTailFloats = NT * 80;      // a wave tile's partial: [n tile][g][20]
+  static long long wave_tiles(long long M) { return (M + MT * 16 - 1) / (MT * 16); }
+  static size_t ws_floats(long long M) { return static_cast<size_t>(wave_tiles(M) + kTailGrid) * kTailFloats; }
+  static void launch(X3Params p, int k_out, float *dW0, float *db0, int accumulate, hipStream_t st) {
+    const long long rows_per_wg = static_cast<long long>(WV) * MT * 16;
+    const long long wg_tiles = (p.M + rows_per_wg - 1) / rows_per_wg;
+    const long long slots = nsdp::num_cus() - (g_x3_side_reserve > 0 && g_x3_side_reserve < nsdp::num_cus() ? g_x3_side_reserve : 0);
+    const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
+    NSDP_TRACE("linear_bf16x3<%d,%d,0,%d,0> k4tail", MT, NT, WV);
+    // (k_out = 3: the fourth input column is zero padding -- its products stay out of the reduction)
+    if (k_out == 3) hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 0, WV, false, KBM, 0, 2>), dim3(grid), dim3(WV * 64), 0, st, p);
+    else hipLaunchKernelGGL((linear_bf16x3_kernel<MT, NT, 0, WV, false, KBM, 0, 1>), dim3(grid), dim3(WV * 64), 0, st, p);
+    const long long tiles = wave_tiles(p.M);
+    const int quads = kTailFloats / 4;
+    const int S = static_cast<int>(tiles < kTailGrid ? tiles : kTailGrid);
+    float *part = p.t_ws + tiles * kTailFloats;
+    hipLaunchKernelGGL(x3_tail_sum_tiles_kernel, dim3(S), dim3(512), 0, st, reinterpret_cast<const f32x4 *>(p.t_ws), tiles, quads,
+                       reinterpret_cast<f32x4 *>(part));
+    hipLaunchKernelGGL(x3_tail_reduce_kernel, dim3((5 * p.N + 255) / 256), dim3(256), 0, st, part, S, p.N, NT, k_out, dW0, db0,
+                       accumulate);
+  }
+};
+inline int tail_tiles(int N) { const int nt = (N + 15) / 16; return nt > 8 && nt <= 13 ? 13 : nt > 13 && nt <= 16 ? 16 : 0; }
+
 }  // namespace
 
 namespace nsdp {
@@ -1127,6 +1323,7 @@ extern "C" void nsdp_debug_x3_timers(unsigned long long *out, int reset) {
 }
 #endif
 void debug_set_x3(int value) { g_x3_dbg = value; }
+void debug_set_x3_reserve(int value) { g_x3_side_reserve = value; }
 }  // namespace nsdp
 
 extern "C" {
@@ -1219,6 +1416,39 @@ int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *b
   if (nt <= 8) return launch_x3<8>(p, st);
   if (nt <= 13) return launch_x3<13>(p, st);
   return launch_x3<16>(p, st);
+}
+
+// Can the dX GEMM dY [M,K] x W2 [K,N] of a position-encoding MLP's second layer take the first (K = 4) layer's weight gradient
+// along (nsdp_linear_bf16x3_k4tail_f32)?  N = width of the hidden layer.
+int nsdp_linear_bf16x3_k4tail_ok(long long M, int N, int K) {
+  return M >= 65536 && M < (1LL << 31) && K > 32 && K % 4 == 0 && N % 4 == 0 && N <= 256 && tail_tiles(N) != 0;
+}
+size_t nsdp_linear_bf16x3_k4tail_workspace_bytes(long long M, int N) {
+  if (M <= 0) return 0;
+  return sizeof(float) * (tail_tiles(N) == 13 ? TailForm<2, 13, 8>::ws_floats(M) : TailForm<3, 16, 4>::ws_floats(M));
+}
+// dW0 [N, k_out], db0 [N] of h0 = relu(X4 W0^T + b0) from the gradient dY [M, K] of the NEXT layer's output: the dX GEMM
+// Y = dY W2 (WpT = bf16x3 pack of W2^T, as for nsdp_linear_bf16x3_f32) with the masked reduction Y^T X4 in its epilogue; Y is
+// never written.  X4 [M,4] (zero-padded coordinates), W0 [N,4] row-major zero-padded, b0 [N] or NULL.  accumulate: add to
+// dW0 / db0.  Deterministic (fixed summation order).
+int nsdp_linear_bf16x3_k4tail_f32(const float *dY, const void *WpT, const float *X4, const float *W0, const float *b0,
+                                  float *dW0, float *db0, long long M, int N, int K, int k_out, int accumulate, float *ws,
+                                  size_t ws_bytes, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(dY && WpT && X4 && W0 && dW0 && ws, "linear_bf16x3_k4tail: null pointer");
+  NSDP_REQUIRE(nsdp_linear_bf16x3_k4tail_ok(M, N, K), "linear_bf16x3_k4tail: unsupported shape M=%lld N=%d K=%d", M, N, K);
+  NSDP_REQUIRE(k_out == 3 || k_out == 4, "linear_bf16x3_k4tail: k_out=%d (the layer's input width) must be 3 or 4", k_out);
+  NSDP_REQUIRE(ws_bytes >= nsdp_linear_bf16x3_k4tail_workspace_bytes(M, N), "linear_bf16x3_k4tail: workspace too small");
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(WpT) | reinterpret_cast<uintptr_t>(X4) |
+                 reinterpret_cast<uintptr_t>(W0) | reinterpret_cast<uintptr_t>(b0) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+               "linear_bf16x3_k4tail: all operands must be 16-byte aligned");
+  X3Params p{dY, WpT, nullptr, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 0, g_x3_dbg};
+  p.t_x4 = X4; p.t_w0 = W0; p.t_b0 = b0; p.t_ws = ws;
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + 4) + static_cast<double>(N) * K));
+  if (tail_tiles(N) == 13) TailForm<2, 13, 8>::launch(p, k_out, dW0, db0, accumulate, st);
+  else TailForm<3, 16, 4>::launch(p, k_out, dW0, db0, accumulate, st);
+  return nsdp::launch_status("linear_bf16x3_kernel (k4 tail)");
 }
 
 int nsdp_linear_bf16x3_addend_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,

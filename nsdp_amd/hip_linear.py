@@ -555,11 +555,64 @@ class SkipGrad:
         self.buf = None
 
 
+# A/B knobs of K4Tail.  NSDP_K4_LINK=0: no link at all (the hidden tensor's gradient goes through autograd: dX GEMM on the main
+# stream, the K = 4 weight gradient on the side stream).  NSDP_K4_TAIL=0: linked, but always the two launches (no fused epilogue).
+# NSDP_K4_TAIL_SIDE=0: the linked launches stay on the main stream.  Measured at B = 32, one box, three interleaved rounds:
+# no link 41.55 / 41.34 / 41.42 ms, fused tail on the main stream 41.54 / 41.79 / 41.71, on the side stream 41.03 / 40.98 / 41.14.
+K4_LINK = os.environ.get("NSDP_K4_LINK", "1") != "0"
+K4_TAIL = os.environ.get("NSDP_K4_TAIL", "1") != "0"
+K4_TAIL_SIDE = os.environ.get("NSDP_K4_TAIL_SIDE", "1") != "0"
+
+
+class K4Tail:
+    """Link between the two layers of a position-encoding MLP Linear(3, d) -> ReLU -> Linear(d, d) whose input (relative
+    coordinates) needs no gradient.  The gradient of the hidden tensor h0 then has ONE reader, the first layer's weight gradient:
+    (a) that dX GEMM is weight-gradient work, not part of the critical chain: it runs on the weight-gradient side stream; (b) where
+    the kernel has the form (13- and 16-tile streaming forms) the GEMM forms dW0 / db0 in its epilogue
+    (nsdp_linear_bf16x3_k4tail_f32) -- the [rows, d] gradient is neither written nor read back, and the ReLU mask is recomputed
+    from the 16-byte coordinate rows.  The first layer (``tail_src``) arms the link and leaves its operands here; the second
+    (``tail_dst``, the ONLY reader of h0) takes it, publishes the first layer's weight gradient from its own backward and
+    reports no input gradient: the first layer's backward then receives None and does nothing."""
+    __slots__ = ("armed", "taken", "x4", "w_param", "b_param", "k_orig", "fwd_key")
+
+    def __init__(self):
+        self.armed = self.taken = False
+        self.x4 = self.w_param = self.b_param = self.k_orig = self.fwd_key = None
+
+
+def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
+    """Weight-gradient routine (the `fn` protocol of wgrad_direct / _wgrad_deferred) of the K = 4 layer behind `link`, run from the
+    NEXT layer's backward: dy2 is that layer's output gradient [M, K], wpt its W^T pack, h0 its input (the K = 4 layer's output).
+    One launch where the dX GEMM has the tail form, otherwise the dX GEMM and the K = 4 weight-gradient kernel back to back --
+    on whatever stream the caller put it (nothing on the critical chain reads the hidden tensor's gradient)."""
+    def fn(dy2, x4, mask, relu_x, want_db, out=None):
+        M, K = dy2.shape
+        L = lib()
+        b0 = None if link.b_param is None else link.b_param.detach()
+        if not (K4_TAIL and kind_t == "x3" and L.nsdp_linear_bf16x3_k4tail_ok(_ll(M), _ci(n_hidden), _ci(K))):
+            dh = _run(kind_t, dy2, wpt, n_hidden, None, None, None, None, False, False)
+            if REMASK_K4 and n_hidden % 4 == 0 and n_hidden >= 16 and M >= 4096:
+                return _wgrad_k4_remask(_padded_w4(link.w_param), b0, link.k_orig)(dh, x4, None, False, want_db, out)
+            return _wgrad_sliced(dh, x4, h0, False, want_db, link.k_orig, out)
+        L.nsdp_linear_bf16x3_k4tail_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.nsdp_linear_bf16x3_k4tail_workspace_bytes(_ll(M), _ci(n_hidden)))
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dy2.device)
+        dw, db, acc = wgrad_out(out, n_hidden, link.k_orig, want_db, dy2.device)
+        with on_device(dy2):
+            check(L.nsdp_linear_bf16x3_k4tail_f32(fptr(dy2, "dy"), ctypes.c_void_p(wpt.data_ptr()), fptr(x4, "x4"),
+                                                  fptr(_padded_w4(link.w_param), "w0"), optptr(b0), fptr(dw), optptr(db), _ll(M),
+                                                  _ci(n_hidden), _ci(K), _ci(int(link.k_orig)), _ci(acc), fptr(ws),
+                                                  ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_bf16x3_k4tail_f32")
+        return dw, db
+    return fn
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                pre=None, init_gather=None, res_sign=1.0, skip=None):
-        # skip: (SkipGrad, is_src) -- see SkipGrad
+                pre=None, init_gather=None, res_sign=1.0, skip=None, tail=None):
+        # skip: (SkipGrad, is_src) -- see SkipGrad;  tail: (K4Tail, is_src) -- see K4Tail
+        ctx.tail = None
         ctx.skip_src = ctx.skip_dst = None
         if skip is not None:
             link, is_src = skip
@@ -609,6 +662,20 @@ class _LinearFn(torch.autograd.Function):
         kind_t = "x3" if _x3_ok(M, Kp, N) else "wp"                    # dX: Kp outputs, N is the reduction dim
         wp = _packs(w, owner, kind, want_t and kind_t == kind)[0]
         wpt = _packs(w, owner, kind_t, True)[1] if want_t else None
+        if tail is not None:
+            tlink, t_src = tail
+            if t_src:
+                # first layer: K = 3 / 4 coordinates that need no gradient, output ReLU, direct publication of the weight gradient
+                if (not ctx.needs_input_grad[0] and w_param is not None and Kp == 4 and relu_out and not relu_in
+                        and res2 is None and grad_sum is None and not bw and N % 4 == 0):
+                    tlink.armed = True
+                    tlink.x4, tlink.w_param, tlink.b_param, tlink.k_orig = x2, w_param, b_param, K
+                    tlink.fwd_key = _pack_key(w_param)
+                    ctx.set_materialize_grads(False)      # (a taken link: this node's backward receives None)
+            elif (tlink.armed and want_t and not relu_in and not (bw & 2) and grad_sum is None and ctx.skip_dst is None
+                  and Kp == K and N % 4 == 0 and M == tlink.x4.shape[0]):
+                tlink.taken = True
+                ctx.tail = tlink
         if pre is not None:
             y = pre.reshape(M, N)
         elif init_gather is not None:
@@ -627,6 +694,8 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:          # (K4Tail: the next layer's dX GEMM produced this layer's weight gradient itself)
+            return (None,) * 16
         x2, wpt, y = ctx.saved_tensors
         N = ctx.n_out
         dy2 = dy.reshape(-1, N)
@@ -648,7 +717,17 @@ class _LinearFn(torch.autograd.Function):
                 wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
-        if ctx.needs_input_grad[0]:
+        tl = ctx.tail
+        if tl is not None and ctx.needs_input_grad[0] and tl.fwd_key == _pack_key(tl.w_param):
+            # the dX GEMM with the K = 4 layer's weight gradient in its epilogue: no input gradient to report
+            # -- and since nothing on the critical chain reads that gradient, the whole GEMM is weight-gradient work: side stream
+            tfn = _k4tail_fn(tl, wpt, x2.shape[1], ctx.kind_t, x2)
+            if K4_TAIL_SIDE and _use_side_stream(dy2):
+                _wgrad_deferred(dy2, tl.x4, None, False, tl.k_orig, tl.w_param, tl.b_param, fn=tfn)
+                wpt.record_stream(_side_stream(dy2.device))
+            else:
+                wgrad_direct(dy2, tl.x4, None, False, tl.k_orig, tl.w_param, tl.b_param, fn=tfn)
+        elif ctx.needs_input_grad[0]:
             dyk, mk = dy2, y
             if N % 4:                                      # N = 3 (fc_out): pad the reduction dimension
                 dyk = _pad_cols(dy2)
@@ -676,7 +755,7 @@ class _LinearFn(torch.autograd.Function):
             dres = dres.reshape(dy.shape)
             if ctx.res_sign != 1.0:
                 dres = -dres
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -711,7 +790,7 @@ def _observed(t):
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
            out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None, residual_sign=1.0,
-           skip_src=None, skip_dst=None):
+           skip_src=None, skip_dst=None, tail_src=None, tail_dst=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -758,10 +837,11 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if skip_src is not None and skip_dst is not None:
         raise ValueError("a layer is either end of a SkipGrad link")
     skip = (skip_src, True) if skip_src is not None else (skip_dst, False) if skip_dst is not None else None
+    tail = (tail_src, True) if tail_src is not None else (tail_dst, False) if tail_dst is not None else None
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
                                bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather,
-                               float(residual_sign), skip)
+                               float(residual_sign), skip, tail)
     return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed,
-                           init_gather, float(residual_sign), skip)
+                           init_gather, float(residual_sign), skip, None)

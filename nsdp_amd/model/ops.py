@@ -112,14 +112,25 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
            out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None,
-           init_gather=None, residual_sign: float = 1.0, skip_src=None, skip_dst=None) -> torch.Tensor:
+           init_gather=None, residual_sign: float = 1.0, skip_src=None, skip_dst=None, tail_src=None,
+           tail_dst=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
                              precomputed=precomputed, init_gather=init_gather, residual_sign=residual_sign,
-                             skip_src=skip_src, skip_dst=skip_dst)
+                             skip_src=skip_src, skip_dst=skip_dst, tail_src=tail_src, tail_dst=tail_dst)
+
+
+def k4_tail(x: torch.Tensor, seq: nn.Sequential):
+    """hip_linear.K4Tail for a position-encoding MLP ``seq`` = Sequential(Linear(3 or 4, d), ReLU, Linear(d, d)) applied to
+    coordinates ``x`` that need no gradient (None otherwise): the second layer's dX GEMM then produces the first layer's
+    weight gradient in its epilogue, and the gradient of the hidden tensor is never materialised."""
+    if (hip_linear.K4_LINK and torch.is_grad_enabled() and not x.requires_grad and not precision.is_bf16() and not PAIR_MASK
+            and x.shape[-1] in (3, 4) and seq[0].weight.requires_grad):
+        return hip_linear.K4Tail()
+    return None
 
 
 def input_grad_sum(x: torch.Tensor):
@@ -148,7 +159,8 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
         return linear(linear(x, seq[0], grad_sum=grad_sum), seq[2], relu_in=True)
     if PAIR_MASK and torch.is_grad_enabled():
         return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, premasked=True), seq[2], mask_dx=True)
-    return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum), seq[2])
+    tl = k4_tail(x, seq) if grad_sum is None else None
+    return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, tail_src=tl), seq[2], tail_dst=tl)
 
 
 def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = False) -> torch.Tensor:
@@ -240,8 +252,9 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
             gather = (None, 1, (qd - kd).reshape(-1, d), idx.reshape(-1), n * k, kf.shape[1])
         else:
             gather = (qd.reshape(-1, d).contiguous(), k, kd.reshape(-1, d).contiguous(), idx.reshape(-1), n * k, kf.shape[1])
-        h = linear(rel, fc_delta[0], relu=True)
-        y = linear(h, fc_delta[2], init_gather=gather)            # values: u; for autograd this node is `pos`
+        tl = k4_tail(rel, fc_delta)
+        h = linear(rel, fc_delta[0], relu=True, tail_src=tl)
+        y = linear(h, fc_delta[2], init_gather=gather, tail_dst=tl)            # values: u; for autograd this node is `pos`
         link = hip_attention.pos_grad_link() if y.requires_grad else None
         if link is not None and FUSE_DPOS:
             link.grad_sum = hip_linear.InputGradSum()

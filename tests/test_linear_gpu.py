@@ -417,3 +417,51 @@ def test_k4_weight_gradient_with_recomputed_relu_mask(k, n, M, bias):
         assert torch.equal(a, b)
     for a, r in zip(got[0], ref):
         assert torch.allclose(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+
+
+@pytest.mark.parametrize("k,d,M,bias", [(3, 200, 200_003, True), (4, 256, 100_000, True), (3, 256, 65_536 + 17, False),
+                                        (3, 200, 65_536, True)])
+def test_k4_tail_weight_gradient_out_of_the_dx_gemm(k, d, M, bias):
+    """Position-encoding MLP Linear(k, d) -> ReLU -> Linear(d, d) on coordinates that need no gradient: the second layer's dX
+    GEMM forms the first layer's dW / db in its epilogue (nsdp_linear_bf16x3_k4tail_f32, ops.k4_tail) -- the [M, d] gradient of
+    the hidden tensor is never written.  Against fp64 autograd and against the two-launch path (same mask decisions: the ReLU
+    mask recomputed from the coordinates is the forward kernel's expression); deterministic; accumulates into existing grads."""
+    from nsdp_amd import hip_linear
+    from nsdp_amd.model import ops
+    from test_model_gpu import _variant_trace
+    torch.manual_seed(M + d)
+    seq = torch.nn.Sequential(torch.nn.Linear(k, d, bias=bias), torch.nn.ReLU(), torch.nn.Linear(d, d)).to(DEV)
+    x = torch.randn(M, k, device=DEV)
+    t = torch.randn(M, d, device=DEV)
+    seq64 = torch.nn.Sequential(torch.nn.Linear(k, d, bias=bias), torch.nn.ReLU(), torch.nn.Linear(d, d)).to(DEV).double()
+    seq64.load_state_dict(seq.state_dict())
+    (seq64(x.double()) * t.double()).sum().backward()
+    ref = [p.grad for p in seq64.parameters()]
+    got = {}
+    trace = {}
+    for mode in ("tail", "two", "tail", "nolink"):        # fused epilogue / linked, two launches / again / plain autograd path
+        hip_linear.K4_TAIL, hip_linear.K4_LINK = mode == "tail", mode != "nolink"
+        try:
+            seq.zero_grad()
+            with _variant_trace() as names:
+                (ops.mlp2(x, seq) * t).sum().backward()
+            torch.cuda.synchronize()
+            got.setdefault(mode, []).append([p.grad.clone() for p in seq.parameters()])
+            trace[mode] = names
+        finally:
+            hip_linear.K4_TAIL = hip_linear.K4_LINK = True
+    assert any("k4tail" in n for n in trace["tail"]), trace["tail"]
+    assert not any("k4tail" in n for n in trace["two"]) and not any("k4tail" in n for n in trace["nolink"])
+    for a, b in zip(*got["tail"]):                     # the same launch twice: bit-equal
+        assert torch.equal(a, b)
+    for a, b in zip(got["two"][0], got["nolink"][0]):  # the linked two-launch form IS the autograd path's kernels
+        assert torch.equal(a, b)
+    for a, b, r in zip(got["tail"][0], got["two"][0], ref):
+        s = float(r.abs().max())
+        assert float((a.double() - r).abs().max()) <= 2e-5 * s, (a.shape, float((a.double() - r).abs().max()), s)
+        assert float((b.double() - r).abs().max()) <= 2e-5 * s
+    # existing gradients: the launch adds to them
+    before = [p.grad.clone() for p in seq.parameters()]
+    (ops.mlp2(x, seq) * t).sum().backward()
+    for p, b0, r in zip(seq.parameters(), before, ref):
+        assert float((p.grad.double() - 2 * r).abs().max()) <= 4e-5 * float(r.abs().max())
