@@ -388,7 +388,7 @@ def _pad_cols(t, mult=4):
 # Large layers run on the bf16 matrix pipe with the error-compensated 3-way split (nsdp_linear_bf16x3_f32, fp32
 # rounding-level accuracy, see csrc/gemm_bf16x3.hip); NSDP_BF16X3=0 keeps every layer on the exact-fp32 MFMA path.
 _USE_X3 = os.environ.get("NSDP_BF16X3", "1") != "0"
-_X3_MIN_ROWS = 32768
+_X3_MIN_ROWS = int(os.environ.get("NSDP_X3_MIN_ROWS", "32768"))      # (A/B knob)
 _X3_MIN_ROWS_WGRAD = 2048      # the split-row wgrad kernel already wins at a few thousand rows
 
 
@@ -562,6 +562,8 @@ class SkipGrad:
 K4_LINK = os.environ.get("NSDP_K4_LINK", "1") != "0"
 K4_TAIL = os.environ.get("NSDP_K4_TAIL", "1") != "0"
 K4_TAIL_SIDE = os.environ.get("NSDP_K4_TAIL_SIDE", "1") != "0"
+# compute units the tail GEMM leaves free on the side stream (None: SIDE_RESERVE_CUS, like the weight-gradient kernels)
+K4_TAIL_RESERVE = int(os.environ["NSDP_K4_TAIL_RESERVE"]) if "NSDP_K4_TAIL_RESERVE" in os.environ else None
 
 
 class K4Tail:
@@ -599,6 +601,8 @@ def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dy2.device)
         dw, db, acc = wgrad_out(out, n_hidden, link.k_orig, want_db, dy2.device)
         with on_device(dy2):
+            if K4_TAIL_RESERVE is not None and torch.cuda.current_stream(dy2.device) == _side.get(dy2.device.index):
+                L.nsdp_debug_set(_ci(9), _ci(K4_TAIL_RESERVE))      # (_wgrad_deferred resets the hint after this routine)
             check(L.nsdp_linear_bf16x3_k4tail_f32(fptr(dy2, "dy"), ctypes.c_void_p(wpt.data_ptr()), fptr(x4, "x4"),
                                                   fptr(_padded_w4(link.w_param), "w0"), optptr(b0), fptr(dw), optptr(db), _ll(M),
                                                   _ci(n_hidden), _ci(K), _ci(int(link.k_orig)), _ci(acc), fptr(ws),
