@@ -21,9 +21,19 @@ data = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(1000, args.b
 
 calls = collections.Counter()
 orig_fwd, orig_wgrad = hip_linear._run, hip_linear._wgrad
-def rec_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out):
+def rec_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, *a, **kw):
     calls[("nt-" + kind, x2.shape[0], N, x2.shape[1], b is not None, residual is not None, mask is not None, out_mask is not None, bool(relu_in), bool(relu_out))] += 1
-    return orig_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out)
+    return orig_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, *a, **kw)
+orig_tail = hip_linear._k4tail_fn
+def rec_tail(link, wpt, n_hidden, kind_t, h0):
+    fn = orig_tail(link, wpt, n_hidden, kind_t, h0)
+    def wrapped(dy2, x4, mask, relu_x, want_db, out=None):
+        M, K = dy2.shape
+        if hip_linear.K4_TAIL and kind_t == "x3" and hip_linear.lib().nsdp_linear_bf16x3_k4tail_ok(hip_linear._ll(M), hip_linear._ci(n_hidden), hip_linear._ci(K)):
+            calls[("tail-x3", M, n_hidden, K)] += 1      # the dX GEMM with the K = 4 weight gradient in its epilogue: no output
+        return fn(dy2, x4, mask, relu_x, want_db, out)
+    return wrapped
+hip_linear._k4tail_fn = rec_tail
 def rec_wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     calls[("wgrad", dy2.shape[0], dy2.shape[1], x2.shape[1], mask is not None, bool(relu_x), bool(want_db))] += 1
     return orig_wgrad(dy2, x2, mask, relu_x, want_db, out)
@@ -34,7 +44,7 @@ for _ in range(2):
     loss = compute_l2_error(model(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"])
     loss.backward()
 torch.cuda.synchronize()
-hip_linear._run, hip_linear._wgrad = orig_fwd, orig_wgrad
+hip_linear._run, hip_linear._wgrad, hip_linear._k4tail_fn = orig_fwd, orig_wgrad, orig_tail
 
 def timeit(fn, n=8):
     for _ in range(2): fn()
@@ -47,7 +57,17 @@ def timeit(fn, n=8):
 
 rows = []
 for key, cnt in calls.items():
-    if key[0].startswith("nt"):
+    if key[0] == "tail-x3":
+        _, M, N, K = key
+        x = torch.relu(torch.randn(M, K, device=dev))
+        lin0 = torch.nn.Linear(3, N).to(dev)
+        wpt = hip_linear.pack_weight_x3(torch.randn(K, N, device=dev), True, True)[1]
+        x4 = torch.nn.functional.pad(torch.randn(M, 3, device=dev), (0, 1)).contiguous()
+        link = hip_linear.K4Tail(); link.w_param, link.b_param, link.k_orig = lin0.weight, lin0.bias, 3
+        tfn = orig_tail(link, wpt, N, "x3", None)
+        t = timeit(lambda: tfn(x, x4, None, False, True))
+        flags = "k4"
+    elif key[0].startswith("nt"):
         kname, M, N, K, hb, hr, hm, ho, ri, ro = key
         kind = kname[3:]
         x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
@@ -69,7 +89,7 @@ for key, cnt in calls.items():
     del x
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-print(f"total isolated GEMM time per step: {tot:.2f} ms  (nt {sum(r[0] for r in rows if r[1].startswith('nt')):.2f}, wgrad {sum(r[0] for r in rows if r[1]=='wgrad'):.2f})")
+print(f"total isolated GEMM time per step: {tot:.2f} ms  (nt {sum(r[0] for r in rows if r[1].startswith('nt')):.2f}, k4 tail {sum(r[0] for r in rows if r[1]=='tail-x3'):.2f}, wgrad {sum(r[0] for r in rows if r[1]=='wgrad'):.2f})")
 print("kind   M        N    K    flags  count  ms/call  TF     ms/step  cum%")
 cum = 0.0
 for tt, kind, M, N, K, flags, cnt, t, tf in rows:
