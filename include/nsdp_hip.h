@@ -173,6 +173,30 @@ typedef struct {
 } NsdpPackDesc;
 int nsdp_pack_weights_batched(const NsdpPackDesc *descs, int count, void *stream);
 
+/* The optimizer step of the train step (reference model/__init__.py:10-41 builds torch.optim.Adam,
+ * model/deformation_networks.py:63-77 and flow_arbitrary.py:30-48 call optimizer.step()): the Adam update of EVERY
+ * parameter tensor in ONE launch (csrc/adam.hip).  Tables in DEVICE memory (static across the replays of a captured step):
+ *   descs  [n tensors]       fp32 tensors of `numel` elements each; `step` = the tensor's fp32 step counter t (torch's
+ *                            capturable layout of state["step"]), read by every chunk and advanced by one by the launch
+ *   chunks [n_chunks][2]     int32 (tensor, chunk of that tensor), chunks of nsdp_adam_chunk_elems() elements, every chunk
+ *                            of every tensor exactly once, any order
+ *   done   [n tensors]       int32 arrival counters, zero on entry, zero on exit
+ * lr_dev (device fp32 scalar, e.g. a schedule changed between replays) overrides lr when not NULL.  Arithmetic: torch's
+ * single-tensor fp32 Adam operation by operation (lerp_, mul_/addcmul_, sqrt / div / add, addcdiv_), bias corrections in
+ * double; weight_decay is the L2 form (g + wd p), amsgrad is not offered (the reference does not use it). */
+typedef struct {
+  float *param;       /* updated in place */
+  const float *grad;
+  float *exp_avg;     /* first moment, in place */
+  float *exp_avg_sq;  /* second moment, in place */
+  float *step;        /* fp32 scalar, in place (+1) */
+  long long numel;
+} NsdpAdamDesc;
+int nsdp_adam_chunk_elems(void);
+int nsdp_adam_multi_f32(const NsdpAdamDesc *descs_dev, const int32_t *chunks_dev, int n_chunks, int32_t *done_dev,
+                        const float *lr_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                        int maximize, void *stream);
+
 long long nsdp_packed_weight_bf16x3_bytes(int N, int K, int transposed);
 int nsdp_pack_weight_bf16x3(const float *W, int N, int K, void *Wp, void *WpT, void *stream);
 int nsdp_linear_bf16x3_f32(const float *X, const void *Wp, const float *bias, const float *residual,

@@ -22,6 +22,7 @@ Rules of the capture (the same as for any CUDA / HIP graph):
 from __future__ import annotations
 
 import ctypes
+import gc
 import os
 
 import torch
@@ -35,6 +36,9 @@ def capturable_adam(optimizer: torch.optim.Optimizer, lr_as_tensor: bool = True,
     ``fused``: PyTorch's fused multi-tensor Adam -- the capturable foreach form computes its bias corrections with ~15
     tensor-list operations, i.e. ~480 tiny kernels per step for the 350 parameter tensors of a TDNet (a replay of 1495 nodes
     instead of ~1020); the fused form is a dozen launches."""
+    from .hip_adam import HipAdam
+    if isinstance(optimizer, HipAdam):      # one launch of csrc/adam.hip, capturable as it is: only the learning rate moves
+        fused = False
     for group in optimizer.param_groups:
         group["capturable"] = True
         if fused and "fused" in group and all(p.is_cuda and torch.is_floating_point(p) for p in group["params"]):
@@ -52,6 +56,19 @@ def set_lr(optimizer: torch.optim.Optimizer, value: float):
             group["lr"].fill_(float(value))
         else:
             group["lr"] = float(value)
+
+
+_graveyard = []       # (executor handle, torch graph) of closed steps that could not be destroyed yet
+
+
+def _bury():
+    if not _graveyard or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        return
+    while _graveyard:
+        handle, graph = _graveyard.pop()
+        if handle:
+            lib().nsdp_graph_exec_destroy(handle)
+        del graph
 
 
 class GraphedStep:
@@ -93,9 +110,16 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph(keep_graph=True)
         # thread_local: other threads of the process (the RCCL watchdog of a data-parallel job polls events) may keep
         # making HIP calls while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            out = self.fn()
+        gc_was_on = gc.isenabled()
+        gc.disable()      # (no collection, hence no finalizer of some unrelated object, between the capture's begin and end)
+        try:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = self.fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
         torch.cuda.synchronize()
+        _bury()
         raw = graph.raw_cuda_graph()
         L = lib()
         handle = ctypes.c_void_p(0)
@@ -121,10 +145,15 @@ class GraphedStep:
         return self._out
 
     def close(self):
-        if self._handle:
-            lib().nsdp_graph_exec_destroy(self._handle)
+        # Destroying a graph (its executor's streams and events, the torch graph and its memory pool) is not something a
+        # thread may do while it CAPTURES another one -- and Python's cycle collector runs `__del__` whenever it likes, in
+        # the middle of a capture too (a GraphedTrainOnBatch and the lambda of its step form a cycle): the process aborted
+        # there.  While a capture is in progress the remains are parked and freed at the next safe point.
+        if self._handle or self._graph is not None:
+            _graveyard.append((self._handle, self._graph))
             self._handle = ctypes.c_void_p(0)
-        self._graph = None
+            self._graph = None
+        _bury()
 
     def __del__(self):
         try:

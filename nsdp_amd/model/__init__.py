@@ -3,6 +3,8 @@
 ``(model, train_on_batch, validate_on_batch, test_on_batch)`` and ``optimizer_factory(cfg, params)``."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .deformation_networks import (Deformation_Networks, test_on_batch_with_cano, train_on_batch_with_cano,
@@ -25,7 +27,13 @@ def optimizer_factory(config, parameters):
         group["momentum"] = config.get("momentum", 0.9)
         return schedule, torch.optim.SGD([group])
     if name == "Adam":
-        # (PyTorch's fused=True variant was measured: no gain once the weight packs are rebuilt by one batched launch)
+        # GPU parameters: the whole update as one launch of csrc/adam.hip behind torch.optim.Adam's own container
+        # (hip_adam.HipAdam; NSDP_HIP_ADAM=0 keeps PyTorch's kernels for an A/B).  CPU parameters (host-side tests, the
+        # gloo harness): torch's Adam, as the reference.
+        if (parameters and all(p.is_cuda and p.dtype == torch.float32 for p in parameters)
+                and os.environ.get("NSDP_HIP_ADAM", "1") != "0"):
+            from ..hip_adam import HipAdam
+            return schedule, HipAdam([group])
         return schedule, torch.optim.Adam([group])
     raise NotImplementedError(name)
 

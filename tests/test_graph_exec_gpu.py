@@ -197,3 +197,26 @@ def test_replays_interleaved_with_validation_and_odd_shape_batches_equal_the_eag
     assert e_out == g_out, (e_out, g_out)
     bad = [k for k in e_state if not torch.equal(e_state[k], g_state[k])]
     assert not bad, bad[:8]
+
+
+def test_a_step_closed_while_another_one_is_captured_is_freed_afterwards():
+    """Python's cycle collector may finalize a forgotten GraphedStep in the middle of another capture (it did: the process
+    aborted inside hipGraphDestroy).  A close() during a capture parks the graph; it is destroyed after the capture."""
+    from nsdp_amd import graph_step
+    from nsdp_amd.graph_step import GraphedStep
+    x = torch.ones(1024, device=DEV)
+    y = torch.zeros(1024, device=DEV)
+    old = GraphedStep(lambda: y.add_(x), weights_change=False).capture(warmup=0)
+    old()
+
+    def fn():
+        y.mul_(2.0)
+        old.close()                 # (what a finalizer run by the collector would do)
+        assert graph_step._graveyard, "a close() during a capture must be deferred"
+        return y
+    new = GraphedStep(fn, weights_change=False).capture(warmup=0)
+    assert not graph_step._graveyard
+    new()
+    torch.cuda.synchronize()
+    assert float(y[0]) == 2.0
+    new.close()
