@@ -184,6 +184,139 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
   }
 }
 
+// The same search with the insertion DEFERRED.  In knn_split_kernel the wave-level branch around the unrolled insertion
+// (~5 K VALU operations) is taken whenever ANY of the 64 lanes improves its list -- for 16 neighbours out of 512
+// candidates per lane that is ~95 % of all iterations, although a single lane inserts only ~70 times.  Here a lane that
+// sees a candidate below its (possibly stale, hence never too small) threshold only appends (distance, index) to a private
+// FIFO of kQueue entries in LDS; the lists are updated when some lane's FIFO is nearly full and once at the end, by
+// insertion rounds in which most lanes take part.  A lane still meets its candidates in increasing index order and the
+// insertion is the same strict `<` chain, so the result -- ties included -- is the one of knn_split_kernel, bit for bit;
+// per candidate the loop is now a distance, a compare and a predicated LDS append.  Measured (k = 16, four lanes per
+// query): 500 x 2048 x 32 shapes 200 -> 111 us, 2048 x 8192 x 32 1227 -> 691 us, 4096 x 16384 x 16 1979 -> 1251 us; a
+// 16-entry FIFO with the candidates taken four at a time (independent LDS reads and distances) against 8 entries one at a
+// time: 111 against 125 us; eight lanes per query instead of four: slower (124 / 1096 / 2029 us, more list work).
+template <int K, int S, int kQueue>
+__global__ __launch_bounds__(256) void knn_split_queue_kernel(const float *__restrict__ query_all,
+                                                              const float *__restrict__ source_all, int n, int m, int k,
+                                                              int32_t *__restrict__ idx_all, float *__restrict__ dist_all) {
+  __shared__ float4 tile[kTile];
+  __shared__ float md[256 * K];      // the FIFOs during the scan ([slot][thread]: conflict-free), the S lists afterwards
+  __shared__ int mi[256 * K];
+  static_assert(K >= kQueue, "the FIFOs live in the merge buffers");
+  constexpr int kQ = 256 / S;
+  const int b = blockIdx.y;
+  const float *query = query_all + static_cast<size_t>(b) * n * 3;
+  const float *source = source_all + static_cast<size_t>(b) * m * 3;
+  const int ql = threadIdx.x / S, sub = threadIdx.x - ql * S;
+  const int i = blockIdx.x * kQ + ql;
+  const bool active = i < n;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active) {
+    qx = query[i * 3 + 0]; qy = query[i * 3 + 1]; qz = query[i * 3 + 2];
+  }
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    bd[t] = FLT_MAX;
+    bi[t] = 0x7fffffff;
+  }
+  int fill = 0;                      // entries in this lane's FIFO
+  auto drain = [&]() __attribute__((always_inline)) {
+    for (int sl = 0; sl < kQueue; ++sl) {
+      const bool has = sl < fill;
+      if (__builtin_amdgcn_ballot_w64(has) == 0) break;
+      const float d = has ? md[sl * 256 + threadIdx.x] : FLT_MAX;
+      const int j = mi[sl * 256 + threadIdx.x];
+      if (d < bd[K - 1]) {
+#pragma unroll
+        for (int u = K - 1; u > 0; --u) {
+          const bool shift = d < bd[u - 1];
+          const bool here = !shift && d < bd[u];
+          const float nd = shift ? bd[u - 1] : (here ? d : bd[u]);
+          const int ni = shift ? bi[u - 1] : (here ? j : bi[u]);
+          bd[u] = nd;
+          bi[u] = ni;
+        }
+        if (d < bd[0]) {
+          bd[0] = d;
+          bi[0] = j;
+        }
+      }
+    }
+    fill = 0;
+  };
+  for (int base = 0; base < m; base += kTile) {
+    const int cnt = min(kTile, m - base);
+    __syncthreads();
+    for (int t = threadIdx.x; t < cnt; t += 256) {
+      const float *p = source + static_cast<size_t>(base + t) * 3;
+      tile[t] = make_float4(p[0], p[1], p[2], 0.f);
+    }
+    __syncthreads();
+    const int per = (cnt + S - 1) / S;           // lane `sub` scans tile entries [sub * per, (sub + 1) * per)
+    const int t0 = sub * per, t1 = min(cnt, t0 + per);
+    // kGroup candidates per round: their tile reads and distances are independent (one wave per SIMD at the encoder's
+    // sizes: nothing else hides the LDS latency), the appends follow; the lists are brought up to date while every lane
+    // still has room for a whole group.  (The same trip count in every lane: the ballots see whole waves.)
+    constexpr int kGroup = kQueue >= 16 ? 4 : 1;
+    for (int tt = 0; tt < per; tt += kGroup) {
+      float d[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const int t = t0 + tt + u;
+        const float4 sp = tile[t < kTile ? t : kTile - 1];
+        d[u] = nsdp::sq_dist3(qx, qy, qz, sp.x, sp.y, sp.z);
+      }
+      const float thr = bd[K - 1];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const int t = t0 + tt + u;
+        if (tt + u < per && t < t1 && d[u] < thr) {
+          md[fill * 256 + threadIdx.x] = d[u];
+          mi[fill * 256 + threadIdx.x] = base + t;
+          ++fill;
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(fill > kQueue - kGroup) != 0) drain();
+    }
+  }
+  drain();
+  __syncthreads();                   // every wave is done with its FIFOs: the buffers become the merge lists
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    md[threadIdx.x * K + t] = bd[t];
+    mi[threadIdx.x * K + t] = bi[t];
+  }
+  __syncthreads();
+  if (active && sub == 0) {
+    int head[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) head[u] = 0;
+    int32_t *io = idx_all + (static_cast<size_t>(b) * n + i) * k;
+    float *dout = dist_all ? dist_all + (static_cast<size_t>(b) * n + i) * k : nullptr;
+    for (int t = 0; t < k; ++t) {
+      float best_d = FLT_MAX;
+      int best_i = 0x7fffffff, best_u = 0;
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int h = head[u];
+        const float dd = h < K ? md[(threadIdx.x + u) * K + h] : FLT_MAX;
+        const int ii = h < K ? mi[(threadIdx.x + u) * K + h] : 0x7fffffff;
+        if (dd < best_d || (dd == best_d && ii < best_i)) {
+          best_d = dd; best_i = ii; best_u = u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < S; ++u) head[u] += (u == best_u) ? 1 : 0;
+      io[t] = best_i;
+      if (dout) dout[t] = best_d;
+    }
+  }
+}
+
+int g_knn_queue = 1;      // nsdp_debug_set(10, v), NSDP_KNN_QUEUE: 0 = the immediate-insertion kernel (A/B)
+
 template <int K>
 int launch(const float *q, const float *s, int B, int n, int m, int k, int32_t *idx, float *d2,
            hipStream_t st) {
@@ -193,6 +326,12 @@ int launch(const float *q, const float *s, int B, int n, int m, int k, int32_t *
   if constexpr (K <= 16) {
     if (m >= 256 && waves < 8LL * nsdp::num_cus()) {
       dim3 grid(nsdp::ceil_div(n, 64), B);
+      if (g_knn_queue) {
+        constexpr int kQueue = K >= 16 ? 16 : 8;
+        NSDP_TRACE("knn_split_queue<%d,4,%d>", K, kQueue);
+        hipLaunchKernelGGL((knn_split_queue_kernel<K, 4, kQueue>), grid, dim3(256), 0, st, q, s, n, m, k, idx, d2);
+        return nsdp::launch_status("knn_split_queue_kernel");
+      }
       NSDP_TRACE("knn_split<%d,4>", K);
       hipLaunchKernelGGL((knn_split_kernel<K, 4>), grid, dim3(256), 0, st, q, s, n, m, k, idx, d2);
       return nsdp::launch_status("knn_split_kernel");
@@ -205,6 +344,10 @@ int launch(const float *q, const float *s, int B, int n, int m, int k, int32_t *
 }
 
 }  // namespace
+
+namespace nsdp {
+void debug_set_knn(int value) { g_knn_queue = value; }
+}  // namespace nsdp
 
 extern "C" int nsdp_knn(const float *query, const float *source, int B, int n, int m, int k,
                         int32_t *idx_out, float *dist2_out, void *stream) {

@@ -83,6 +83,37 @@ def test_knn_ties_follow_distance_then_index():
     np.testing.assert_array_equal(idx, ref.knn(s, s, 16))
 
 
+@pytest.mark.parametrize("kind,b,n,m,k", [("uniform", 3, 2048, 2048, 16), ("dupes", 2, 500, 2048, 16), ("grid", 2, 512, 512, 16),
+                                          ("uniform", 2, 300, 5000, 16), ("allorigin", 2, 300, 700, 9), ("uniform", 2, 257, 1025, 5)])
+def test_knn_deferred_insertion_equals_immediate_insertion(kind, b, n, m, k):
+    """knn_split_queue_kernel (candidates appended to per-lane FIFOs, lists updated in rounds) is the default of the
+    several-lanes-per-query search; knn_split_kernel (insert at once) stays as its A/B form.  Same candidate order per lane,
+    same strict `<` chain: indices and distance bits must be equal on ties, duplicates, ragged tiles and all."""
+    from test_model_gpu import _variant_trace
+    from nsdp_amd import _lib
+    from nsdp_amd import pointnet2_utils as pu
+    s = _cloud(11 * n + m, b, m, kind)
+    q = s[:, :n].copy() if n <= m else _cloud(n, b, n, kind)
+    out = {}
+    for mode in (0, 1):
+        _lib.lib().nsdp_debug_set(10, mode)
+        try:
+            with _variant_trace() as names:
+                idx, d2 = pu.knn(_dev(q), _dev(s), k, return_dist=True)
+                torch.cuda.synchronize()
+        finally:
+            _lib.lib().nsdp_debug_set(10, int(os.environ.get("NSDP_KNN_QUEUE", "1")))
+        assert any(x.startswith("knn_split_queue<" if mode else "knn_split<") for x in names), names
+        out[mode] = (idx.cpu().numpy(), d2.cpu().numpy().view(np.uint32))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    ridx = ref.knn(q, s, k)
+    if kind != "allorigin":        # (all distances equal: the oracle's order is distance-then-index as well, checked below)
+        np.testing.assert_array_equal(out[1][0], ridx)
+    else:
+        np.testing.assert_array_equal(out[1][0], np.tile(np.arange(k, dtype=np.int32), (b, n, 1)))
+
+
 def test_knn_golden_sets(golden_dir):
     """kNN sets produced by the reference's own square_distance + argsort (tiny fixture, every site)."""
     from nsdp_amd import pointnet2_utils as pu

@@ -12,6 +12,7 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--top", type=int, default=25)
+    ap.add_argument("--dump-ms", type=float, default=0.0, help="list every kernel that starts in the first DUMP_MS ms of the step")
     args = ap.parse_args()
     rows = []
     with open(args.trace) as f:
@@ -20,7 +21,7 @@ def main():
     rows.sort()
     # the timed steps: the last `steps` occurrences of the fused Adam kernel chain end a step; cut at the first multi_tensor launch
     # of each optimizer step (a gap of > 5 ms between multi_tensor kernels separates steps)
-    opt = [r for r in rows if "multi_tensor_apply" in r[3]]
+    opt = [r for r in rows if "multi_tensor_apply" in r[3] or "adam_multi_kernel" in r[3]]
     step_ends, last = [], None
     for r in opt:
         if last is None or r[0] - last > 5_000_000:
@@ -69,6 +70,24 @@ def main():
             other[(q, r[3][:70])][1] += 1
     for (q, n), (t, c) in sorted(other.items(), key=lambda kv: -kv[1][0])[:args.top]:
         print(f"    q{q} {t / 1e6:6.2f} ms {c:4d}x {n}")
+    # busy share of the main queue / of the others per millisecond of the step (where does a queue sit idle?)
+    nb = int((b - a) / 1e6) + 1
+    share = {True: [0.0] * nb, False: [0.0] * nb}
+    for r in step:
+        t0, t1 = r[0], min(r[1], b)
+        while t0 < t1:
+            i = int((t0 - a) / 1e6)
+            edge = min(t1, a + (i + 1) * 1_000_000)
+            share[r[2] == main_q][i] += (edge - t0) / 1e6
+            t0 = edge
+    print("busy share per ms of the step (main queue | other queues):")
+    for i in range(nb):
+        print(f"    {i:3d} ms  {share[True][i]:5.2f} | {share[False][i]:5.2f}")
+    if args.dump_ms > 0:
+        print(f"kernels starting in the first {args.dump_ms} ms (start ms, dur us, queue):")
+        for r in step:
+            if r[0] - a < args.dump_ms * 1e6:
+                print(f"    {(r[0] - a) / 1e6:7.3f} {(r[1] - r[0]) / 1e3:8.1f} q{r[2]} {r[3][:90]}")
     # when does each queue finish relative to the step end
     print("tail: last 12 kernels of the step (start ms, dur us, queue)")
     for r in sorted(step, key=lambda r: r[1])[-12:]:
