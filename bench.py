@@ -581,7 +581,14 @@ def main():
         }
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.workload != "forward_train") \
             else cpu_baseline()
-        print(json.dumps(line))
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: flush it first, so that the
+        # JSON line is the LAST line of stdout for whoever parses it
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
     if not in_sync:

@@ -21,6 +21,8 @@
 namespace {
 
 constexpr int kTile = 1024;  // source points per LDS tile (16 KiB)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int K>
 __global__ __launch_bounds__(256) void knn_kernel(const float *__restrict__ query_all,
@@ -194,12 +196,17 @@ __global__ __launch_bounds__(256) void knn_split_kernel(const float *__restrict_
 // per candidate the loop is now a distance, a compare and a predicated LDS append.  Measured (k = 16, four lanes per
 // query): 500 x 2048 x 32 shapes 200 -> 111 us, 2048 x 8192 x 32 1227 -> 691 us, 4096 x 16384 x 16 1979 -> 1251 us; a
 // 16-entry FIFO with the candidates taken four at a time (independent LDS reads and distances) against 8 entries one at a
-// time: 111 against 125 us; eight lanes per query instead of four: slower (124 / 1096 / 2029 us, more list work).
+// time: 111 against 125 us; eight lanes per query instead of four: slower (124 / 1096 / 2029 us, more list work).  With the
+// tile as three planes + sentinels and the distances on packed fp32 operations (below): 92 / 458 / 767 us.
 template <int K, int S, int kQueue>
 __global__ __launch_bounds__(256) void knn_split_queue_kernel(const float *__restrict__ query_all,
                                                               const float *__restrict__ source_all, int n, int m, int k,
                                                               int32_t *__restrict__ idx_all, float *__restrict__ dist_all) {
-  __shared__ float4 tile[kTile];
+  // the tile as three planes (four candidates = three 16-byte reads, two distances per packed operation) with 16 sentinel
+  // entries behind the last point: x = FLT_MAX squares to +inf, which no threshold admits -- no range checks in the scan
+  __shared__ __attribute__((aligned(16))) float tx[kTile + 16];
+  __shared__ __attribute__((aligned(16))) float ty[kTile + 16];
+  __shared__ __attribute__((aligned(16))) float tz[kTile + 16];
   __shared__ float md[256 * K];      // the FIFOs during the scan ([slot][thread]: conflict-free), the S lists afterwards
   __shared__ int mi[256 * K];
   static_assert(K >= kQueue, "the FIFOs live in the merge buffers");
@@ -251,34 +258,45 @@ __global__ __launch_bounds__(256) void knn_split_queue_kernel(const float *__res
     __syncthreads();
     for (int t = threadIdx.x; t < cnt; t += 256) {
       const float *p = source + static_cast<size_t>(base + t) * 3;
-      tile[t] = make_float4(p[0], p[1], p[2], 0.f);
+      tx[t] = p[0]; ty[t] = p[1]; tz[t] = p[2];
+    }
+    if (threadIdx.x < 16) {
+      tx[cnt + threadIdx.x] = FLT_MAX; ty[cnt + threadIdx.x] = 0.f; tz[cnt + threadIdx.x] = 0.f;
     }
     __syncthreads();
-    const int per = (cnt + S - 1) / S;           // lane `sub` scans tile entries [sub * per, (sub + 1) * per)
-    const int t0 = sub * per, t1 = min(cnt, t0 + per);
-    // kGroup candidates per round: their tile reads and distances are independent (one wave per SIMD at the encoder's
-    // sizes: nothing else hides the LDS latency), the appends follow; the lists are brought up to date while every lane
-    // still has room for a whole group.  (The same trip count in every lane: the ballots see whole waves.)
-    constexpr int kGroup = kQueue >= 16 ? 4 : 1;
-    for (int tt = 0; tt < per; tt += kGroup) {
-      float d[kGroup];
-#pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int t = t0 + tt + u;
-        const float4 sp = tile[t < kTile ? t : kTile - 1];
-        d[u] = nsdp::sq_dist3(qx, qy, qz, sp.x, sp.y, sp.z);
+    // lane `sub` scans tile entries [sub * per, (sub + 1) * per), per a multiple of four (the same trip count in every
+    // lane: the ballots see whole waves); S * per <= cnt + 4 S - 1: the sentinels cover what lies behind the tile.
+    const int per = (((cnt + S - 1) / S) + 3) & ~3;
+    const int t0 = sub * per;
+    static_assert(S <= 4, "16 sentinel entries");
+    for (int tt = 0; tt < per; tt += 4) {
+      const int t = t0 + tt;
+      const f32x4 X = *reinterpret_cast<const f32x4 *>(&tx[t]);
+      const f32x4 Y = *reinterpret_cast<const f32x4 *>(&ty[t]);
+      const f32x4 Z = *reinterpret_cast<const f32x4 *>(&tz[t]);
+      // ((dx*dx + dy*dy) + dz*dz), dx = query - source, one rounding per operation (contraction is off in this file):
+      // nsdp::sq_dist3 on two candidates per packed instruction
+      const f32x2 q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+      f32x2 d01, d23;
+      {
+        const f32x2 dx = q2x - f32x2{X[0], X[1]}, dy = q2y - f32x2{Y[0], Y[1]}, dz = q2z - f32x2{Z[0], Z[1]};
+        d01 = (dx * dx + dy * dy) + dz * dz;
       }
+      {
+        const f32x2 dx = q2x - f32x2{X[2], X[3]}, dy = q2y - f32x2{Y[2], Y[3]}, dz = q2z - f32x2{Z[2], Z[3]};
+        d23 = (dx * dx + dy * dy) + dz * dz;
+      }
+      const float d[4] = {d01[0], d01[1], d23[0], d23[1]};
       const float thr = bd[K - 1];
 #pragma unroll
-      for (int u = 0; u < kGroup; ++u) {
-        const int t = t0 + tt + u;
-        if (tt + u < per && t < t1 && d[u] < thr) {
+      for (int u = 0; u < 4; ++u) {
+        if (d[u] < thr) {
           md[fill * 256 + threadIdx.x] = d[u];
-          mi[fill * 256 + threadIdx.x] = base + t;
+          mi[fill * 256 + threadIdx.x] = base + t + u;
           ++fill;
         }
       }
-      if (__builtin_amdgcn_ballot_w64(fill > kQueue - kGroup) != 0) drain();
+      if (__builtin_amdgcn_ballot_w64(fill > kQueue - 4) != 0) drain();
     }
   }
   drain();
