@@ -37,7 +37,8 @@ const char *nsdp_last_error(void);
  * ablation bits, 7 bf16 wgrad phases (1 no MFMA, 2 no transposition, 4 no DMA), 8 bf16 linear phases (1 no MFMA, 2 no stores).
  * 9 is a HOST HINT, not an ablation: the number of compute units nsdp_linear_wgrad_bf16x3_f32 leaves free (its persistent
  * one-wave-per-SIMD workgroups otherwise hold every CU until the kernel ends); the host sets it around weight-gradient
- * launches that run on a side stream next to the critical chain and resets it to 0 (the workspace query sees the same value). */
+ * launches that run on a side stream next to the critical chain and resets it to 0 (the workspace query sees the same value).
+ * 10: 0 = immediate-insertion kNN kernel; 11: 0 = three-launch BatchNorm forms (A/B against the one-launch slab kernels). */
 void nsdp_debug_set(int key, int value);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int nsdp_device_count(void);
@@ -313,6 +314,10 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
 int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
                        float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
                        long long *num_batches_tracked, void *stream);
+int nsdp_bn_train_fwd_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum, int updates,
+                           float *running_mean, float *running_var, long long *num_batches_tracked, const float *gamma,
+                           const float *beta, int relu, void *y, float *mean, float *invstd, float *workspace,
+                           void *stream);
 int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
                        const float *beta, long long R, int C, int relu, void *y, void *stream);
 int nsdp_bn_backward_bf16(const void *dy, const void *y_relu, const void *x, const void *addend, const float *mean,
@@ -445,6 +450,15 @@ size_t nsdp_bn_workspace_bytes(int C);
 int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float eps, float momentum,
                   float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,
                   long long *num_batches_tracked, void *stream);
+/* The training-mode forward as ONE call: statistics, running-average update, normalisation (y, and mean / invstd for the
+ * backward).  For R <= 16384 rows it is one launch (a workgroup owns a slab of channels and all rows, in registers);
+ * larger tensors take nsdp_bn_stats + nsdp_bn_apply.  `updates` >= 1: the momentum update of the running statistics is
+ * applied that many times from the same batch statistics and *num_batches_tracked += updates -- what `updates` forward
+ * passes of the module over the SAME input leave behind (FlowArbitrary encodes one cloud twice, reference
+ * model/flow_arbitrary.py:19-20; this library encodes it once). */
+int nsdp_bn_train_fwd(const float *x, const float *addend, long long R, int C, float eps, float momentum, int updates,
+                      float *running_mean, float *running_var, long long *num_batches_tracked, const float *gamma,
+                      const float *beta, int relu, float *y, float *mean, float *invstd, float *workspace, void *stream);
 /* y = ((x + addend) - mean) * invstd * gamma + beta, then ReLU if relu */
 int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
                   const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream);

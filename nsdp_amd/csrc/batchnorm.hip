@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T *__restrict__ 
                                                           float *__restrict__ running_mean,
                                                           float *__restrict__ running_var, float *__restrict__ mean,
                                                           float *__restrict__ invstd,
-                                                          long long *__restrict__ num_batches_tracked) {
-  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+                                                          long long *__restrict__ num_batches_tracked, int updates) {
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += updates;
   const int c = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int sub16 = threadIdx.x & 15;
   double s, q;
@@ -144,8 +144,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const T *__restrict__ 
   invstd[c] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
   if (running_mean) {
     const double unbiased = R > 1 ? var * static_cast<double>(R) / static_cast<double>(R - 1) : var;
-    running_mean[c] = static_cast<float>((1.0 - momentum) * running_mean[c] + momentum * m);
-    running_var[c] = static_cast<float>((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    float rm = running_mean[c], rv = running_var[c];
+    for (int u = 0; u < updates; ++u) {
+      rm = static_cast<float>((1.0 - momentum) * rm + momentum * m);
+      rv = static_cast<float>((1.0 - momentum) * rv + momentum * unbiased);
+    }
+    running_mean[c] = rm;
+    running_var[c] = rv;
   }
 }
 
@@ -273,6 +278,305 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One-launch forms for R <= 16384 rows (34 of the encoder's 35 BatchNorms at 32 shapes per GPU: 3 200 and 16 000 rows).
+//
+// A workgroup owns a SLAB of VEC channels and ALL rows, held in registers (row t + i*THREADS in slot i of thread t), so the
+// statistics, the running-average update and the normalisation need no pass across workgroups: one launch instead of
+// stats + finalize + apply (a dependent kernel boundary costs 1.5-1.9 us, more than these tensors take to stream), and x is
+// read ONCE.  Every lane issues all of its loads before the first use (up to 16 x 16 B in flight per lane).  Slabs that
+// share 128-byte lines run on the same XCD (block b runs on XCD b % 8), so the line is fetched into one L2.  The
+// variance is the two-pass form (the values are in registers); sums are combined in double in a fixed order (bit-reproducible).
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int VEC>
+struct VecOps;
+template <>
+struct VecOps<4> {
+  template <typename T>
+  static __device__ __forceinline__ void ld(const T *p, float (&v)[4]) {
+    const float4 t = ld4(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  template <typename T>
+  static __device__ __forceinline__ void st(T *p, const float (&v)[4]) { st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+};
+template <>
+struct VecOps<2> {
+  static __device__ __forceinline__ void ld(const float *p, float (&v)[2]) {
+    const float2 t = *reinterpret_cast<const float2 *>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+  static __device__ __forceinline__ void ld(const bf16_t *p, float (&v)[2]) {
+    const unsigned r = *reinterpret_cast<const unsigned *>(p);
+    v[0] = __builtin_bit_cast(float, r << 16);
+    v[1] = __builtin_bit_cast(float, r & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(float *p, const float (&v)[2]) {
+    *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+  }
+  static __device__ __forceinline__ void st(bf16_t *p, const float (&v)[2]) {
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+    *reinterpret_cast<unsigned *>(p) = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, bf16x2));
+  }
+};
+
+// sum of N per-thread values over the workgroup, every thread gets the totals (fixed combination order)
+template <int N, int THREADS>
+__device__ __forceinline__ void block_sum(double (&a)[N], double *red /* [N][THREADS/64] */) {
+  constexpr int W = THREADS / 64;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a[j] += __shfl_xor(a[j], off);
+  }
+  __syncthreads();          // (red may still be read by the previous call)
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) red[j * W + (threadIdx.x >> 6)] = a[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    double t = red[j * W];
+#pragma unroll
+    for (int w = 1; w < W; ++w) t += red[j * W + w];
+    a[j] = t;
+  }
+}
+
+// slab of block b: blocks b, b + 8, b + 16, ... (one XCD) take adjacent slabs
+__device__ __forceinline__ int slab_of_block(int nslabs) {
+  const int per = (nslabs + 7) >> 3;
+  const int j = blockIdx.x >> 3;
+  const int s = (blockIdx.x & 7) * per + j;
+  return (j < per && s < nslabs) ? s : -1;
+}
+
+template <typename T, int VEC, int NPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_slab_fwd_kernel(
+    const T *__restrict__ x, const T *__restrict__ addend, int R, int C, float eps, float momentum, int updates,
+    float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
+    const float *__restrict__ gamma, const float *__restrict__ beta, int relu, T *__restrict__ y,
+    float *__restrict__ mean_out, float *__restrict__ invstd_out) {
+  __shared__ double red[VEC * (THREADS / 64)];
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += updates;
+  const int slab = slab_of_block(C / VEC);
+  if (slab < 0) return;
+  const int c0 = slab * VEC;
+  // (everything the tail of the kernel needs is requested now, next to the row loads: a second dependent memory round trip
+  // costs 1-2 us in a kernel that takes 7)
+  float ga[VEC], be[VEC], rm0[VEC], rv0[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    ga[j] = gamma[c0 + j];
+    be[j] = beta[c0 + j];
+    rm0[j] = running_mean ? running_mean[c0 + j] : 0.f;
+    rv0[j] = running_mean ? running_var[c0 + j] : 0.f;
+  }
+  float v[NPT][VEC];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int r = i * THREADS + threadIdx.x;
+    if (r < R) {
+      VecOps<VEC>::ld(x + static_cast<long long>(r) * C + c0, v[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) v[i][j] = 0.f;
+    }
+  }
+  if (addend) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int r = i * THREADS + threadIdx.x;
+      if (r < R) {
+        float a[VEC];
+        VecOps<VEC>::ld(addend + static_cast<long long>(r) * C + c0, a);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[i][j] += a[j];
+      }
+    }
+  }
+  double acc[VEC];
+  {
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) s[j] += v[i][j];      // (rows past R hold zeros)
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = s[j];
+  }
+  block_sum<VEC, THREADS>(acc, red);
+  float mean[VEC];
+  double mean_d[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    mean_d[j] = acc[j] / static_cast<double>(R);
+    mean[j] = static_cast<float>(mean_d[j]);
+  }
+  {
+    float q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) q[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const bool ok = i * THREADS + static_cast<int>(threadIdx.x) < R;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float d = v[i][j] - mean[j];
+        q[j] += ok ? d * d : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = q[j];
+  }
+  block_sum<VEC, THREADS>(acc, red);
+  float invstd[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    // (sum (v - mean_f32)^2 = sum (v - mean)^2 + R (mean - mean_f32)^2: the rounding of the mean is removed exactly)
+    const double dm = mean_d[j] - static_cast<double>(mean[j]);
+    double var = acc[j] / static_cast<double>(R) - dm * dm;
+    if (var < 0.0) var = 0.0;
+    invstd[j] = static_cast<float>(1.0 / sqrt(var + static_cast<double>(eps)));
+    if (threadIdx.x == 0) {
+      mean_out[c0 + j] = mean[j];
+      invstd_out[c0 + j] = invstd[j];
+      if (running_mean) {
+        const double unbiased = R > 1 ? var * static_cast<double>(R) / static_cast<double>(R - 1) : var;
+        float rm = rm0[j], rv = rv0[j];
+        for (int u = 0; u < updates; ++u) {       // (the same batch statistics folded in `updates` times, see nsdp_bn_train_fwd)
+          rm = static_cast<float>((1.0 - momentum) * rm + momentum * mean_d[j]);
+          rv = static_cast<float>((1.0 - momentum) * rv + momentum * unbiased);
+        }
+        running_mean[c0 + j] = rm;
+        running_var[c0 + j] = rv;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int r = i * THREADS + threadIdx.x;
+    if (r < R) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        o[j] = (v[i][j] - mean[j]) * invstd[j] * ga[j] + be[j];
+        if (relu) o[j] = fmaxf(o[j], 0.f);
+      }
+      VecOps<VEC>::st(y + static_cast<long long>(r) * C + c0, o);
+    }
+  }
+}
+
+template <typename T, int VEC, int NPT, int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_slab_bwd_kernel(
+    const T *__restrict__ dy, const T *__restrict__ y, const T *__restrict__ x, const T *__restrict__ addend,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ gamma, int R, int C,
+    int training, T *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ double red[2 * VEC * (THREADS / 64)];
+  const int slab = slab_of_block(C / VEC);
+  if (slab < 0) return;
+  const int c0 = slab * VEC;
+  float d[NPT][VEC], xh[NPT][VEC];
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int r = i * THREADS + threadIdx.x;
+    if (r < R) {
+      VecOps<VEC>::ld(dy + static_cast<long long>(r) * C + c0, d[i]);
+      VecOps<VEC>::ld(x + static_cast<long long>(r) * C + c0, xh[i]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d[i][j] = xh[i][j] = 0.f;
+    }
+  }
+  if (y) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int r = i * THREADS + threadIdx.x;
+      if (r < R) {
+        float yv[VEC];
+        VecOps<VEC>::ld(y + static_cast<long long>(r) * C + c0, yv);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d[i][j] = yv[j] > 0.f ? d[i][j] : 0.f;
+      }
+    }
+  }
+  if (addend) {
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+      const int r = i * THREADS + threadIdx.x;
+      if (r < R) {
+        float a[VEC];
+        VecOps<VEC>::ld(addend + static_cast<long long>(r) * C + c0, a);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) xh[i][j] += a[j];
+      }
+    }
+  }
+  float m[VEC], is[VEC], ga[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    m[j] = mean[c0 + j];
+    is[j] = invstd[c0 + j];
+    ga[j] = gamma[c0 + j];
+  }
+  double acc[2 * VEC];
+  {
+    float s[VEC], q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = q[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        xh[i][j] = (xh[i][j] - m[j]) * is[j];
+        s[j] += d[i][j];                       // (rows past R: d = 0)
+        q[j] += d[i][j] * xh[i][j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      acc[j] = s[j];
+      acc[VEC + j] = q[j];
+    }
+  }
+  block_sum<2 * VEC, THREADS>(acc, red);
+  float db[VEC], dg[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    db[j] = static_cast<float>(acc[j]);
+    dg[j] = static_cast<float>(acc[VEC + j]);
+    if (threadIdx.x == 0) {
+      dbeta[c0 + j] = db[j];
+      dgamma[c0 + j] = dg[j];
+    }
+  }
+  const float inv_r = 1.0f / static_cast<float>(R);
+#pragma unroll
+  for (int i = 0; i < NPT; ++i) {
+    const int r = i * THREADS + threadIdx.x;
+    if (r < R) {
+      float o[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        o[j] = training ? ga[j] * is[j] * (d[i][j] - db[j] * inv_r - xh[i][j] * dg[j] * inv_r) : ga[j] * is[j] * d[i][j];
+      }
+      VecOps<VEC>::st(dx + static_cast<long long>(r) * C + c0, o);
+    }
+  }
+}
+
+int g_bn_slab = 1;   // nsdp_debug_set(11, v), NSDP_BN_SLAB: 0 = always the three-launch forms, 2 = slabs up to 16384 rows (A/B)
+// longer slabs lose to the three-launch forms (every 16-byte row piece pulls a whole 128-byte line into L1: 16 000 x 256 takes
+// 29 us forward / 64 us backward against 26 / 30): they stay compiled for the A/B, nsdp_debug_set(11, 2)
+inline long long slab_max_rows() { return g_bn_slab >= 2 ? 16384 : 4096; }
+inline int slab_grid(int nslabs) { return 8 * ((nslabs + 7) / 8); }
+
 struct Plan {
   int parts;
   long long rows_per_blk;
@@ -297,7 +601,8 @@ inline bool c_ok(int C) { return C >= 4 && C % 4 == 0 && C <= 1024; }
 
 template <typename T>
 int bn_stats_t(const T *x, const T *addend, long long R, int C, float eps, float momentum, float *running_mean,
-               float *running_var, float *mean, float *invstd, float *workspace, long long *num_batches, void *stream) {
+               float *running_var, float *mean, float *invstd, float *workspace, long long *num_batches, void *stream,
+               int updates = 1) {
   NSDP_REQUIRE(R > 0 && c_ok(C), "bn_stats: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
   NSDP_REQUIRE(x && mean && invstd && workspace, "bn_stats: null pointer");
   NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_stats: running stats go together");
@@ -306,7 +611,7 @@ int bn_stats_t(const T *x, const T *addend, long long R, int C, float eps, float
   nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, sizeof(T) * 1.0 * R * C * (addend ? 2 : 1));
   hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(p.parts), dim3(kThreads), 0, st, x, addend, R, C, p.rows_per_blk, workspace);
   hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3((C + 15) / 16), dim3(256), 0, st, x, addend, workspace, p.parts, R, C, eps,
-                     momentum, running_mean, running_var, mean, invstd, num_batches);
+                     momentum, running_mean, running_var, mean, invstd, num_batches, updates);
   return nsdp::launch_status("bn_stats_kernel");
 }
 
@@ -325,12 +630,60 @@ int bn_apply_t(const T *x, const T *addend, const float *mean, const float *invs
 }
 
 template <typename T>
+int bn_train_fwd_t(const T *x, const T *addend, long long R, int C, float eps, float momentum, int updates,
+                   float *running_mean, float *running_var, long long *num_batches, const float *gamma, const float *beta,
+                   int relu, T *y, float *mean, float *invstd, float *workspace, void *stream) {
+  NSDP_REQUIRE(R > 0 && c_ok(C), "bn_train_fwd: need R > 0 and C %% 4 == 0, C <= 1024 (R=%lld C=%d)", R, C);
+  NSDP_REQUIRE(x && gamma && beta && y && mean && invstd && workspace, "bn_train_fwd: null pointer");
+  NSDP_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats go together");
+  NSDP_REQUIRE(updates >= 1 && updates <= 64, "bn_train_fwd: updates=%d", updates);
+  if (!g_bn_slab || R > slab_max_rows()) {
+    const int rc = bn_stats_t<T>(x, addend, R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace,
+                                 num_batches, stream, updates);
+    if (rc) return rc;
+    return bn_apply_t<T>(x, addend, mean, invstd, gamma, beta, R, C, relu, y, stream);
+  }
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0, sizeof(T) * 1.0 * R * C * (addend ? 3 : 2));
+  const int r = static_cast<int>(R);
+  if (R <= 4096) {
+    NSDP_TRACE("bn_slab_fwd<4,256>");
+    hipLaunchKernelGGL((bn_slab_fwd_kernel<T, 4, 16, 256>), dim3(slab_grid(C / 4)), dim3(256), 0, st, x, addend, r, C, eps,
+                       momentum, updates, running_mean, running_var, num_batches, gamma, beta, relu, y, mean, invstd);
+  } else {
+    NSDP_TRACE("bn_slab_fwd<4,512>");
+    hipLaunchKernelGGL((bn_slab_fwd_kernel<T, 4, 32, 512>), dim3(slab_grid(C / 4)), dim3(512), 0, st, x, addend, r, C, eps,
+                       momentum, updates, running_mean, running_var, num_batches, gamma, beta, relu, y, mean, invstd);
+  }
+  return nsdp::launch_status("bn_slab_fwd_kernel");
+}
+
+template <typename T>
 int bn_backward_t(const T *dy, const T *y_relu, const T *x, const T *addend, const float *mean, const float *invstd,
                   const float *gamma, long long R, int C, int training, T *dx, float *dgamma, float *dbeta,
                   float *workspace, void *stream) {
   NSDP_REQUIRE(R > 0 && c_ok(C), "bn_backward: need R > 0 and C %% 4 == 0, C <= 1024");
   NSDP_REQUIRE(dy && x && mean && invstd && gamma && dx && dgamma && dbeta && workspace, "bn_backward: null pointer");
   hipStream_t st = nsdp::as_stream(stream);
+  if (g_bn_slab && R <= slab_max_rows()) {
+    nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
+                            sizeof(T) * 1.0 * R * C * (3.0 + (y_relu ? 1 : 0) + (addend ? 1 : 0)));
+    const int r = static_cast<int>(R);
+    if (R <= 4096) {
+      NSDP_TRACE("bn_slab_bwd<4,256>");
+      hipLaunchKernelGGL((bn_slab_bwd_kernel<T, 4, 16, 256>), dim3(slab_grid(C / 4)), dim3(256), 0, st, dy, y_relu, x, addend,
+                         mean, invstd, gamma, r, C, training, dx, dgamma, dbeta);
+    } else if (R <= 8192) {
+      NSDP_TRACE("bn_slab_bwd<4,512>");
+      hipLaunchKernelGGL((bn_slab_bwd_kernel<T, 4, 16, 512>), dim3(slab_grid(C / 4)), dim3(512), 0, st, dy, y_relu, x, addend,
+                         mean, invstd, gamma, r, C, training, dx, dgamma, dbeta);
+    } else {
+      NSDP_TRACE("bn_slab_bwd<2,512>");
+      hipLaunchKernelGGL((bn_slab_bwd_kernel<T, 2, 32, 512>), dim3(slab_grid(C / 2)), dim3(512), 0, st, dy, y_relu, x,
+                         addend, mean, invstd, gamma, r, C, training, dx, dgamma, dbeta);
+    }
+    return nsdp::launch_status("bn_slab_bwd_kernel");
+  }
   const Plan p = plan(R, C);
   const long long total4 = R * (C >> 2);
   nsdp::prof::Scope scope(nsdp::prof::kBatchNorm, st, 0.0,
@@ -345,6 +698,10 @@ int bn_backward_t(const T *dy, const T *y_relu, const T *x, const T *addend, con
 
 }  // namespace
 
+namespace nsdp {
+void debug_set_bn(int value) { g_bn_slab = value; }
+}  // namespace nsdp
+
 extern "C" {
 
 size_t nsdp_bn_workspace_bytes(int C) { return static_cast<size_t>(kMaxParts) * 2 * C * sizeof(float); }
@@ -354,6 +711,12 @@ int nsdp_bn_stats(const float *x, const float *addend, long long R, int C, float
                   long long *num_batches_tracked, void *stream) {
   return bn_stats_t<float>(x, addend, R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace,
                            num_batches_tracked, stream);
+}
+int nsdp_bn_train_fwd(const float *x, const float *addend, long long R, int C, float eps, float momentum, int updates,
+                      float *running_mean, float *running_var, long long *num_batches_tracked, const float *gamma,
+                      const float *beta, int relu, float *y, float *mean, float *invstd, float *workspace, void *stream) {
+  return bn_train_fwd_t<float>(x, addend, R, C, eps, momentum, updates, running_mean, running_var, num_batches_tracked,
+                               gamma, beta, relu, y, mean, invstd, workspace, stream);
 }
 int nsdp_bn_apply(const float *x, const float *addend, const float *mean, const float *invstd,
                   const float *gamma, const float *beta, long long R, int C, int relu, float *y, void *stream) {
@@ -372,6 +735,14 @@ int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, fl
                        long long *num_batches_tracked, void *stream) {
   return bn_stats_t<bf16_t>(B16(x), B16(addend), R, C, eps, momentum, running_mean, running_var, mean, invstd, workspace,
                             num_batches_tracked, stream);
+}
+int nsdp_bn_train_fwd_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum, int updates,
+                           float *running_mean, float *running_var, long long *num_batches_tracked, const float *gamma,
+                           const float *beta, int relu, void *y, float *mean, float *invstd, float *workspace,
+                           void *stream) {
+  return bn_train_fwd_t<bf16_t>(B16(x), B16(addend), R, C, eps, momentum, updates, running_mean, running_var,
+                                num_batches_tracked, gamma, beta, relu, reinterpret_cast<bf16_t *>(y), mean, invstd,
+                                workspace, stream);
 }
 int nsdp_bn_apply_bf16(const void *x, const void *addend, const float *mean, const float *invstd, const float *gamma,
                        const float *beta, long long R, int C, int relu, void *y, void *stream) {

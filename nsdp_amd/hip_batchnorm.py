@@ -3,11 +3,28 @@
 unbiased for running_var, eval mode on running statistics)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes
 
 import torch
 
 from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
+
+_RUNNING_UPDATES = 1
+
+
+@contextlib.contextmanager
+def running_updates(n: int):
+    """Inside this context a training-mode norm folds its batch statistics into the running statistics ``n`` times and
+    counts ``n`` batches: what ``n`` forward passes of the module over the SAME input leave behind.  FlowArbitrary's
+    reference encodes one cloud twice per step (model/flow_arbitrary.py:19-20); this library encodes it once."""
+    global _RUNNING_UPDATES
+    prev, _RUNNING_UPDATES = _RUNNING_UPDATES, int(n)
+    try:
+        yield
+    finally:
+        _RUNNING_UPDATES = prev
+
 
 NATIVE_BF16 = True        # bf16-storage kernels (False: ops.batch_norm casts around the fp32 ones -- reference semantics for tests)
 BF16 = torch.bfloat16
@@ -37,7 +54,7 @@ def _ws(C, device):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt=None):
+    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt=None, updates=1):
         shape = x.shape
         C = shape[-1]
         x2 = x.reshape(-1, C)
@@ -52,19 +69,22 @@ class _BatchNormFn(torch.autograd.Function):
         if a2 is not None and a2.dtype is not dt:
             a2 = a2.to(dt)
         with on_device(x2):
+            y = torch.empty_like(x2)
             if training:
-                mean = torch.empty(C, dtype=torch.float32, device=dev)
-                invstd = torch.empty(C, dtype=torch.float32, device=dev)
-                check(_fn("nsdp_bn_stats", dt)(_p(x2, dt, "x"), _p(a2, dt, "addend"), _ll(R), _ci(C), _cf(eps), _cf(momentum),
-                                               optptr(running_mean), optptr(running_var), fptr(mean), fptr(invstd),
-                                               fptr(_ws(C, dev)), optptr(nbt), stream_ptr()), "nsdp_bn_stats")
+                # statistics + running-average update + normalisation: one launch for R <= 16384 rows (csrc/batchnorm.hip)
+                stats = torch.empty(2, C, dtype=torch.float32, device=dev)
+                mean, invstd = stats[0], stats[1]
+                check(_fn("nsdp_bn_train_fwd", dt)(_p(x2, dt, "x"), _p(a2, dt, "addend"), _ll(R), _ci(C), _cf(eps),
+                                                   _cf(momentum), _ci(updates), optptr(running_mean), optptr(running_var),
+                                                   optptr(nbt), fptr(gamma, "weight"), fptr(beta, "bias"), _ci(int(relu)),
+                                                   _p(y, dt), fptr(mean), fptr(invstd), fptr(_ws(C, dev)), stream_ptr()),
+                      "nsdp_bn_train_fwd")
             else:
                 mean = running_mean
                 invstd = torch.rsqrt(running_var + eps)
-            y = torch.empty_like(x2)
-            check(_fn("nsdp_bn_apply", dt)(_p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
-                                           fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), _p(y, dt), stream_ptr()),
-                  "nsdp_bn_apply")
+                check(_fn("nsdp_bn_apply", dt)(_p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
+                                               fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), _p(y, dt), stream_ptr()),
+                      "nsdp_bn_apply")
         ctx.save_for_backward(x2, a2, gamma, mean, invstd, y if relu else None)
         ctx.training, ctx.shape, ctx.has_addend = bool(training), shape, addend is not None
         return y.reshape(shape)
@@ -87,18 +107,21 @@ class _BatchNormFn(torch.autograd.Function):
                                               fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), _p(dx, dt), fptr(dgamma),
                                               fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
         dx = dx.reshape(ctx.shape)
-        return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
     """relu?( BN(x + addend) ) with bn's parameters / running statistics / mode."""
     training = bn.training or not bn.track_running_stats
     counts = bn.training and bn.track_running_stats
+    updates = _RUNNING_UPDATES if counts else 1
     nbt = None
     if counts and bn.momentum is not None and bn.num_batches_tracked.is_cuda:
-        nbt = bn.num_batches_tracked          # incremented by the finalize kernel (35 tiny add kernels per step otherwise)
+        nbt = bn.num_batches_tracked          # incremented by the norm's own kernel (35 tiny add kernels per step otherwise)
     elif counts:
-        bn.num_batches_tracked.add_(1)
+        if updates != 1 and bn.momentum is None:
+            raise NotImplementedError("running_updates(n > 1) with momentum=None (cumulative average)")
+        bn.num_batches_tracked.add_(updates)
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     if bn.momentum is None:
@@ -107,4 +130,5 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
         momentum = 1.0 / max(1.0, float(bn.num_batches_tracked)) if (bn.training and bn.track_running_stats) else 0.0
     else:
         momentum = float(bn.momentum)
-    return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, momentum, float(bn.eps), bool(relu), nbt)
+    return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, momentum, float(bn.eps), bool(relu), nbt,
+                              updates)

@@ -2,12 +2,17 @@
 (mirror of the reference's model/deformation_networks.py)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from .decoder import decoder_dict
 from .encoder import encoder_dict
 from .utils import compute_l2_error
+
+# One encoder pass per distinct surface cloud (NSDP_ENCODE_ONCE=0: one per module call, the reference's op sequence -- A/B)
+ENCODE_ONCE = os.environ.get("NSDP_ENCODE_ONCE", "1") != "0"
 
 
 class Deformation_Networks(nn.Module):
@@ -25,12 +30,19 @@ class Deformation_Networks(nn.Module):
             has_features=has_features, inp_feat_dim=inp_feat_dim, **cfg["model"]["encoder_kwargs"])
         self.decoder = decoder_dict[cfg["model"]["decoder"]](**cfg["model"]["decoder_kwargs"])
 
-    def forward(self, points, surface_samples_inputs):
+    def encode(self, surface_samples_inputs):
+        """The encoding {'z', 'anchors', 'anchor_feats'} of a surface cloud -- the half of forward() that does not depend on
+        the query points.  Callers that decode several query sets against ONE cloud (FlowArbitrary, the dense-inference step
+        functions) encode once and call decode() per set; the reference re-runs the whole module each time."""
         if self.no_input_corr:
-            encoding = self.encoder(surface_samples_inputs[:, :, 0:3].contiguous())
-        else:
-            encoding = self.encoder(surface_samples_inputs)
+            return self.encoder(surface_samples_inputs[:, :, 0:3].contiguous())
+        return self.encoder(surface_samples_inputs)
+
+    def decode(self, points, encoding):
         return self.decoder(points, encoding)
+
+    def forward(self, points, surface_samples_inputs):
+        return self.decoder(points, self.encode(surface_samples_inputs))
 
 
 def _loss_with_cano(model, data_dict, config):
@@ -69,8 +81,14 @@ def validate_on_batch_with_cano(model, data_dict, config):
 def test_on_batch_with_cano(model, data_dict, config, compute_loss=False):
     """Dense inference: surface samples, then all mesh vertices (reference :90-109)."""
     inputs = data_dict["surface_samples_inputs"]
-    data_dict["surface_samples_tgt_pred"] = model(data_dict["surface_samples_src"], inputs)
-    deformed_verts = model(data_dict["verts_src"], inputs)
+    if ENCODE_ONCE:
+        # the reference runs the module twice on the same surface input (:96, :101): same encoding both times
+        encoding = model.encode(inputs)
+        data_dict["surface_samples_tgt_pred"] = model.decode(data_dict["surface_samples_src"], encoding)
+        deformed_verts = model.decode(data_dict["verts_src"], encoding)
+    else:
+        data_dict["surface_samples_tgt_pred"] = model(data_dict["surface_samples_src"], inputs)
+        deformed_verts = model(data_dict["verts_src"], inputs)
     data_dict["verts_tgt_pred"] = deformed_verts
     if compute_loss:
         loss = compute_l2_error(deformed_verts, data_dict["verts_tgt"])

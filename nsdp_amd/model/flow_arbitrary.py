@@ -2,10 +2,13 @@
 (mirror of the reference's model/flow_arbitrary.py)."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
-from .. import precision
+from .. import hip_batchnorm, precision
+from . import deformation_networks
 from .utils import compute_l2_error
 
 
@@ -17,18 +20,38 @@ class FlowArbitrary(nn.Module):
         self.model_canonicalize = model_canonicalize
         self.model_deform = model_deform
 
-    def forward(self, space_samples_src, surface_samples_src, surface_samples_tgt, cano_handle_sample_mask):
+    def _canonicalize_storage(self):
+        # mixed storage (see nsdp_amd/precision.py): the network whose output points feed the second network's geometry
+        # runs in fp32 storage; inputs and outputs are fp32 coordinates in either mode, so there is nothing to cast
         if precision.is_bf16() and precision.canonicalize_f32():
-            # mixed storage (see nsdp_amd/precision.py): the network whose output points feed the second network's geometry
-            # runs in fp32 storage; inputs and outputs are fp32 coordinates in either mode, so there is nothing to cast
-            with precision.storage(torch.float32):
-                space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
-                surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
-        else:
-            space_src2cano = self.model_canonicalize(space_samples_src, surface_samples_src)
-            surf_src2cano = self.model_canonicalize(surface_samples_src, surface_samples_src)
-        deform_in = torch.cat([surf_src2cano, surface_samples_tgt, cano_handle_sample_mask], dim=-1).contiguous()
-        return self.model_deform(space_src2cano, deform_in)
+            return precision.storage(torch.float32)
+        return contextlib.nullcontext()
+
+    def canonicalize(self, query_sets, surface_samples_src):
+        """model_canonicalize applied to several query sets against the SAME source cloud: ONE encoder pass, ONE decoder pass
+        over the concatenated queries (the decoder has no BatchNorm and treats query points independently).  The reference
+        runs the whole network once per set (model/flow_arbitrary.py:19-20); in training mode the two encoder passes see the
+        same batch, produce the same tensors and differ only in what they leave in the BatchNorm buffers -- two momentum
+        updates from the same batch statistics, num_batches_tracked += 2 -- which hip_batchnorm.running_updates reproduces.
+        Autograd sums the decoder paths into one encoder backward."""
+        net = self.model_canonicalize
+        with self._canonicalize_storage():
+            if not deformation_networks.ENCODE_ONCE:
+                return [net(q, surface_samples_src) for q in query_sets]
+            with hip_batchnorm.running_updates(len(query_sets)):      # (inert on eval-mode norms)
+                encoding = net.encode(surface_samples_src)
+            if len(query_sets) == 1:
+                return [net.decode(query_sets[0], encoding)]
+            out = net.decode(torch.cat(list(query_sets), dim=1), encoding)
+            return list(torch.split(out, [q.shape[1] for q in query_sets], dim=1))
+
+    def deform_input(self, surf_src2cano, surface_samples_tgt, cano_handle_sample_mask):
+        return torch.cat([surf_src2cano, surface_samples_tgt, cano_handle_sample_mask], dim=-1).contiguous()
+
+    def forward(self, space_samples_src, surface_samples_src, surface_samples_tgt, cano_handle_sample_mask):
+        space_src2cano, surf_src2cano = self.canonicalize([space_samples_src, surface_samples_src], surface_samples_src)
+        deform_in = self.deform_input(surf_src2cano, surface_samples_tgt, cano_handle_sample_mask)
+        return self.model_deform(space_src2cano.contiguous(), deform_in)
 
 
 def _split(data_dict):
@@ -73,8 +96,16 @@ def validate_on_batch_with_arbitrary(model, data_dict, config):
 def test_on_batch_with_arbitrary(model, data_dict, config, compute_loss=False):
     """reference model/flow_arbitrary.py:65-85."""
     src, tgt, mask = _split(data_dict)
-    data_dict["surface_samples_tgt_pred"] = model(src, src, tgt, mask)
-    deformed_verts = model(data_dict["verts_src"], src, tgt, mask)
+    if deformation_networks.ENCODE_ONCE:
+        # the reference's two model() calls (:71, :76) run six encoder passes over two distinct clouds: the source cloud
+        # (four times) and the canonicalised surface + target + mask (twice).  Two passes here.
+        surf2cano, verts2cano = model.canonicalize([src, data_dict["verts_src"]], src)
+        encoding = model.model_deform.encode(model.deform_input(surf2cano, tgt, mask))
+        data_dict["surface_samples_tgt_pred"] = model.model_deform.decode(surf2cano.contiguous(), encoding)
+        deformed_verts = model.model_deform.decode(verts2cano.contiguous(), encoding)
+    else:
+        data_dict["surface_samples_tgt_pred"] = model(src, src, tgt, mask)
+        deformed_verts = model(data_dict["verts_src"], src, tgt, mask)
     data_dict["verts_tgt_pred"] = deformed_verts
     if compute_loss:
         loss = compute_l2_error(deformed_verts, data_dict["verts_tgt"])

@@ -424,8 +424,13 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
     # Measured (profiles/r4_bf16_bisect.txt): forward.yaml 8.7e-3 -- twice what inputs x (1 + 2^-8) do to the fp32 model
     # (4.4e-3); arbitrary.yaml 1.3e-1 = network 1's ~9e-3 output error amplified by network 2's FPS / kNN on those points, the
     # same as the fp32 model's response to bf16-rounded input coordinates (1.4e-1); with network 1 in fp32 storage 1.0e-2.
-    for name, mtype, l2_bound, net1_f32 in (("full_forward", "forward", 2e-2, False), ("full_arbitrary", "arbitrary", 2.5e-1, False),
-                                            ("full_arbitrary", "arbitrary", 2.5e-2, True)):
+    # The train-step loss of the all-bf16 FlowArbitrary is as ill-conditioned as its eval output: the SAME arithmetic with the batch
+    # mean rounded differently (one-launch BatchNorm kernels against the three-launch forms, NSDP_BN_SLAB=1 / 0) gives 0.1520 /
+    # 0.1455 against the reference's 0.1443 -- a 4.5 % swing from a 1e-7 perturbation, so that case is held to 8 %; with network
+    # 1 in fp32 storage the same switch moves the loss by 1e-3 and the bar stays at 5 %.
+    for name, mtype, l2_bound, net1_f32, loss_bound in (("full_forward", "forward", 2e-2, False, 0.05),
+                                                        ("full_arbitrary", "arbitrary", 2.5e-1, False, 0.08),
+                                                        ("full_arbitrary", "arbitrary", 2.5e-2, True, 0.05)):
         fx, cfg, seed, data = fixture_setup(name, mtype)
         model, train_fn, _ = build_product(cfg, seed, DEV)
         s = int(fx["meta_eval_stride"]) if "meta_eval_stride" in fx else 1
@@ -443,4 +448,4 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
         print(f"\nbf16 storage{' (network 1 in fp32)' if net1_f32 else ''} vs the reference, {name}: eval L2 {l2:.2e}, "
               f"train loss {loss:.6f} (reference {ref_loss:.6f}, rel {abs(loss - ref_loss) / ref_loss:.2e})")
         assert l2 <= l2_bound, (name, l2)
-        assert abs(loss - ref_loss) <= 0.05 * ref_loss, (name, loss, ref_loss)
+        assert abs(loss - ref_loss) <= loss_bound * ref_loss, (name, loss, ref_loss)
