@@ -522,6 +522,21 @@ def main():
             t = torch.tensor([with_readback], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             with_readback = float(t.item())
+    # The dominant kernel class AS REPLAYED: one more replay (outside every timed region) with a HIP event pair around each
+    # of its launches inside the executor -- durations then include the time a kernel shares the chip with the other
+    # stream's kernels, which the isolated pass above excludes on purpose.
+    replayed = None
+    if graph is not None and dominant and hasattr(graph, "timed_replay"):
+        try:
+            fence()
+            stem = dominant.replace("_kernels", "").replace("_kernel", "") + "_kernel"
+            n1, ms1 = graph.timed_replay(stem)
+            n2, ms2 = graph.timed_replay(stem)
+            if n1 and n1 == n2:
+                replayed = {"launches_per_step": n1, "ms_per_step": round(0.5 * (ms1 + ms2), 3)}
+        except Exception as exc:      # (measurement only)
+            replayed = {"error": f"{type(exc).__name__}: {str(exc)[:100]}"}
+        fence()
     gc.enable()
     in_sync = dp.in_sync(model) if dp is not None else True
     parity = None
@@ -574,7 +589,7 @@ def main():
             "final_loss": round(final_loss, 6),
             "roofline": profiling.roofline(prof, prof_iso,
                                            pmc_matches=(args.workload == "forward_train" and args.batch == 32),
-                                           pmc_suffix=("" if args.dtype == "f32" else "_bf16")),
+                                           pmc_suffix=("" if args.dtype == "f32" else "_bf16"), replayed=replayed),
             "kernels": profiling.summary(prof_iso if prof_iso else prof),
             "kernels_from": ("2 untimed steps, every launch timed, weight gradients on the main stream" if prof_iso
                              else "timed region"),

@@ -38,7 +38,8 @@ const char *nsdp_last_error(void);
  * 9 is a HOST HINT, not an ablation: the number of compute units nsdp_linear_wgrad_bf16x3_f32 leaves free (its persistent
  * one-wave-per-SIMD workgroups otherwise hold every CU until the kernel ends); the host sets it around weight-gradient
  * launches that run on a side stream next to the critical chain and resets it to 0 (the workspace query sees the same value).
- * 10: 0 = immediate-insertion kNN kernel; 11: 0 = three-launch BatchNorm forms (A/B against the one-launch slab kernels). */
+ * 10: 0 = immediate-insertion kNN kernel; 11: 0 = three-launch BatchNorm forms (A/B against the one-launch slab kernels), 2 = slab kernels up to 16384 rows;
+ * 12: 0 = one-lane-per-query ball_query / three_nn kernels (A/B against the four-lane plane-tile scans). */
 void nsdp_debug_set(int key, int value);
 /* Number of HIP devices visible (0 when there is none; never fails). */
 int nsdp_device_count(void);
@@ -489,22 +490,6 @@ const char *nsdp_prof_name(int kind);
 int nsdp_prof_collect(int kind, long long *launches, double *total_ms, double *flops, double *bytes);
 
 /* ----------------------------------------------------------------------------------------------
- * Training-mode forward of the decoder's cross attention (CrossTransformerBlock.forward, model/decoder/blocks.py:48-95)
- * as one register-resident chain kernel (csrc/decoder_train.hip): per query point and neighbour slot
- *   h0 = relu(fc_delta.0(rel)), pos = fc_delta.2(h0), u = q - kf[idx] + pos, g0 = relu(fc_gamma.0(u)),
- *   logits = fc_gamma.2(g0);  out = sum over the KN neighbours and the global token of softmax(logits) * (vf[idx] + pos),
- * writing h0 / pos / u / g0 / logits ([B*NQ*KN, dim]) and out / lse ([B*NQ, dim]) -- everything the layered backward
- * pass reads.  rel (B,NQ,KN,3), idx (B,NQ,KN), q (B,dim), kf / vf (B,A,dim), a_g / v_g (B,dim) global-token logits and
- * values, w0 (dim,3) b0 (dim) the row-major fc_delta.0 parameters, w*p the nsdp_pack_weight_f32 packs of the three
- * dim x dim layers with their biases (dim).  dim = 200.
- * -------------------------------------------------------------------------------------------- */
-int nsdp_decoder_attn_train_fwd(const float *rel, const int32_t *idx, const float *q, const float *kf, const float *vf,
-                                const float *a_g, const float *v_g, const float *w0, const float *b0, const float *wd2p,
-                                const float *bd2, const float *wg0p, const float *bg0, const float *wg2p, const float *bg2,
-                                int B, int NQ, int A, int KN, int dim, float *h0, float *pos, float *u, float *g0,
-                                float *logits, float *out, float *lse, void *stream);
-
-/* ----------------------------------------------------------------------------------------------
  * Multi-stream replay of a stream-captured step (csrc/graph_exec.hip).  No counterpart in the reference (its step is
  * enqueued op by op from Python, train.py:150-225); this is the host side of `train_on_batch` taken off the critical
  * path: the step is captured once into a hipGraph_t (our kernels, ATen's, memsets, copies) and replayed from C with the
@@ -516,6 +501,10 @@ int nsdp_decoder_attn_train_fwd(const float *rel, const int32_t *idx, const floa
 int nsdp_graph_exec_create(void *graph, int max_streams, void **out_handle);
 int nsdp_graph_exec_info(void *handle, int *nodes, int *kernels, int *streams, int *cross_edges, int *own_graph_nodes);
 int nsdp_graph_exec_launch(void *handle, void *stream);
+/* One replay with a HIP event pair around every kernel node whose (mangled) name contains `name_substr`; waits for the
+ * replay to finish and returns the number of such launches and the sum of their durations AS REPLAYED -- i.e. including the
+ * time a kernel shares the chip with the other streams' kernels (measurement, not for timed regions). */
+int nsdp_graph_exec_launch_timed(void *handle, void *stream, const char *name_substr, long long *launches, double *total_ms);
 int nsdp_graph_exec_destroy(void *handle);
 
 #ifdef __cplusplus

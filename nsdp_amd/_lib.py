@@ -41,7 +41,7 @@ def lib() -> ctypes.CDLL:
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the hot path.")
         _lib = ctypes.CDLL(SO_PATH)
         _lib.nsdp_last_error.restype = ctypes.c_char_p
-        for key, env in ((1, "NSDP_WGRAD_PIPE"), (3, "NSDP_NT_VARIANT"), (6, "NSDP_X3_DBG"), (7, "NSDP_WG16_DBG"), (8, "NSDP_LIN16_DBG"), (10, "NSDP_KNN_QUEUE"), (11, "NSDP_BN_SLAB")):  # kernel-variant knobs for A/B runs
+        for key, env in ((1, "NSDP_WGRAD_PIPE"), (3, "NSDP_NT_VARIANT"), (6, "NSDP_X3_DBG"), (7, "NSDP_WG16_DBG"), (8, "NSDP_LIN16_DBG"), (10, "NSDP_KNN_QUEUE"), (11, "NSDP_BN_SLAB"), (12, "NSDP_SEARCH_QUAD")):  # kernel-variant knobs for A/B runs
             if os.environ.get(env) is not None:
                 _lib.nsdp_debug_set(key, int(os.environ[env]))
     return _lib

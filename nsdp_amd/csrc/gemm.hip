@@ -974,6 +974,7 @@ void debug_set_wg3(int value);   // wgrad_bf16x3.hip
 void debug_set_x3_reserve(int value);   // gemm_bf16x3.hip
 void debug_set_knn(int value);   // knn.hip
 void debug_set_bn(int value);    // batchnorm.hip
+void debug_set_search(int value);   // pointnet2_ops.hip
 }
 
 extern "C" {
@@ -989,6 +990,7 @@ void nsdp_debug_set(int key, int value) {
   if (key == 9) { nsdp::debug_set_wg3(value); nsdp::debug_set_x3_reserve(value); }
   if (key == 10) nsdp::debug_set_knn(value);
   if (key == 11) nsdp::debug_set_bn(value);
+  if (key == 12) nsdp::debug_set_search(value);
 }
 
 static int linear_dispatch(const float *X, const float *W, const float *bias, const float *residual,

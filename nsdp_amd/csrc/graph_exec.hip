@@ -31,6 +31,7 @@ struct ExecNode {
   int stream = 0;                    // index into GraphExec::streams (0 = the caller's stream)
   int record = -1;                   // event to record after this node, or -1
   std::vector<int> waits;     // events this node's stream waits for before the node
+  hipEvent_t t0 = nullptr, t1 = nullptr;      // launch_timed: timing events around this kernel (created on first use)
 };
 
 struct GraphExec {
@@ -77,6 +78,8 @@ int fail(GraphExec *g, const char *what, hipError_t e) {
     for (auto &x : g->nodes) {
       if (x.sub) (void)hipGraphExecDestroy(x.sub);
       if (x.sub_graph) (void)hipGraphDestroy(x.sub_graph);
+      if (x.t0) (void)hipEventDestroy(x.t0);
+      if (x.t1) (void)hipEventDestroy(x.t1);
     }
     for (auto s : g->side) (void)hipStreamDestroy(s);
     for (auto ev : g->events) (void)hipEventDestroy(ev);
@@ -287,10 +290,40 @@ int nsdp_graph_exec_info(void *handle, int *nodes, int *kernels, int *streams, i
   return 0;
 }
 
+static int launch_impl(GraphExec *g, hipStream_t main, const char *timed_substr);
+
 int nsdp_graph_exec_launch(void *handle, void *stream) {
   NSDP_REQUIRE(handle, "graph_exec_launch: null handle");
+  return launch_impl(static_cast<GraphExec *>(handle), nsdp::as_stream(stream), nullptr);
+}
+
+int nsdp_graph_exec_launch_timed(void *handle, void *stream, const char *name_substr, long long *launches, double *total_ms) {
+  NSDP_REQUIRE(handle && name_substr && launches && total_ms, "graph_exec_launch_timed: null argument");
   GraphExec *g = static_cast<GraphExec *>(handle);
   hipStream_t main = nsdp::as_stream(stream);
+  const int rc = launch_impl(g, main, name_substr);
+  if (rc) return rc;
+  NSDP_HIP_TRY(hipStreamSynchronize(main));
+  long long n = 0;
+  double ms = 0.0;
+  for (ExecNode &x : g->nodes) {
+    if (!x.t0) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, x.t0, x.t1) == hipSuccess) {
+      ++n;
+      ms += t;
+    }
+    (void)hipEventDestroy(x.t0);
+    (void)hipEventDestroy(x.t1);
+    x.t0 = x.t1 = nullptr;
+  }
+  (void)hipGetLastError();
+  *launches = n;
+  *total_ms = ms;
+  return 0;
+}
+
+static int launch_impl(GraphExec *g, hipStream_t main, const char *timed_substr) {
   auto st_of = [&](int s) { return s == 0 ? main : g->side[s - 1]; };
   if (g->n_streams > 1) {      // side streams start behind everything the caller's stream has been given so far
     NSDP_HIP_TRY(hipEventRecord(g->begin, main));
@@ -302,9 +335,22 @@ int nsdp_graph_exec_launch(void *handle, void *stream) {
     if (x.sub) {
       NSDP_HIP_TRY(hipGraphLaunch(x.sub, st));
     } else switch (x.type) {
-      case hipGraphNodeTypeKernel:
+      case hipGraphNodeTypeKernel: {
+        bool timed = false;
+        if (timed_substr) {
+          const char *nm = hipKernelNameRefByPtr(x.kp.func, st);
+          timed = nm && strstr(nm, timed_substr);
+          if (!nm) (void)hipGetLastError();
+        }
+        if (timed) {
+          NSDP_HIP_TRY(hipEventCreate(&x.t0));
+          NSDP_HIP_TRY(hipEventCreate(&x.t1));
+          NSDP_HIP_TRY(hipEventRecord(x.t0, st));
+        }
         NSDP_HIP_TRY(hipLaunchKernel(x.kp.func, x.kp.gridDim, x.kp.blockDim, x.kp.kernelParams, x.kp.sharedMemBytes, st));
+        if (timed) NSDP_HIP_TRY(hipEventRecord(x.t1, st));
         break;
+      }
       case hipGraphNodeTypeMemset:
         if (x.ms.height <= 1) {
           if (x.ms.elementSize == 4) NSDP_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(x.ms.dst), static_cast<int>(x.ms.value), x.ms.width, st));
@@ -339,6 +385,8 @@ int nsdp_graph_exec_destroy(void *handle) {
   for (auto &x : g->nodes) {
     if (x.sub) (void)hipGraphExecDestroy(x.sub);
     if (x.sub_graph) (void)hipGraphDestroy(x.sub_graph);
+    if (x.t0) (void)hipEventDestroy(x.t0);
+    if (x.t1) (void)hipEventDestroy(x.t1);
   }
   for (auto ev : g->events) (void)hipEventDestroy(ev);
   for (auto ev : g->tail_events) (void)hipEventDestroy(ev);

@@ -6,6 +6,8 @@
 // 256 CUs; here every kernel is a flat grid-stride launch over output elements with the fastest-moving
 // output index on consecutive lanes (coalesced stores; gathers hit L2).  All of them are HBM-bound byte
 // movers -- no LDS reuse exists except for the ball-query / 3-NN source cloud, which is LDS-tiled.
+#include <cfloat>
+
 #include "common.h"
 #include "prof.h"
 
@@ -592,6 +594,198 @@ __global__ __launch_bounds__(kThreads) void three_nn_kernel(const float *__restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The two searches above with the scan of csrc/knn.hip (knn_split_queue_kernel): the source tile as three coordinate planes
+// with 16 sentinel entries behind the last point (x = FLT_MAX squares to +inf, which neither `d < r^2` nor `d < best` admits:
+// no range checks), FOUR lanes per query -- a quad walks the tile 16 candidates at a time, lane `sub` takes candidates
+// 4 sub .. 4 sub + 3 of every group (one 64-byte LDS read per quad and plane, the same for all 16 quads of a wave: a
+// broadcast) -- and the distances two at a time on packed fp32 operations, still ((dx*dx + dy*dy) + dz*dz) with one rounding
+// per operation (contraction is off in this file).  With one lane per query (the kernels above) the encoder-sized problems
+// are one wave per SIMD and the scan is latency-bound: 0.04-0.18 of the VALU peak in distance tests (profiles/r4_grouping.txt).
+// Results are bit-identical to the one-lane kernels (tests/test_geometry_gpu.py holds both to the CPU checker); nsdp_debug_set(12, 0)
+// switches back (A/B).
+// ---------------------------------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kQuad = 4;
+constexpr int kQuadQueries = kThreads / kQuad;      // queries per workgroup
+constexpr int kBallMaxSample = 64;                  // the LDS output rows of ball_query_quad_kernel
+
+struct PlaneTile {
+  __attribute__((aligned(16))) float x[kSrcTile + 16];
+  __attribute__((aligned(16))) float y[kSrcTile + 16];
+  __attribute__((aligned(16))) float z[kSrcTile + 16];
+};
+
+// (the caller has a barrier in front: nobody reads the previous tile any more)
+__device__ __forceinline__ void load_plane_tile(PlaneTile &t, const float *__restrict__ src, int cnt) {
+  for (int i = threadIdx.x; i < cnt; i += kThreads) {
+    const float *p = src + static_cast<size_t>(i) * 3;
+    t.x[i] = p[0]; t.y[i] = p[1]; t.z[i] = p[2];
+  }
+  if (threadIdx.x < 16) {
+    t.x[cnt + threadIdx.x] = FLT_MAX; t.y[cnt + threadIdx.x] = 0.f; t.z[cnt + threadIdx.x] = 0.f;
+  }
+}
+
+// squared distances of the query to candidates i .. i + 3 of the tile (i % 4 == 0)
+__device__ __forceinline__ void dist4(const PlaneTile &t, int i, float qx, float qy, float qz, float (&d)[4]) {
+  const f32x4_t X = *reinterpret_cast<const f32x4_t *>(&t.x[i]);
+  const f32x4_t Y = *reinterpret_cast<const f32x4_t *>(&t.y[i]);
+  const f32x4_t Z = *reinterpret_cast<const f32x4_t *>(&t.z[i]);
+  const f32x2_t q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+  {
+    const f32x2_t dx = q2x - f32x2_t{X[0], X[1]}, dy = q2y - f32x2_t{Y[0], Y[1]}, dz = q2z - f32x2_t{Z[0], Z[1]};
+    const f32x2_t r = (dx * dx + dy * dy) + dz * dz;
+    d[0] = r[0]; d[1] = r[1];
+  }
+  {
+    const f32x2_t dx = q2x - f32x2_t{X[2], X[3]}, dy = q2y - f32x2_t{Y[2], Y[3]}, dz = q2z - f32x2_t{Z[2], Z[3]};
+    const f32x2_t r = (dx * dx + dy * dy) + dz * dz;
+    d[2] = r[0]; d[3] = r[1];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void ball_query_quad_kernel(const float *__restrict__ new_xyz_all,
+                                                                  const float *__restrict__ xyz_all, int N, int M, float radius2,
+                                                                  int nsample, int32_t *__restrict__ idx_all) {
+  __shared__ PlaneTile tile;
+  __shared__ int32_t obuf[kQuadQueries * kBallMaxSample];      // [query][nsample]: written out in one contiguous run
+  const int b = blockIdx.y;
+  const float *xyz = xyz_all + static_cast<size_t>(b) * N * 3;
+  const int ql = threadIdx.x / kQuad, sub = threadIdx.x % kQuad;
+  const int j0 = blockIdx.x * kQuadQueries, j = j0 + ql;
+  const bool active = j < M;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (active) {
+    const float *q = new_xyz_all + (static_cast<size_t>(b) * M + j) * 3;
+    qx = q[0]; qy = q[1]; qz = q[2];
+  }
+  const int lane = threadIdx.x & 63, quad0 = lane & ~3;
+  int cnt = active ? 0 : nsample;       // hits so far (the same value in the four lanes of a query)
+  int first = 0;                        // the first hit: what the reference pre-fills every slot with
+  for (int base = 0; base < N; base += kSrcTile) {
+    if (__syncthreads_and(cnt >= nsample)) break;          // (a barrier: the previous tile is no longer read)
+    const int n_tile = min(kSrcTile, N - base);
+    load_plane_tile(tile, xyz + static_cast<size_t>(base) * 3, n_tile);
+    __syncthreads();
+    const int steps = (n_tile + 15) >> 4;
+    for (int s = 0; s < steps; ++s) {
+      if (__builtin_amdgcn_ballot_w64(cnt < nsample) == 0) break;
+      const int t = 16 * s + 4 * sub;
+      float d[4];
+      dist4(tile, t, qx, qy, qz, d);
+      const unsigned mask = (d[0] < radius2 ? 1u : 0u) | (d[1] < radius2 ? 2u : 0u) | (d[2] < radius2 ? 4u : 0u) |
+                            (d[3] < radius2 ? 8u : 0u);
+      if (__builtin_amdgcn_ballot_w64(mask != 0) == 0) continue;
+      const int h = __builtin_popcount(mask);
+      const int h0 = __shfl(h, quad0), h1 = __shfl(h, quad0 + 1), h2 = __shfl(h, quad0 + 2), h3 = __shfl(h, quad0 + 3);
+      const int pre = (sub > 0 ? h0 : 0) + (sub > 1 ? h1 : 0) + (sub > 2 ? h2 : 0);
+      const int total = h0 + h1 + h2 + h3;
+      // candidates of a group in index order = (lane of the quad, slot of the lane): lane `sub` appends behind the hits of
+      // the lanes before it
+      const int mine = mask ? base + t + __builtin_ctz(mask) : 0x7fffffff;
+      const int f01 = min(__shfl(mine, quad0), __shfl(mine, quad0 + 1));
+      const int f23 = min(__shfl(mine, quad0 + 2), __shfl(mine, quad0 + 3));
+      if (cnt == 0 && total) first = min(f01, f23);
+      if (cnt < nsample) {
+        int pos = cnt + pre;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (mask & (1u << u)) {
+            if (pos < nsample) obuf[ql * nsample + pos] = base + t + u;
+            ++pos;
+          }
+        }
+        cnt += total;
+      }
+    }
+  }
+  // slots behind the last hit hold the first hit (ball_query_gpu.cu:33-37); a query without a hit keeps torch::zeros
+  const int filled = cnt < nsample ? cnt : nsample;
+  if (active)
+    for (int l = filled + sub; l < nsample; l += kQuad) obuf[ql * nsample + l] = cnt > 0 ? first : 0;
+  __syncthreads();
+  const int rows = min(kQuadQueries, M - j0);
+  int32_t *out = idx_all + (static_cast<size_t>(b) * M + j0) * nsample;
+  for (int e = threadIdx.x; e < rows * nsample; e += kThreads) out[e] = obuf[e];
+}
+
+__global__ __launch_bounds__(kThreads) void three_nn_quad_kernel(const float *__restrict__ unknown_all,
+                                                                const float *__restrict__ known_all, int n, int m,
+                                                                float *__restrict__ dist2_all, int32_t *__restrict__ idx_all) {
+  __shared__ PlaneTile tile;
+  const int b = blockIdx.y;
+  const float *known = known_all + static_cast<size_t>(b) * m * 3;
+  const int ql = threadIdx.x / kQuad, sub = threadIdx.x % kQuad;
+  const int j = blockIdx.x * kQuadQueries + ql;
+  const bool active = j < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (active) {
+    const float *u = unknown_all + (static_cast<size_t>(b) * n + j) * 3;
+    ux = u[0]; uy = u[1]; uz = u[2];
+  }
+  // (the reference keeps its bests in double, initialised to 1e40: a float distance compares the same against +inf, and
+  // (float)1e40 = +inf is what it stores when fewer than three points exist)
+  const float inf = __builtin_inff();
+  float b1 = inf, b2 = inf, b3 = inf;
+  int i1 = 0, i2 = 0, i3 = 0;
+  for (int base = 0; base < m; base += kSrcTile) {
+    const int n_tile = min(kSrcTile, m - base);
+    __syncthreads();
+    load_plane_tile(tile, known + static_cast<size_t>(base) * 3, n_tile);
+    __syncthreads();
+    const int steps = (n_tile + 15) >> 4;
+    for (int s = 0; s < steps; ++s) {
+      const int t = 16 * s + 4 * sub;
+      float d[4];
+      dist4(tile, t, ux, uy, uz, d);
+      const bool any = d[0] < b3 || d[1] < b3 || d[2] < b3 || d[3] < b3;
+      if (__builtin_amdgcn_ballot_w64(any) == 0) continue;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dd = d[u];
+        const int k = base + t + u;
+        if (dd < b1) {
+          b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = dd; i1 = k;
+        } else if (dd < b2) {
+          b3 = b2; i3 = i2; b2 = dd; i2 = k;
+        } else if (dd < b3) {
+          b3 = dd; i3 = k;
+        }
+      }
+    }
+  }
+  // A lane met its candidates in increasing index order and kept them by strict `<`: its list is ascending in (distance,
+  // index).  The quad's four lists merge by (distance, index) into lane 0 -- the order the reference's single scan produces.
+  const int lane = threadIdx.x & 63, quad0 = lane & ~3;
+  float m1 = b1, m2 = b2, m3 = b3;
+  int k1 = i1, k2 = i2, k3 = i3;
+#pragma unroll
+  for (int o = 1; o < kQuad; ++o) {
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const float dd = __shfl(e == 0 ? b1 : e == 1 ? b2 : b3, quad0 + o);
+      const int k = __shfl(e == 0 ? i1 : e == 1 ? i2 : i3, quad0 + o);
+      if (dd < m1 || (dd == m1 && k < k1)) {
+        m3 = m2; k3 = k2; m2 = m1; k2 = k1; m1 = dd; k1 = k;
+      } else if (dd < m2 || (dd == m2 && k < k2)) {
+        m3 = m2; k3 = k2; m2 = dd; k2 = k;
+      } else if (dd < m3 || (dd == m3 && k < k3)) {
+        m3 = dd; k3 = k;
+      }
+    }
+  }
+  if (active && sub == 0) {
+    float *d2 = dist2_all + (static_cast<size_t>(b) * n + j) * 3;
+    int32_t *io = idx_all + (static_cast<size_t>(b) * n + j) * 3;
+    d2[0] = m1; d2[1] = m2; d2[2] = m3;
+    io[0] = k1; io[1] = k2; io[2] = k3;
+  }
+}
+
+int g_search_quad = 1;      // nsdp_debug_set(12, v), NSDP_SEARCH_QUAD: 0 = the one-lane-per-query kernels (A/B)
+
 // out[b,l,j] = sum_t points[b,l,idx[b,j,t]] * weight[b,j,t]  (interpolate_gpu.cu:72-101), LDS-staged like the gathers:
 // a workgroup owns CH whole (b, l) rows of m floats; a thread owns one j at a time -- its three indices and weights are
 // loaded once for all CH channels -- and the stores of a wave are 256 contiguous bytes of one channel row.
@@ -736,6 +930,10 @@ __global__ void scatter_add_rows_kernel(const float *__restrict__ grad_out,
 
 }  // namespace
 
+namespace nsdp {
+void debug_set_search(int value) { g_search_quad = value; }
+}  // namespace nsdp
+
 extern "C" {
 
 int nsdp_gather_points(const float *points, const int32_t *idx, int B, int C, int N, int M, float *out,
@@ -803,8 +1001,15 @@ int nsdp_ball_query(const float *new_xyz, const float *xyz, int B, int N, int M,
   NSDP_REQUIRE(new_xyz && xyz && idx_out, "ball_query: null pointer");
   NSDP_REQUIRE(B <= 65535, "ball_query: batch %d too large", B);
   hipStream_t st = nsdp::as_stream(stream);
-  NSDP_HIP_TRY(hipMemsetAsync(idx_out, 0, sizeof(int32_t) * static_cast<size_t>(total), st));
   const float radius2 = radius * radius;
+  if (g_search_quad && nsample <= kBallMaxSample) {      // (writes every slot itself: no memset in front)
+    NSDP_TRACE("ball_query_quad");
+    hipLaunchKernelGGL(ball_query_quad_kernel, dim3(nsdp::ceil_div(M, kQuadQueries), B), dim3(kThreads), 0, st, new_xyz, xyz, N,
+                       M, radius2, nsample, idx_out);
+    return nsdp::launch_status("ball_query_quad_kernel");
+  }
+  NSDP_HIP_TRY(hipMemsetAsync(idx_out, 0, sizeof(int32_t) * static_cast<size_t>(total), st));
+  NSDP_TRACE("ball_query");
   hipLaunchKernelGGL(ball_query_kernel, dim3(nsdp::ceil_div(M, kThreads), B), dim3(kThreads), 0, st,
                      new_xyz, xyz, N, M, radius2, nsample, idx_out);
   return nsdp::launch_status("ball_query_kernel");
@@ -815,6 +1020,13 @@ int nsdp_three_nn(const float *unknown, const float *known, int B, int n, int m,
   if (static_cast<long long>(B) * n <= 0) return 0;
   NSDP_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn: null pointer");
   NSDP_REQUIRE(B <= 65535, "three_nn: batch %d too large", B);
+  if (g_search_quad) {
+    NSDP_TRACE("three_nn_quad");
+    hipLaunchKernelGGL(three_nn_quad_kernel, dim3(nsdp::ceil_div(n, kQuadQueries), B), dim3(kThreads), 0,
+                       nsdp::as_stream(stream), unknown, known, n, m, dist2, idx);
+    return nsdp::launch_status("three_nn_quad_kernel");
+  }
+  NSDP_TRACE("three_nn");
   hipLaunchKernelGGL(three_nn_kernel, dim3(nsdp::ceil_div(n, kThreads), B), dim3(kThreads), 0,
                      nsdp::as_stream(stream), unknown, known, n, m, dist2, idx);
   return nsdp::launch_status("three_nn_kernel");

@@ -144,6 +144,19 @@ class GraphedStep:
             hip_linear.invalidate_weight_packs()
         return self._out
 
+    def timed_replay(self, name_substr: str):
+        """One replay with HIP events around every kernel whose name contains ``name_substr``: (launches, total ms) as they
+        run INSIDE the replay, beside the other streams' kernels.  Synchronises; a measurement, not for timed regions."""
+        if self._graph is None:
+            raise RuntimeError("capture() first")
+        n, ms = ctypes.c_longlong(0), ctypes.c_double(0.0)
+        check(lib().nsdp_graph_exec_launch_timed(self._handle, stream_ptr(), name_substr.encode(), ctypes.byref(n),
+                                                 ctypes.byref(ms)), "nsdp_graph_exec_launch_timed")
+        if self.weights_change:
+            from . import hip_linear
+            hip_linear.invalidate_weight_packs()
+        return int(n.value), float(ms.value)
+
     def close(self):
         # Destroying a graph (its executor's streams and events, the torch graph and its memory pool) is not something a
         # thread may do while it CAPTURES another one -- and Python's cycle collector runs `__del__` whenever it likes, in

@@ -227,7 +227,7 @@ class _AttnPost(torch.autograd.Function):
     """y = sum_j softmax_j(a) * (vf[idx] + pos) [+ global token] [+ residual]."""
 
     @staticmethod
-    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None, pre=None, sub=None):
+    def forward(ctx, a, vf, pos, idx, a_g, v_g, residual, link=None, inv=None, sub=None):
         # sub = (kf, q), constants of this node: `pos` holds u = q_i - k_j + pos (hip_linear's init_gather: pos itself was never
         # materialised).  The values v_j + pos_ij are then u + (v + k)[idx] - q_i: the kernels get the table v + k (minus q
         # when it is one vector per shape) in place of vf and, for per-point queries, q as `qsub`.  Gradients are the original
@@ -256,21 +256,18 @@ class _AttnPost(torch.autograd.Function):
         B, n, k, d = a.shape
         N = vf.shape[1] if vf is not None else 1
         dt = a.dtype
-        if pre is not None:          # (aggregate, log-sum-exp) from a fused forward kernel
-            y, lse = pre[0].reshape(B, n, d), pre[1].reshape(B, n, d)
-        else:
-            y = torch.empty((B, n, d), dtype=dt, device=a.device)
-            lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
-            with on_device(a):
-                if qsub is not None:
-                    check(lib().nsdp_attn_post_fwd_q(fptr(a, "a"), fptr(vf, "vk"), fptr(pos, "u"), iptr(idx, "idx"), fptr(qsub, "q"),
-                                                     optptr(residual), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), fptr(y), fptr(lse),
-                                                     stream_ptr()), "nsdp_attn_post_fwd_q")
-                else:
-                    check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
-                                                        _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
-                                                        _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse),
-                                                        stream_ptr()), "nsdp_attn_post_fwd")
+        y = torch.empty((B, n, d), dtype=dt, device=a.device)
+        lse = torch.empty((B, n, d), dtype=torch.float32, device=a.device)
+        with on_device(a):
+            if qsub is not None:
+                check(lib().nsdp_attn_post_fwd_q(fptr(a, "a"), fptr(vf, "vk"), fptr(pos, "u"), iptr(idx, "idx"), fptr(qsub, "q"),
+                                                 optptr(residual), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), fptr(y), fptr(lse),
+                                                 stream_ptr()), "nsdp_attn_post_fwd_q")
+            else:
+                check(_fn("nsdp_attn_post_fwd", dt)(_p(a, dt, "a"), _p(vf, dt, "vf"), _p(pos, dt, "pos"), iptr(idx, "idx"),
+                                                    _p(a_g, dt, "a_g"), _p(v_g, dt, "v_g"), _p(residual, dt, "residual"),
+                                                    _ci(B), _ci(n), _ci(N), _ci(k), _ci(d), _p(y, dt), fptr(lse),
+                                                    stream_ptr()), "nsdp_attn_post_fwd")
         ctx.save_for_backward(a, vf, pos, idx, a_g, v_g, y, residual, lse, qsub)
         ctx.dims = (B, n, N, k, d)
         return y
@@ -334,7 +331,7 @@ class _AttnPost(torch.autograd.Function):
             dpos = None                               # travels as the dX GEMM's residual; attn_pre reports the total
         elif link is not None and ctx.needs_input_grad[2]:
             link.dpos, dpos = dpos, None              # attn_pre's backward adds d(u) and reports the sum
-        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None, None, None
+        return da, dvf, dpos, None, da_g, dv_g, (dy if residual is not None else None), None, None, None
 
 
 def pos_grad_link():
@@ -370,7 +367,7 @@ def attn_pre(q, kf, pos, idx, link=None, inv=None, precomputed=None):
     return _AttnPre.apply(q, kf, pos, idx, link, inv, precomputed)
 
 
-def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None, precomputed=None, sub=None):
+def attn_post(a, vf, pos, idx, a_g=None, v_g=None, residual=None, link=None, inv=None, sub=None):
     if a.dtype is torch.bfloat16 and not NATIVE_BF16:
         return _AttnPost.apply(_f(a), _f(vf), _f(pos), idx, _f(a_g), _f(v_g), _f(residual), link, inv).to(torch.bfloat16)
-    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv, precomputed, sub)
+    return _AttnPost.apply(a, vf, pos, idx, a_g, v_g, residual, link, inv, sub)

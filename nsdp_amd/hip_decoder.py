@@ -128,47 +128,3 @@ def decoder_forward(dec, xyz_q: torch.Tensor, encoding: dict) -> torch.Tensor:
             pack.ptrs, len(t), B, NQ, A, ct.nneigh, DIM, HIDDEN, _lib.fptr(out, "out"), _lib.stream_ptr()),
             "nsdp_decoder_fused_fwd")
     return out
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# training-mode forward of the cross attention as one chain kernel (csrc/decoder_train.hip)
-# ---------------------------------------------------------------------------------------------------------------------
-# "1": the fused forward wherever the shapes allow; "0": the layered kernels; default: see DESIGN.md (measured per box)
-TRAIN_FUSED = os.environ.get("NSDP_DECODER_TRAIN_FUSED", "0") == "1"
-
-
-def attn_train_supported(rel, q, kf, a_g, fc_delta, fc_gamma) -> bool:
-    """One query vector per shape + a global token (the decoder's block), dim = 200, fp32 storage, gradients on."""
-    return (rel is not None and rel.dtype is torch.float32 and rel.is_cuda and rel.dim() == 4 and rel.shape[-1] == 3
-            and q.dim() == 3 and q.shape[1] == 1 and rel.shape[1] != 1 and a_g is not None and kf.shape[-1] == DIM
-            and fc_delta[0].in_features == 3 and fc_delta[2].out_features == DIM and fc_gamma[2].out_features == DIM
-            and fc_delta[0].bias is not None and fc_delta[2].bias is not None and fc_gamma[0].bias is not None
-            and fc_gamma[2].bias is not None)
-
-
-@torch.no_grad()
-def attn_train_forward(rel, idx, q, kf, vf, a_g, v_g, fc_delta, fc_gamma):
-    """All tensors of CrossTransformerBlock's attention that the layered backward pass reads, from ONE launch:
-    returns (h0, pos, u, g0, logits) as [B,n,k,D] and (out, lse) as [B,n,D]  (nsdp_decoder_attn_train_fwd).
-    The three D x D weights are taken as their fp32 fragment-major packs -- the same per-parameter cache the layered path
-    uses (rebuilt by the one batched pack launch after every optimizer step)."""
-    B, n, k, _ = rel.shape
-    A = kf.shape[1]
-    dev = rel.device
-    rel = rel.contiguous()
-    packs = [hip_linear._packs(l.weight.detach(), l.weight, "wp", False)[0] for l in (fc_delta[2], fc_gamma[0], fc_gamma[2])]
-    big = [torch.empty((B, n, k, DIM), dtype=torch.float32, device=dev) for _ in range(5)]
-    out = torch.empty((B, n, DIM), dtype=torch.float32, device=dev)
-    lse = torch.empty((B, n, DIM), dtype=torch.float32, device=dev)
-    f = _lib.fptr
-    with _lib.on_device(rel):
-        _lib.check(_lib.lib().nsdp_decoder_attn_train_fwd(
-            f(rel, "rel"), _lib.iptr(idx, "idx"), f(q.detach().reshape(B, DIM).contiguous(), "q"), f(kf.detach().contiguous(), "kf"),
-            f(vf.detach().contiguous(), "vf"), f(a_g.detach().reshape(B, DIM).contiguous(), "a_g"),
-            f(v_g.detach().reshape(B, DIM).contiguous(), "v_g"),
-            f(fc_delta[0].weight.detach().contiguous(), "fc_delta.0.weight"), f(fc_delta[0].bias.detach(), "fc_delta.0.bias"),
-            f(packs[0], "pack"), f(fc_delta[2].bias.detach(), "bias"), f(packs[1], "pack"), f(fc_gamma[0].bias.detach(), "bias"),
-            f(packs[2], "pack"), f(fc_gamma[2].bias.detach(), "bias"),
-            ctypes.c_int(B), ctypes.c_int(n), ctypes.c_int(A), ctypes.c_int(k), ctypes.c_int(DIM),
-            *[f(t) for t in big], f(out), f(lse), _lib.stream_ptr()), "nsdp_decoder_attn_train_fwd")
-    return big, (out, lse)

@@ -614,7 +614,7 @@ def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                pre=None, init_gather=None, res_sign=1.0, skip=None, tail=None):
+                init_gather=None, res_sign=1.0, skip=None, tail=None):
         # skip: (SkipGrad, is_src) -- see SkipGrad;  tail: (K4Tail, is_src) -- see K4Tail
         ctx.tail = None
         ctx.skip_src = ctx.skip_dst = None
@@ -633,8 +633,6 @@ class _LinearFn(torch.autograd.Function):
         # res_sign: -1 = the residual is subtracted (a projection "minus a table" in one launch)
         # init_gather: (gq, g_div, gk, gidx, rows_per_shape, nsrc), constants of this node -- a gathered difference of two small
         # tables joins the output in the epilogue (see _fwd_x3_gather); whoever owns the tables accounts for their gradients
-        # pre: this layer's output, already computed by a fused forward kernel (hip_decoder.attn_train_forward): the node
-        # only records what its backward needs -- no launch
         # bw (backward contract of a Linear -> ReLU -> Linear pair whose middle tensor has no other reader):
         #   1 on the first layer ("premasked"): the incoming gradient already carries this layer's ReLU mask
         #   2 on the second ("mask_dx"): dX is masked by (x > 0) in the dX kernel's epilogue, i.e. it IS that gradient
@@ -680,9 +678,7 @@ class _LinearFn(torch.autograd.Function):
                   and Kp == K and N % 4 == 0 and M == tlink.x4.shape[0]):
                 tlink.taken = True
                 ctx.tail = tlink
-        if pre is not None:
-            y = pre.reshape(M, N)
-        elif init_gather is not None:
+        if init_gather is not None:
             if kind != "x3" or res2 is not None:
                 raise ValueError("init_gather needs a layer on the bf16x3 kernel (gather_init_ok) without a residual")
             y = _fwd_x3_gather(x2, wp, N, b, init_gather, relu_in, relu_out)
@@ -699,7 +695,7 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:          # (K4Tail: the next layer's dX GEMM produced this layer's weight gradient itself)
-            return (None,) * 16
+            return (None,) * 15
         x2, wpt, y = ctx.saved_tensors
         N = ctx.n_out
         dy2 = dy.reshape(-1, N)
@@ -759,7 +755,7 @@ class _LinearFn(torch.autograd.Function):
             dres = dres.reshape(dy.shape)
             if ctx.res_sign != 1.0:
                 dres = -dres
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -793,7 +789,7 @@ def _observed(t):
 
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
-           out_f32=False, premasked=False, mask_dx=False, precomputed=None, init_gather=None, residual_sign=1.0,
+           out_f32=False, premasked=False, mask_dx=False, init_gather=None, residual_sign=1.0,
            skip_src=None, skip_dst=None, tail_src=None, tail_dst=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
@@ -814,8 +810,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
     if precision.is_bf16():
-        if precomputed is not None or init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst:
-            raise ValueError("precomputed outputs / init_gather / signed residuals / SkipGrad belong to fp32 storage")
+        if init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst:
+            raise ValueError("init_gather / signed residuals / SkipGrad belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -845,7 +841,7 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     if w_param is not None:
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
-                               bool(relu_out), w_param, b_param, grad_sum, None, bw, precomputed, init_gather,
+                               bool(relu_out), w_param, b_param, grad_sum, None, bw, init_gather,
                                float(residual_sign), skip, tail)
-    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw, precomputed,
+    return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw,
                            init_gather, float(residual_sign), skip, None)

@@ -111,7 +111,7 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 # dense layers
 # ---------------------------------------------------------------------------------------------
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
-           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False, precomputed=None,
+           out_f32: bool = False, premasked: bool = False, mask_dx: bool = False,
            init_gather=None, residual_sign: float = 1.0, skip_src=None, skip_dst=None, tail_src=None,
            tail_dst=None) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
@@ -119,7 +119,7 @@ def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, resi
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
-                             precomputed=precomputed, init_gather=init_gather, residual_sign=residual_sign,
+                             init_gather=init_gather, residual_sign=residual_sign,
                              skip_src=skip_src, skip_dst=skip_dst, tail_src=tail_src, tail_dst=tail_dst)
 
 
@@ -222,11 +222,6 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
     as [B,n,k,d]); idx [B,n,k] int32; ``pos`` re-uses an already computed delta(rel) (second attention of the
     set abstraction); a_g / v_g [B,d]: logits / values of a per-shape global token (decoder).
     Returns (aggregate [B,n,d], pos [B,n,k,d])."""
-    if (pos is None and q is not None and a_g is not None and torch.is_grad_enabled() and not precision.is_bf16()
-            and not PAIR_MASK):
-        from .. import hip_decoder
-        if hip_decoder.TRAIN_FUSED and hip_decoder.attn_train_supported(rel, q, kf, a_g, fc_delta, fc_gamma):
-            return _vector_attention_fused_forward(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual, a_g, v_g)
     if isinstance(pos, PosAsU):
         # second attention over the same index set (set abstraction): pos = y - q1_i + k1_j, so
         # u2 = q2_i - k2_j + pos = (q2 - q1)_i - (k2 - k1)_j + y, and the values are y + (v2 + k1)_j - q1_i
@@ -282,23 +277,4 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         u = hip_attention.attn_pre(q, kf, pos, idx, link, inv)      # q_i - kf[idx] + pos, gather fused
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv)
-    return out, pos
-
-
-def _vector_attention_fused_forward(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual, a_g, v_g):
-    """The decoder's block in training mode with its forward pass in ONE launch (hip_decoder.attn_train_forward, the
-    register-resident chain kernel): the autograd graph is the layered one -- the same per-layer nodes with the same
-    backward kernels and hand-over protocols -- but every node receives its output precomputed and launches nothing."""
-    from .. import hip_decoder
-    (h0, pos_t, u_t, g0, logits_t), out_lse = hip_decoder.attn_train_forward(rel, idx, q, kf, vf, a_g, v_g, fc_delta, fc_gamma)
-    pos = linear(linear(rel, fc_delta[0], relu=True, precomputed=h0), fc_delta[2], precomputed=pos_t)
-    link = hip_attention.pos_grad_link() if pos.requires_grad else None
-    if link is not None and FUSE_DPOS:
-        link.grad_sum = hip_linear.InputGradSum()
-    inv = hip_attention.backward_lists(idx, pos.shape[1], kf.shape[1], pos.shape[-1], qb=True)
-    u = hip_attention.attn_pre(q, kf, pos, idx, link, inv, precomputed=u_t)
-    gs = link.grad_sum if link is not None else None
-    logits = linear(linear(u, fc_gamma[0], relu=True, grad_sum=gs, precomputed=g0), fc_gamma[2], precomputed=logits_t)
-    out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv,
-                                  precomputed=out_lse)
     return out, pos

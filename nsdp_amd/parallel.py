@@ -159,10 +159,27 @@ class DataParallel:
         hip_linear.invalidate_weight_packs()      # (parameters changed behind the optimizer's back)
 
     def shard(self, loader):
-        """This rank's batches of one pass over ``loader`` (see the class docstring)."""
-        batches = list(loader)
-        groups = len(batches) // self.world_size
-        return [batches[g * self.world_size + self.rank] for g in range(groups)]
+        """This rank's batches of one pass over ``loader`` (see the class docstring), lazily: one batch is held at a time.
+
+        A loader that can produce a rank's share ITSELF -- a ``shard(rank, world_size)`` method returning an iterable, e.g. on
+        top of a ``DistributedSampler`` with a per-epoch seed -- is asked to: nothing is then loaded and thrown away.
+        Otherwise every rank walks the whole loader and keeps every world-th batch, which REQUIRES that the loader yields the
+        same sequence on every rank (a shuffling loader must be seeded identically on all ranks: ranks that disagree on the order
+        would train on overlapping / missing samples without any error) and costs world x the I/O."""
+        own = getattr(loader, "shard", None)
+        if callable(own):
+            return own(self.rank, self.world_size)
+        return self._every_nth(loader)
+
+    def _every_nth(self, loader):
+        mine = None
+        for i, batch in enumerate(loader):
+            pos = i % self.world_size
+            if pos == self.rank:
+                mine = batch
+            if pos == self.world_size - 1:      # the group is complete on every rank: all of them step (a trailing partial
+                yield mine                      # group is dropped -- the gradient exchange is a collective)
+                mine = None
 
     def mean(self, value: float, device="cpu") -> float:
         """Mean over ranks of a per-rank scalar (epoch losses, validation losses)."""
@@ -185,3 +202,32 @@ class DataParallel:
     def wrap(self, train_on_batch):
         """The reference-shaped step function with the gradient exchange in front of ``optimizer.step``."""
         return data_parallel_step(train_on_batch, self.reducer)
+
+
+def rank_device(local_rank: int, world_size: int, backend: str = "nccl"):
+    """(device index, cpu mask) of this rank of a one-process-per-GPU job, the policy bench.py and nsdp_amd.train share:
+    rank r -> GPU r; the ONE visible device when the launcher narrowed HIP_VISIBLE_DEVICES per process; with a non-RCCL
+    backend (gloo: the path exercised on a single GPU) ranks wrap around the visible devices.  RCCL needs a device per rank.
+    The process is pinned to its slice of the container's CPUs, taken from the GPU's NUMA node (cpu_budget.pin_rank)."""
+    import os
+    n_dev = torch.cuda.device_count()
+    vis = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")).split(",") if d]
+    if n_dev == 1 and world_size > 1 and backend == "nccl" and len(vis) == 1:
+        index = 0
+    elif backend != "nccl":
+        index = local_rank % max(1, n_dev)
+    else:
+        if local_rank >= n_dev:
+            raise RuntimeError(f"rank with LOCAL_RANK {local_rank} needs its own GPU for RCCL, {n_dev} visible "
+                               "(--backend gloo shares devices between ranks)")
+        index = local_rank
+    torch.cuda.set_device(index)
+    mask = None
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world_size)))
+    if local_world > 1:
+        from .cpu_budget import pin_rank
+        props = torch.cuda.get_device_properties(index)
+        bdf = (f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+               if hasattr(props, "pci_bus_id") else None)
+        mask = pin_rank(local_rank, local_world, bdf)
+    return index, mask

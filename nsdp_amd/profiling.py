@@ -80,7 +80,7 @@ def summary(prof):
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
 
-def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix=""):
+def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix="", replayed=None):
     """Roofline object of the dominant hand-written kernel class.
 
     Two measurements exist for every kernel, both taken live with HIP events on the launch stream: inside the timed
@@ -102,6 +102,21 @@ def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix=""):
     if prof_isolated and name in prof:
         ins = _roofline_one(name, prof[name])
         out["in_step"] = {k: ins[k] for k in ("achieved", "frac", "launches", "avg_launch_ms")}
+    # ``replayed`` = {"launches_per_step", "ms_per_step"} of this kernel class inside a REPLAY of the captured step
+    # (GraphedStep.timed_replay): the same algorithmic bytes per launch against the duration a launch has beside the other
+    # stream's kernels -- what the timed region actually runs (the isolated `frac` is the kernel's own).
+    if replayed and replayed.get("launches_per_step"):
+        per = replayed["ms_per_step"] / replayed["launches_per_step"]
+        iso_per_step = v["launches"] / 2.0 if prof_isolated else None        # (the isolated pass times two steps)
+        rate = out["algorithmic_bytes"] / (per * 1e6) if out["bound"] == "hbm" else None
+        out["replayed"] = {"launches_per_step": replayed["launches_per_step"], "avg_launch_ms": round(per, 4),
+                           "class_ms_per_step": replayed["ms_per_step"],
+                           "same_launch_count_as_isolated": (iso_per_step == replayed["launches_per_step"]) if iso_per_step else None}
+        if rate is not None:
+            out["replayed"]["achieved"] = round(rate, 1)
+            out["frac_replayed"] = out["replayed"]["frac"] = round(rate / PEAK_HBM_GBPS, 4)
+    elif replayed:
+        out["replayed"] = replayed
     return out
 
 

@@ -111,6 +111,12 @@ class SyntheticLoader:
     def __len__(self):
         return len(self.batches)
 
+    def shard(self, rank, world_size):
+        """This rank's share of an epoch (DataParallel.shard asks for it): of every ``world_size`` consecutive batches the
+        rank-th; a trailing partial group is dropped so that all ranks take the same number of steps."""
+        groups = len(self.batches) // world_size
+        return (self.batches[g * world_size + rank] for g in range(groups))
+
 
 def initial_weight_files(config, args=None):
     """train.py:140-146: the three weight files that initialise the networks come from the config's ``training``
@@ -171,10 +177,13 @@ def main(argv=None):
     rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     args.best_val_loss = float("inf")
     seed_everything(args.seed)           # (the same seed on every rank: identical initial weights even before the broadcast)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", 0)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(device)
+        from .parallel import rank_device
+        index, cpus = rank_device(local_rank, world, args.backend)       # rank r -> GPU r, pinned to its CPU slice
+        device = torch.device("cuda", index)
+        print(f"nsdp_amd.train: rank {rank} -> GPU {index}, CPUs {cpus}", file=sys.stderr)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)

@@ -15,6 +15,7 @@ seeds, expected outputs and sampled intermediates only.
     python oracle/make_golden.py --arbitrary-full   # writes tests/golden/full_arbitrary.npz only: arbitrary.yaml
                                             # (FlowArbitrary, model/flow_arbitrary.py:15-48) at B = 2, 2048 surface +
                                             # 8192 query points -- BASELINE config 3's shapes on the reference itself
+    python oracle/make_golden.py --arbitrary-b8     # writes tests/golden/b8_arbitrary.npz only: the same at B = 8 (~25 GB)
 """
 from __future__ import annotations
 
@@ -197,6 +198,13 @@ def main():
     if "--arbitrary-full" in sys.argv:
         run_case(ref_model, ref_utils, "arbitrary", [2048, 500, 100], 2, 2048, 8192, 3072, "full_arbitrary", False,
                  eval_stride=8)
+        return
+
+    if "--arbitrary-b8" in sys.argv:
+        # config 3's function at a batch where the decoder's attention layers (458 752 rows) and the first encoder block
+        # (163 840 rows) are on the at-scale kernels of the product; ~25 GB of CPU temporaries in the reference
+        run_case(ref_model, ref_utils, "arbitrary", [2048, 500, 100], 8, 2048, 8192, 5120, "b8_arbitrary", False,
+                 eval_stride=16)
         return
 
     tiny_npl = [256, 64, 16]

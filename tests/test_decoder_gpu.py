@@ -74,105 +74,3 @@ def test_fused_decoder_rejects_other_geometry():
     assert not hip_decoder.supported(dec)
     with pytest.raises(Exception):
         hip_decoder.decoder_forward(dec, torch.zeros(1, 4, 3, device=DEV), {})
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# training-mode forward of the cross attention as one chain kernel (nsdp_decoder_attn_train_fwd, csrc/decoder_train.hip)
-# ---------------------------------------------------------------------------------------------------------------------
-@pytest.fixture
-def train_fused():
-    from nsdp_amd import hip_decoder
-    was = hip_decoder.TRAIN_FUSED
-    hip_decoder.TRAIN_FUSED = True
-    try:
-        yield
-    finally:
-        hip_decoder.TRAIN_FUSED = was
-
-
-@pytest.mark.parametrize("fixture,mtype", [("tiny_forward", "forward"), ("tiny_backward", "backward"), ("full_forward", "forward"),
-                                           ("b16_forward", "forward")])
-def test_train_step_through_the_fused_decoder_forward_matches_the_reference(train_fused, fixture, mtype):
-    """The reference's train step (loss, every gradient, BN statistics, Adam deltas: the fixtures of the imported
-    reference) with the decoder's attention forward running as the one-launch chain kernel and the layered backward."""
-    from helpers import build_product, fixture_setup
-    from test_model_gpu import _check_train_step, _variant_trace
-    fx, cfg, seed, data = fixture_setup(fixture, mtype)
-    model, train_fn, _ = build_product(cfg, seed, DEV)
-    with _variant_trace() as names:
-        _check_train_step(fx, model, train_fn, cfg, data)
-    from nsdp_amd.model import ops
-    if not ops.PAIR_MASK:          # (NSDP_PAIR_MASK=1 keeps the layered forward: its backward contract differs)
-        assert "decoder_attn_train_fwd" in names, sorted(names)
-
-
-def test_fused_decoder_forward_tensors_equal_the_layered_ones():
-    """Every tensor the chain kernel hands to the backward pass against the layered kernels' (ragged query count: the last
-    wave's 16-query tile is partly empty)."""
-    from helpers import build_product, model_cfg, to_dev
-    from nsdp_amd import hip_decoder, synth
-    from nsdp_amd.model import ops
-    cfg = model_cfg("forward", [256, 64, 16])
-    model, _, _ = build_product(cfg, 5, DEV)
-    ct = model.decoder.ct1
-    B, NQ, A = 3, 203, 16
-    g = torch.Generator().manual_seed(3)
-    xyz_q = (torch.rand(B, NQ, 3, generator=g) - 0.5).to(DEV)
-    anchors = (torch.rand(B, A, 3, generator=g) - 0.5).to(DEV)
-    idx = ops.knn_indices(xyz_q, anchors, ct.nneigh)
-    rel = xyz_q.unsqueeze(2) - ops.index_points(anchors, idx)
-    q = torch.randn(B, 1, 200, generator=g).to(DEV)
-    kf, vf = torch.randn(B, A, 200, generator=g).to(DEV), torch.randn(B, A, 200, generator=g).to(DEV)
-    a_g, v_g = torch.randn(B, 200, generator=g).to(DEV), torch.randn(B, 200, generator=g).to(DEV)
-    (h0, pos, u, g0, logits), (out, lse) = hip_decoder.attn_train_forward(rel, idx, q, kf, vf, a_g, v_g, ct.fc_delta, ct.fc_gamma)
-    with torch.no_grad():
-        h0_r = ops.linear(rel, ct.fc_delta[0], relu=True)
-        pos_r = ops.linear(h0_r, ct.fc_delta[2])
-        out_r, _ = ops.vector_attention(rel, q, kf, vf, idx, ct.fc_delta, ct.fc_gamma, a_g=a_g, v_g=v_g)
-        u_r = q.unsqueeze(2) - ops.index_points(kf, idx) + pos_r
-        g0_r = ops.linear(u_r, ct.fc_gamma[0], relu=True)
-        logits_r = ops.linear(g0_r, ct.fc_gamma[2])
-    for name, a, b in (("h0", h0, h0_r), ("pos", pos, pos_r), ("u", u, u_r), ("g0", g0, g0_r), ("logits", logits, logits_r),
-                       ("out", out, out_r)):
-        scale = float(b.abs().max())
-        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, name
-    full = torch.cat([logits, a_g.view(B, 1, 1, 200).expand(B, NQ, 1, 200)], dim=2)
-    assert float((lse - torch.logsumexp(full.double(), dim=2).float()).abs().max()) <= 1e-4
-
-
-@pytest.mark.parametrize("rows", [40000, 3000])
-def test_resnet_block_skip_gradient_joins_the_dx_gemm(rows, monkeypatch):
-    """ResnetBlockFC backward with the skip connection's gradient handed to fc_0's dX GEMM (hip_linear.SkipGrad; large M: in
-    the kernel's epilogue, small M: one add) against autograd's own accumulation: the same two fp32 addends, bit-equal input
-    and weight gradients -- and no elementwise add kernel on the kernel route."""
-    from nsdp_amd.model import ops
-    from nsdp_amd.model.decoder.blocks import ResnetBlockFC
-    if ops.PAIR_MASK:
-        pytest.skip("knob run: the premasked contract takes the add route")
-    torch.manual_seed(1)
-    blk = ResnetBlockFC(128).to(DEV)
-    with torch.no_grad():
-        blk.fc_1.weight.normal_(0, 0.1)
-    g = torch.Generator().manual_seed(rows)
-    x0 = torch.randn(8, rows // 8, 128, generator=g).to(DEV)
-    go = torch.randn(8, rows // 8, 128, generator=g).to(DEV)
-
-    def run(on):
-        monkeypatch.setattr(ops, "SKIP_GRAD", on)
-        for p in blk.parameters():
-            p.grad = None
-        x = x0.clone().requires_grad_(True)
-        y = blk(x * 1.0)            # (x is a non-leaf inside the model: the block's input gradient flows on)
-        y.backward(go)
-        torch.cuda.synchronize()
-        return [y.detach(), x.grad] + [p.grad.clone() for p in blk.parameters()]
-
-    plain, fused = run(False), run(True)
-    for a_, e_ in zip(fused, plain):
-        assert torch.equal(a_, e_)
-    ref = x0.double().requires_grad_(True)
-    w0, b0, w1, b1 = (t.detach().double() for t in (blk.fc_0.weight, blk.fc_0.bias, blk.fc_1.weight, blk.fc_1.bias))
-    yr = ref + torch.relu(torch.relu(ref) @ w0.t() + b0) @ w1.t() + b1
-    yr.backward(go.double())
-    # (norm-wise: a handful of the 5 M hidden activations sit within fp32 rounding of zero and flip their ReLU against fp64)
-    assert float((fused[1].double() - ref.grad).norm()) <= 5e-3 * float(ref.grad.norm())

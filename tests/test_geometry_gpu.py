@@ -206,6 +206,66 @@ def test_ball_query_matches_oracle(radius, nsample):
     np.testing.assert_array_equal(got.cpu().numpy(), ref.ball_query(new_xyz, xyz, radius, nsample))
 
 
+def _trace_names(fn):
+    import ctypes
+    from nsdp_amd import _lib
+    L = _lib.lib()
+    L.nsdp_trace_enable(1)
+    try:
+        out = fn()
+    finally:
+        L.nsdp_trace_enable(0)
+    n = L.nsdp_trace_read(None, 0)
+    buf = ctypes.create_string_buffer(n)
+    L.nsdp_trace_read(buf, n)
+    return out, set(buf.value.decode().split("\n"))
+
+
+@pytest.mark.parametrize("kind", ["uniform", "dupes", "grid"])
+@pytest.mark.parametrize("B,N,M,radius,nsample", [
+    (2, 2048, 500, 0.2, 16), (3, 1500, 300, 0.05, 4), (2, 1000, 64, 2.0, 64), (2, 1025, 65, 0.3, 32), (1, 15, 7, 0.4, 8),
+    (2, 16, 130, 1e-4, 3), (1, 3000, 1, 0.1, 1), (2, 4096, 200, 0.02, 32), (2, 700, 100, 0.25, 65)])
+def test_ball_query_four_lane_scan_matches_oracle(kind, B, N, M, radius, nsample):
+    """The four-lanes-per-query plane-tile scan (ball_query_quad_kernel) against the literal emulation of the reference kernel
+    (ball_query_gpu.cu:9-44): first `nsample` hits in index order, the first hit in every unused slot, zeros without a hit --
+    ragged sizes (tile / group / workgroup edges), early exits, exact distance ties, nsample above the LDS rows (fallback)."""
+    from nsdp_amd import pointnet2_utils as pu
+    xyz = _cloud(100 + N, B, N, kind)
+    new_xyz = _cloud(200 + M, B, M) if kind != "grid" else np.ascontiguousarray(xyz[:, :M] + (0.0 if M <= N else 0.0))
+    if new_xyz.shape[1] != M:
+        new_xyz = _cloud(200 + M, B, M)
+    got, names = _trace_names(lambda: pu.ball_query(radius, nsample, _dev(xyz), _dev(new_xyz)))
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.ball_query(new_xyz, xyz, radius, nsample))
+    if os.environ.get("NSDP_SEARCH_QUAD", "1") != "0":
+        assert ("ball_query_quad" in names) == (nsample <= 64), names
+
+
+@pytest.mark.parametrize("kind", ["uniform", "dupes", "grid"])
+@pytest.mark.parametrize("B,n,m", [(2, 500, 2048), (3, 700, 1300), (2, 65, 1025), (1, 7, 15), (2, 130, 16), (2, 100, 2),
+                                   (1, 50, 1), (2, 2048, 4096), (1, 1, 3000)])
+def test_three_nn_four_lane_scan_matches_oracle(kind, B, n, m):
+    """three_nn_quad_kernel against the literal emulation of interpolate_gpu.cu:9-59 (bests in double from 1e40, strict `<` in
+    index order): indices AND squared distances bit for bit, with exact ties and with fewer than three known points."""
+    from nsdp_amd import _lib
+    unknown = _cloud(300 + n, B, n)
+    known = _cloud(400 + m, B, m, kind)
+    if kind == "grid" and n <= m:
+        unknown = np.ascontiguousarray(known[:, :n])          # queries ON lattice points: ties at every distance
+    d2 = torch.empty(B, n, 3, device="cuda")
+    idx = torch.empty(B, n, 3, dtype=torch.int32, device="cuda")
+    u, k = _dev(unknown), _dev(known)
+
+    def run():
+        _lib.check(_lib.lib().nsdp_three_nn(_lib.fptr(u), _lib.fptr(k), B, n, m, _lib.fptr(d2), _lib.iptr(idx), _lib.stream_ptr()),
+                   "nsdp_three_nn")
+    _, names = _trace_names(run)
+    rd2, ridx = ref.three_nn(unknown, known)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(d2.cpu().numpy(), rd2)
+    if os.environ.get("NSDP_SEARCH_QUAD", "1") != "0":
+        assert "three_nn_quad" in names, names
+
+
 def test_three_nn_and_interpolate_match_oracle():
     from nsdp_amd import pointnet2_utils as pu
     unknown, known = _cloud(31, 2, 700), _cloud(32, 2, 1300)

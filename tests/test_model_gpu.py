@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_product, fixture_setup, l2_err, model_cfg, run_forward, sample_flat, to_dev
+from helpers import build_product, fixture_setup, l2_err, model_cfg, nondeterministic_knobs, run_forward, sample_flat, to_dev
 from nsdp_amd import synth
 from oracle import tdnet_ref
 
@@ -101,7 +101,8 @@ def _variant_trace():
     return cm()
 
 
-def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, replay=False):
+def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, replay=False, loss_rtol=2e-5, chaotic_norm_rtol=5e-2,
+                      chaotic_bn_rtol=2e-2):
     """One optimizer step of the product against what the imported reference produced for the same seeded inputs:
     loss, every gradient (norm + 16 samples), the None-gradient set, BatchNorm running statistics, Adam deltas.
     ``replay``: the checked step is a REPLAY of the captured step through the multi-stream graph executor
@@ -131,7 +132,8 @@ def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, repla
         torch.cuda.synchronize()
     else:
         loss = train_fn(model, opt, to_dev(data, DEV), cfg)
-    assert abs(loss - float(fx["train_loss"])) <= 2e-5 * max(1.0, abs(loss)), (loss, float(fx["train_loss"]))
+    assert abs(loss - float(fx["train_loss"])) <= loss_rtol * max(1.0, abs(loss)), (loss, float(fx["train_loss"]))
+    worst_norm = 0.0
     none = sorted(k for k, p in model.named_parameters() if p.grad is None)
     assert none == sorted(str(s) for s in fx["none_grads"])
     for k, p in model.named_parameters():
@@ -140,13 +142,17 @@ def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, repla
         gn = float(fx["grad_norm/" + k])
         mine = float(p.grad.double().norm())
         if chaotic_prefix and k.startswith(chaotic_prefix):
-            assert abs(mine - gn) <= 5e-2 * gn + 2e-5, (k, mine, gn)
+            worst_norm = max(worst_norm, (abs(mine - gn) - 2e-5) / max(gn, 1e-30))
+            assert abs(mine - gn) <= chaotic_norm_rtol * gn + 2e-5, (k, mine, gn)
             continue
         # absolute floor: some gradients (e.g. fc_delta.2.bias in front of a train-mode BatchNorm) are
         # analytically ~0 and consist of fp32 cancellation noise whose value depends on summation order
         assert abs(mine - gn) <= 3e-3 * gn + 2e-5, (k, mine, gn)
         np.testing.assert_allclose(sample_flat(p.grad, 16), fx["grad_sample/" + k], rtol=5e-3,
                                    atol=1e-4 * gn + 1.5e-5 + 3e-3 * float(np.abs(fx["grad_sample/" + k]).max()), err_msg=k)
+    if chaotic_prefix:
+        print(f"\ntrain step vs the reference: loss rel {abs(loss - float(fx['train_loss'])) / abs(loss):.2e}, worst gradient-norm deviation "
+              f"{worst_norm:.2e}")
     sd = model.state_dict()
     for key, ref in fx.items():
         if key.startswith("bn_after/"):
@@ -154,7 +160,7 @@ def _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix=None, repla
             mine = mine.cpu().numpy() if key.endswith("num_batches_tracked") else sample_flat(mine, 16)
             if chaotic_prefix and key[len("bn_after/"):].startswith(chaotic_prefix) and not key.endswith("num_batches_tracked"):
                 # (batch statistics over a point set that one flipped sample changes: 1e-5 absolute was observed)
-                np.testing.assert_allclose(mine, ref, rtol=2e-2, atol=1e-4, err_msg=key)
+                np.testing.assert_allclose(mine, ref, rtol=chaotic_bn_rtol, atol=1e-4, err_msg=key)
                 continue
             np.testing.assert_allclose(mine, ref, rtol=2e-4, atol=2e-6, err_msg=key)
     for k, p in model.named_parameters():
@@ -248,6 +254,119 @@ def test_full_shape_arbitrary_eval_and_train_step_match_golden():
         # FlowArbitrary fixture stays on the tight bars)
         _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix="model_")
     assert any(n.startswith("linear_bf16x3<") for n in names), names
+
+
+def test_b8_arbitrary_eval_matches_golden_and_train_step_matches_the_oracle_network_by_network():
+    """FlowArbitrary (BASELINE config 3's function) at B = 8 full-size shapes: 458 752 rows in each decoder's attention layers and
+    163 840 in the first encoder blocks, i.e. the at-scale bf16x3 forward / dX / weight-gradient kernels, the one-hot scatter and
+    the side stream -- the code paths of the timed B = 32 step, which full_arbitrary.npz (B = 2) only partly takes.
+
+    FlowArbitrary is a COMPOSITION in which network 2 samples (FPS) and groups (kNN) the points network 1 PREDICTS, so a 1e-6
+    difference in those points flips a farthest-point choice -- and every later choice of that shape -- in most shapes.  The
+    reference does this to itself: the same reference model on the same inputs with 3 instead of 8 CPU threads differs by
+    1.3e-6 (median) in one shape's canonical points and by 5.1e-4 L2 in that shape's output.  Measured for this library at this
+    size: network 1 agrees with the oracle to 3.9e-6 (max abs), network 2 ON THE ORACLE'S canonical points agrees to 6e-7 L2
+    per shape (loss 0.19710150 against 0.19710149), the end-to-end output to 9e-5 ... 2.3e-3 per shape and the end-to-end
+    train loss to 2.4e-3 -- the composition's conditioning, not a kernel's error.  Hence three checks:
+      1. eval mode against the REFERENCE (tests/golden/b8_arbitrary.npz, oracle/make_golden.py --arbitrary-b8): every tap of
+         network 1 at the 2e-4 bar; the final output inside the composition's chaos band per shape;
+      2. train mode against the ORACLE (pinned to the reference, run here on the host), network by network: network 1's
+         predicted points <= 2e-5, network 2 fed the oracle's points <= 1e-5 L2 per shape, loss to 2e-5;
+      3. the GRADIENTS of that train step with network 2's inputs pinned to the oracle's VALUES (the gradient still flows
+         through this library's network 1): every parameter's gradient norm against the oracle's autograd at 3e-3 -- the bar
+         of the forward-model fixtures, with both networks, the coordinate gradients between them and the encode-once
+         decoder pass in the graph."""
+    fx, cfg, seed, data = fixture_setup("b8_arbitrary", "arbitrary")
+    assert (int(fx["meta_batch"]), int(fx["meta_ns"]), int(fx["meta_nq"])) == (8, 2048, 8192)
+    model, train_fn, state = build_product(cfg, seed, DEV)
+    dd = to_dev(data, DEV)
+    # ---- 1. eval mode against the reference's fixture ------------------------------------------------------------------
+    model.eval()
+    from nsdp_amd import hip_decoder
+    tape = {}
+    hs = _hooks(model, tape)
+    hip_decoder.ENABLED = False                  # (layer-by-layer decoders: expose the taps)
+    try:
+        with torch.no_grad():
+            out = run_forward(model, cfg, dd).cpu().numpy()
+    finally:
+        hip_decoder.ENABLED = True
+        for h in hs:
+            h.remove()
+    checked = 0
+    for key, ref in fx.items():
+        if key.startswith("eval_tap/model_canonicalize."):
+            mine = tape[key[len("eval_tap/"):]]
+            if key.startswith("eval_tap/model_canonicalize.decoder") and mine.shape[1] != int(fx["meta_ns"]):
+                mine = mine[:, int(fx["meta_nq"]):].contiguous()       # (see test_eval_forward_matches_golden)
+            np.testing.assert_allclose(sample_flat(mine, 64), ref, rtol=0, atol=2e-4, err_msg=key)
+            checked += 1
+    assert checked >= 15, checked
+    s = int(fx["meta_eval_stride"])
+    err = np.sqrt(((out[:, ::s].astype(np.float64) - fx["eval_out"]) ** 2).sum(-1))
+    per_shape = np.sqrt((np.sort(err, axis=1)[:, :-2] ** 2).mean(-1))
+    print(f"\nFlowArbitrary B = 8 full size, eval L2 vs the reference per shape: {np.array2string(per_shape, precision=2)}")
+    assert np.median(per_shape) <= 3e-3 and per_shape.max() <= 2e-2, per_shape
+    del tape
+    # ---- 2. train mode, network by network, against the oracle ------------------------------------------------------------
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    sd = tdnet_ref.to_torch_state(state, requires_grad=True)
+    cpu = {k: torch.from_numpy(v) for k, v in data.items()}
+    inputs = cpu["surface_samples_inputs"]
+    src, tgt, mask = inputs[:, :, 0:3], inputs[:, :, 3:6], inputs[:, :, 6:7]
+    mc = cfg["model"]
+    q2c = tdnet_ref.deformation_network(sd, mc, cpu["space_samples_src"], src, True, True, "model_canonicalize.", None)
+    s2c = tdnet_ref.deformation_network(sd, mc, src, src, True, True, "model_canonicalize.", None)
+    ref = tdnet_ref.deformation_network(sd, mc, q2c, torch.cat([s2c, tgt, mask], dim=-1).contiguous(), False, True,
+                                        "model_deform.", None)
+    ref_loss = tdnet_ref.compute_l2_error(ref, cpu["space_samples_tgt"])
+    ref_loss.backward()
+    model.train()
+    q2c_d, s2c_d = q2c.detach().to(DEV), s2c.detach().to(DEV)
+    with _variant_trace() as names:
+        orig = model.canonicalize
+        seen = {}
+
+        def pinned(query_sets, surface):
+            a, b = orig(query_sets, surface)
+            seen["a"], seen["b"] = a.detach(), b.detach()
+            # the oracle's VALUES into network 2 (identical inputs -> identical FPS / kNN decisions), this library's GRADIENT path
+            return [q2c_d + (a - a.detach()), s2c_d + (b - b.detach())]
+        model.canonicalize = pinned
+        try:
+            loss = train_fn.loss_fn(model, dd, cfg)
+            loss.backward()
+        finally:
+            model.canonicalize = orig
+    d1 = max(float((seen["a"] - q2c_d).abs().max()), float((seen["b"] - s2c_d).abs().max()))
+    print(f"train mode: network 1's predicted points vs the oracle {d1:.2e} (max abs); loss {float(loss):.8f} vs {float(ref_loss):.8f}")
+    assert d1 <= 2e-5, d1
+    assert abs(float(loss) - float(ref_loss)) <= 2e-5 * float(ref_loss), (float(loss), float(ref_loss))
+    # ---- 3. gradients of both networks against the oracle's autograd -------------------------------------------------------
+    none = sorted(k for k, p in model.named_parameters() if p.grad is None)
+    assert none == sorted(str(x) for x in fx["none_grads"])
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        gn = float(sd[k].grad.double().norm())
+        mine = float(p.grad.double().norm())
+        dev = abs(mine - gn) / max(gn, 1e-30)
+        if gn > 1e-4 and dev > worst[0]:
+            worst = (dev, k)
+        assert abs(mine - gn) <= 3e-3 * gn + 2e-5, (k, mine, gn)
+        sg = sample_flat(sd[k].grad, 16)
+        # entries: 16 samples per tensor at 1.5 % of the largest sampled entry (sums with heavy cancellation, e.g. BatchNorm
+        # weights of network 1, whose gradient arrives through ~70 layers and the coordinate path of network 2), ONE outlier
+        # allowed: a channel that is active in a handful of the 800 rows of the 100-anchor level loses or gains a third of its
+        # gradient when one pre-activation at 1e-7 changes sign (observed: elementwise_extras.1.conv2.weight[204, 204], the
+        # other 15 samples equal to three digits).  The norms carry the bar.
+        mg = sample_flat(p.grad, 16)
+        bad = np.abs(mg - sg) > 5e-3 * np.abs(sg) + 1e-4 * gn + 1.5e-5 + 1.5e-2 * float(np.abs(sg).max())
+        assert int(bad.sum()) <= 1, (k, mg, sg)
+    print(f"worst gradient-norm deviation from the oracle (norms > 1e-4): {worst[0]:.2e} ({worst[1]})")
+    assert any(n.startswith("linear_bf16x3<") and n.split(",")[3] == "8" for n in names), names
+    assert any(n.startswith("wgrad_bf16x3<13,13") for n in names), names
 
 
 def test_b16_train_step_matches_golden():
@@ -513,8 +632,10 @@ def test_flat_bucket_gradients_equal_plain_gradients_on_gpu():
     for k, p in model2.named_parameters():
         assert p.grad.data_ptr() == dict(zip([n for n, _ in red.named], red.views))[k].data_ptr()
         g = plain[k]
-        # two runs differ by fp32 atomic-ordering noise in the scatter-adds
-        assert float((p.grad - g).abs().max()) <= 2e-3 * float(g.abs().max()) + 1e-6, k
+        if nondeterministic_knobs():       # (the A/B forms with floating-point atomics: ordering noise in the scatter-adds)
+            assert float((p.grad - g).abs().max()) <= 2e-3 * float(g.abs().max()) + 1e-6, k
+        else:                              # the step is bit-reproducible: a view into the flat bucket receives the SAME bits
+            assert torch.equal(p.grad, g), k
 
 
 @pytest.mark.parametrize("mtype", ["forward", "arbitrary"])

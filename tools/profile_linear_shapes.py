@@ -37,14 +37,20 @@ hip_linear._k4tail_fn = rec_tail
 def rec_wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     calls[("wgrad", dy2.shape[0], dy2.shape[1], x2.shape[1], mask is not None, bool(relu_x), bool(want_db))] += 1
     return orig_wgrad(dy2, x2, mask, relu_x, want_db, out)
-hip_linear._run, hip_linear._wgrad = rec_fwd, rec_wgrad
+orig_gather = hip_linear._fwd_x3_gather
+def rec_gather(x2, wp, N, b, gather, relu_in, relu_out):
+    # the position-encoding GEMM whose epilogue adds the gathered q - k rows (nsdp_linear_bf16x3_gather_f32): the same kernel class
+    calls[("gat-x3", x2.shape[0], N, x2.shape[1], b is not None, gather[0] is not None, bool(relu_in), bool(relu_out),
+           int(gather[1]), int(gather[4]), int(gather[5]))] += 1
+    return orig_gather(x2, wp, N, b, gather, relu_in, relu_out)
+hip_linear._run, hip_linear._wgrad, hip_linear._fwd_x3_gather = rec_fwd, rec_wgrad, rec_gather
 for _ in range(2):
     calls.clear()
     model.zero_grad(set_to_none=True)
     loss = compute_l2_error(model(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"])
     loss.backward()
 torch.cuda.synchronize()
-hip_linear._run, hip_linear._wgrad, hip_linear._k4tail_fn = orig_fwd, orig_wgrad, orig_tail
+hip_linear._run, hip_linear._wgrad, hip_linear._k4tail_fn, hip_linear._fwd_x3_gather = orig_fwd, orig_wgrad, orig_tail, orig_gather
 
 def timeit(fn, n=8):
     for _ in range(2): fn()
@@ -67,6 +73,18 @@ for key, cnt in calls.items():
         tfn = orig_tail(link, wpt, N, "x3", None)
         t = timeit(lambda: tfn(x, x4, None, False, True))
         flags = "k4"
+    elif key[0] == "gat-x3":
+        _, M, N, K, hb, two, ri, ro, kk, rps, nsrc = key
+        x = torch.randn(M, K, device=dev)
+        wp = hip_linear.pack_weight_x3(torch.randn(N, K, device=dev))[0]
+        b = torch.randn(N, device=dev) if hb else None
+        # the step's own geometry: rows = (shape, centre, neighbour); a per-centre q table + a per-shape k table (two tables), or
+        # one per-shape table of differences (the decoder: one query vector per shape)
+        gidx = torch.randint(0, nsrc, (M,), device=dev, dtype=torch.int32)
+        gk = torch.randn((M // rps) * nsrc, N, device=dev)
+        gq = torch.randn(-(-M // kk), N, device=dev) if two else None
+        t = timeit(lambda: orig_gather(x, wp, N, b, (gq, kk, gk, gidx, rps, nsrc), ri, ro))
+        flags = "".join(c for c, f in zip("b2IO", (hb, two, ri, ro)) if f)
     elif key[0].startswith("nt"):
         kname, M, N, K, hb, hr, hm, ho, ri, ro = key
         kind = kname[3:]
@@ -85,13 +103,25 @@ for key, cnt in calls.items():
         t = timeit(lambda: orig_wgrad(dy, x, m, rx, wdb))
         flags = "".join(c for c, f in zip("mxb", (hm, rx, wdb)) if f)
     fl = 2.0 * M * N * K
-    rows.append((t * cnt, key[0], M, N, K, flags, cnt, t, fl / t / 1e9))
+    # algorithmic bytes per launch exactly as the C side accounts them (4(M(K+N)+NK); the tail form stores nothing:
+    # 4(M(K+4)+NK); weight gradient 4M(N+K)) -- csrc/gemm_bf16x3.hip, csrc/wgrad_bf16x3.hip prof::Scope lines
+    ab = 4.0 * (M * (K + 4) + N * K) if key[0] == "tail-x3" else 4.0 * M * (N + K) if key[0] == "wgrad" else 4.0 * (M * (K + N) + N * K)
+    rows.append((t * cnt, key[0], M, N, K, flags, cnt, t, fl / t / 1e9, ab))
     del x
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-print(f"total isolated GEMM time per step: {tot:.2f} ms  (nt {sum(r[0] for r in rows if r[1].startswith('nt')):.2f}, k4 tail {sum(r[0] for r in rows if r[1]=='tail-x3'):.2f}, wgrad {sum(r[0] for r in rows if r[1]=='wgrad'):.2f})")
-print("kind   M        N    K    flags  count  ms/call  TF     ms/step  cum%")
+print(f"total isolated GEMM time per step: {tot:.2f} ms  (nt {sum(r[0] for r in rows if r[1].startswith('nt')):.2f}, gather epilogue {sum(r[0] for r in rows if r[1]=='gat-x3'):.2f}, k4 tail {sum(r[0] for r in rows if r[1]=='tail-x3'):.2f}, wgrad {sum(r[0] for r in rows if r[1]=='wgrad'):.2f})")
+# per kernel class: launches, algorithmic bytes, isolated time per step -- `linear_bf16x3_kernel` here must equal the bench line's
+# roofline.launches / 2 (the isolated pass times two steps) and roofline.algorithmic_bytes x launches
+classes = {"linear_bf16x3_kernel": ("nt-x3", "gat-x3", "tail-x3"), "linear_nt_kernel (exact fp32)": ("nt-wp",), "weight gradients (all kernels)": ("wgrad",)}
+print("class                              launches/step  algorithmic GB/step  isolated ms/step  GB/s    frac of 8 TB/s")
+for cname, kinds in classes.items():
+    sel = [r for r in rows if r[1] in kinds]
+    n = sum(r[6] for r in sel); gb = sum(r[9] * r[6] for r in sel) / 1e9; ms = sum(r[0] for r in sel)
+    if n:
+        print(f"{cname:34s} {n:13d}  {gb:19.2f}  {ms:16.2f}  {gb / ms * 1e3:6.0f}  {gb / ms / 8.0:6.3f}")
+print("kind   M        N    K    flags  count  ms/call  TF     ms/step  cum%   alg MB/launch")
 cum = 0.0
-for tt, kind, M, N, K, flags, cnt, t, tf in rows:
+for tt, kind, M, N, K, flags, cnt, t, tf, ab in rows:
     cum += tt
-    print(f"{kind:6s} {M:8d} {N:4d} {K:4d} {flags:6s} {cnt:5d}  {t:7.3f}  {tf:6.1f} {tt:7.2f}  {100*cum/tot:5.1f}")
+    print(f"{kind:6s} {M:8d} {N:4d} {K:4d} {flags:6s} {cnt:5d}  {t:7.3f}  {tf:6.1f} {tt:7.2f}  {100*cum/tot:5.1f}  {ab / 1e6:9.2f}")
