@@ -1218,7 +1218,9 @@ void launch_x3_pre(const X3Params &p, hipStream_t st, int wgs_per_cu = 1) {
   // persistent workgroups, one per CU: the next tile's first k blocks are prefetched under the current tile's
   // last MFMAs and epilogue
   // (experiment knob, read once: NSDP_X3_RESERVE_CUS = compute units left free for the other stream's kernels)
-  static const int reserve = getenv("NSDP_X3_RESERVE_CUS") ? atoi(getenv("NSDP_X3_RESERVE_CUS")) : 0;
+  static const int reserve_env = getenv("NSDP_X3_RESERVE_CUS") ? atoi(getenv("NSDP_X3_RESERVE_CUS")) : 0;
+  // (host hint 9, set around launches that run on a side stream beside the critical chain: see nsdp_debug_set)
+  const int reserve = g_x3_side_reserve > 0 && g_x3_side_reserve < nsdp::num_cus() ? g_x3_side_reserve : reserve_env;
   const long long slots = static_cast<long long>(nsdp::num_cus() - reserve) * wgs_per_cu;
   const unsigned grid = static_cast<unsigned>(wg_tiles < slots ? wg_tiles : slots);
   NSDP_TRACE("linear_bf16x3<%d,%d,%d,%d,%d>x%d%s%s", MT, NT, PRE, WV, static_cast<int>(XREG), wgs_per_cu, KBM > 2 ? " wres" : "",

@@ -476,6 +476,23 @@ def _repack_all(device):
     return True
 
 
+def refresh_weight_packs(device):
+    """Rebuild the registered packs of ``device`` NOW, on the current stream, if any of them is stale.  For code that is
+    about to launch dense layers on ANOTHER stream: the batched rebuild is triggered by the first stale pack that is used, on
+    whatever stream that use happens to be -- every other stream's layers would then read packs that are being rewritten."""
+    reg = _pack_registry.get(device.index)
+    if reg is None or len(reg["entries"]) < _BATCH_MIN:
+        return
+    for ent in reg["entries"].values():
+        prm = ent[0]()
+        if prm is None:
+            continue
+        cache = prm.__dict__.get("_nsdp_pack")
+        if cache is None or cache["key"] != _pack_key(prm):
+            _repack_all(device)
+            return
+
+
 def _packs(w, owner, kind, want_t):
     """(pack of W, pack of W^T or None) of w [N,K]; kind 'wp' = fp32 fragment-major, 'x3' = bf16x3 planes.
     `owner` (the layer's nn.Parameter, or None) carries a cache keyed by (storage pointer, version counter, weights

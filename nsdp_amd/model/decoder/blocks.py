@@ -9,6 +9,9 @@ from .. import ops
 from ... import precision
 
 
+PREFETCH_RESERVE_CUS = int(__import__("os").environ.get("NSDP_PREFETCH_RESERVE_CUS", "0"))
+
+
 class CrossTransformerBlock(nn.Module):
     """Cross attention from every query point to its `nneigh` nearest anchors plus one global token
     (reference model/decoder/blocks.py:12-95, separate_delta=True: delta evaluated twice with the same
@@ -30,18 +33,52 @@ class CrossTransformerBlock(nn.Module):
             self.fc = nn.Linear(dim, dim_inp)
         self.reduce_dim = reduce_dim
 
-    def forward(self, xyz_q, lat_rep, xyz, points):
+    def prefetch(self, xyz_q, xyz, after=None):
+        """The part of forward() that needs only the query points and the ANCHOR COORDINATES -- the anchor search, the relative
+        coordinates and the position encoding delta(q_i - a_j) (a K = 4 layer and a 200 x 200 GEMM over B * NQ * 7 rows: ~1.8 ms
+        of a B = 32 step) -- enqueued on a stream of its own behind ``after`` (the stream that produces ``xyz``) and behind the
+        current stream, i.e. BESIDE the encoder's forward chain, whose 500- and 100-point levels leave most of the chip idle.
+        The reference computes it after the encoder (model/decoder/blocks.py:49-52, :77-79).  forward(prefetched=) joins."""
+        from ... import hip_linear
+        hip_linear.refresh_weight_packs(xyz_q.device)      # (on THIS stream: see there)
+        main = torch.cuda.current_stream(xyz_q.device)
+        s = ops.prefetch_stream(xyz_q.device)
+        s.wait_stream(main)
+        if after is not None:
+            s.wait_stream(after)
+        with torch.cuda.stream(s):
+            idx = ops.knn_indices(xyz_q, xyz, self.nneigh)
+            rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)
+            # (the position-encoding GEMM is a persistent full-chip kernel: it leaves PREFETCH_RESERVE_CUS compute units to the
+            # encoder's chain, like the weight-gradient kernels of the backward pass do)
+            hip_linear.lib().nsdp_debug_set(9, PREFETCH_RESERVE_CUS)
+            try:
+                pos = ops.mlp2(rel, self.fc_delta)
+            finally:
+                hip_linear.lib().nsdp_debug_set(9, 0)
+        return {"xyz_q": xyz_q, "xyz": xyz, "idx": idx, "rel": rel, "pos": pos, "stream": s}
+
+    def forward(self, xyz_q, lat_rep, xyz, points, prefetched=None):
         assert lat_rep.dim() == 2, "per-query latent codes are not used by any NSDP configuration"
-        idx = ops.knn_indices(xyz_q, xyz, self.nneigh)                       # [B,NQ,k]
+        pos = None
+        if prefetched is not None and prefetched["xyz_q"] is xyz_q and prefetched["xyz"] is xyz:
+            main = torch.cuda.current_stream(xyz_q.device)
+            main.wait_stream(prefetched["stream"])
+            idx, rel, pos = prefetched["idx"], prefetched["rel"], prefetched["pos"]
+            for t in (idx, rel, pos):
+                t.record_stream(main)
+        else:
+            idx = ops.knn_indices(xyz_q, xyz, self.nneigh)                   # [B,NQ,k]
         q = ops.linear(lat_rep, self.w_qs)                                   # [B,D]  (shared by all queries)
         k_g = ops.linear(lat_rep, self.w_k_global)
         v_g = ops.linear(lat_rep, self.w_v_global)
         kf = ops.linear(points, self.w_ks)                                   # [B,A,D] anchor tables
         vf = ops.linear(points, self.w_vs)
-        rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)                # xyz_q - a_j
+        if pos is None:
+            rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)            # xyz_q - a_j
         logit_g = ops.mlp2(q - k_g, self.fc_gamma)                           # [B,D]: identical for all queries
         res, _ = ops.vector_attention(rel, q.unsqueeze(1), kf, vf, idx, self.fc_delta,
-                                      self.fc_gamma, a_g=logit_g, v_g=v_g)
+                                      self.fc_gamma, a_g=logit_g, v_g=v_g, pos=pos)
         if not self.reduce_dim:
             res = ops.linear(res, self.fc)
         return res

@@ -26,12 +26,19 @@ class CrossTransformerDecoder(nn.Module):
         self.fc_c = nn.ModuleList([nn.Linear(dim, hidden_dim) for _ in range(n_blocks)])
         self.fc_out = nn.Linear(hidden_dim, out_dim)
 
+    def prefetch(self, xyz_q, anchors, after=None):
+        """CrossTransformerBlock.prefetch for this decoder's attention block (None where forward() would not use it: the
+        no-grad path runs the fused whole-decoder kernel)."""
+        if (hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self) and not precision.is_bf16()):
+            return None
+        return self.ct1.prefetch(xyz_q, anchors, after)
+
     def forward(self, xyz_q, encoding):
         if (hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self)
                 and not precision.is_bf16()):
             # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
             return hip_decoder.decoder_forward(self, xyz_q, encoding)
-        lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"])
+        lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"], prefetched=encoding.get("prefetch"))
         if precision.is_bf16() and TRUNK_F32:
             # bf16 storage keeps the [B, NQ, 7, 200] tensors of the attention block in bf16 -- 7 x the rows and 1.6 x the width
             # of the trunk -- while the residual stream `net` (128 wide, one row per query: the tensor that accumulates six

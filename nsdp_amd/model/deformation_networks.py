@@ -2,6 +2,7 @@
 (mirror of the reference's model/deformation_networks.py)."""
 from __future__ import annotations
 
+import inspect
 import os
 
 import torch
@@ -13,6 +14,13 @@ from .utils import compute_l2_error
 
 # One encoder pass per distinct surface cloud (NSDP_ENCODE_ONCE=0: one per module call, the reference's op sequence -- A/B)
 ENCODE_ONCE = os.environ.get("NSDP_ENCODE_ONCE", "1") != "0"
+# NSDP_DECODER_PREFETCH=1: the decoder's anchor-only work (anchor search, relative coordinates, position-encoding MLP: ~1.8 ms
+# at B = 32) on its own stream beside the encoder's forward chain instead of behind it.  OFF by default -- measured on one box,
+# interleaved: B = 32 41.30 / 41.38 ms against 40.91 / 41.03 (41.06-41.18 with the prefetch GEMM confined to half the chip), bf16
+# +0.1 ms, FlowArbitrary +1 ms; B = 8 14.73 / 14.76 against 14.86 / 14.90 (the only win).  The encoder's forward is not idle
+# under it: its 500- and 100-point levels are 256 k- and 320 k-row GEMMs that fill the chip, so the two chains time-share, and
+# the early launch gives up the q - k + pos epilogue of the position-encoding GEMM (docs/EXPERIMENTS.md, round 5).
+DECODER_PREFETCH = os.environ.get("NSDP_DECODER_PREFETCH", "0") == "1"
 
 
 class Deformation_Networks(nn.Module):
@@ -30,19 +38,24 @@ class Deformation_Networks(nn.Module):
             has_features=has_features, inp_feat_dim=inp_feat_dim, **cfg["model"]["encoder_kwargs"])
         self.decoder = decoder_dict[cfg["model"]["decoder"]](**cfg["model"]["decoder_kwargs"])
 
-    def encode(self, surface_samples_inputs):
+    def encode(self, surface_samples_inputs, queries=None):
         """The encoding {'z', 'anchors', 'anchor_feats'} of a surface cloud -- the half of forward() that does not depend on
         the query points.  Callers that decode several query sets against ONE cloud (FlowArbitrary, the dense-inference step
-        functions) encode once and call decode() per set; the reference re-runs the whole module each time."""
-        if self.no_input_corr:
-            return self.encoder(surface_samples_inputs[:, :, 0:3].contiguous())
-        return self.encoder(surface_samples_inputs)
+        functions) encode once and call decode() per set; the reference re-runs the whole module each time.
+        ``queries``: the points decode() will be called with next -- the decoder's anchor-only work is then launched beside the
+        encoder's forward chain (CrossTransformerDecoder.prefetch, NSDP_DECODER_PREFETCH=0 switches it off)."""
+        x = surface_samples_inputs[:, :, 0:3].contiguous() if self.no_input_corr else surface_samples_inputs
+        if (DECODER_PREFETCH and queries is not None and queries.is_cuda and hasattr(self.decoder, "prefetch")
+                and "on_anchors" in inspect.signature(self.encoder.forward).parameters):
+            return self.encoder(x, on_anchors=lambda anchors, after: self.decoder.prefetch(queries, anchors, after))
+        return self.encoder(x)
 
     def decode(self, points, encoding):
         return self.decoder(points, encoding)
 
     def forward(self, points, surface_samples_inputs):
-        return self.decoder(points, self.encode(surface_samples_inputs))
+        points = points if points.is_contiguous() else points.contiguous()
+        return self.decoder(points, self.encode(surface_samples_inputs, queries=points))
 
 
 def _loss_with_cano(model, data_dict, config):

@@ -40,13 +40,18 @@ class PointTransformerEncoder(nn.Module):
         self.final_elementwise = nn.ModuleList(
             [ElementwiseMLP(dim=d_transformer) for _ in range(nfinal_transformers)])
 
-    def forward(self, xyz):
+    def forward(self, xyz, on_anchors=None):
+        """``on_anchors(anchors, after)``: called as soon as the anchor coordinates (the last level of the geometry pyramid) are
+        ENQUEUED -- on the pyramid's stream ``after``, ~1 ms into a step -- so that work which needs nothing else of the encoding
+        (the decoder's anchor search and position encoding, CrossTransformerDecoder.prefetch) can be launched beside the
+        encoder's forward chain.  Whatever it returns travels in the encoding as ``'prefetch'``."""
         coords = xyz[:, :, :3].contiguous() if self.has_features else xyz
         # all FPS / kNN index tensors of the pyramid, launched on a side stream under transformer_begin
         levels, join = ops.geometry_pyramid(
             coords, [td.sa.npoint for td in self.transition_downs],
             [(td.sa.nneigh, None if tb.group_all else tb.k)
              for td, tb in zip(self.transition_downs, self.transformer_downs)])
+        prefetch = on_anchors(levels[-1]["new_xyz"], ops.geometry_stream(coords.device)) if (on_anchors and levels) else None
         if self.has_features:
             feats = ops.linear(xyz[:, :, 3:], self.enc_sdf)
             xyz = coords
@@ -67,4 +72,7 @@ class PointTransformerEncoder(nn.Module):
                 final_idx = ops.knn_indices(xyz, xyz, blk.k)
             feats = mlp(blk(xyz, feats, idx=final_idx))
         lat_vec = feats.max(dim=1)[0]
-        return {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}
+        enc = {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}
+        if prefetch is not None:
+            enc["prefetch"] = prefetch
+        return enc

@@ -38,11 +38,13 @@ class FlowArbitrary(nn.Module):
         with self._canonicalize_storage():
             if not deformation_networks.ENCODE_ONCE:
                 return [net(q, surface_samples_src) for q in query_sets]
+            queries = query_sets[0] if len(query_sets) == 1 else torch.cat(list(query_sets), dim=1)
+            queries = queries if queries.is_contiguous() else queries.contiguous()
             with hip_batchnorm.running_updates(len(query_sets)):      # (inert on eval-mode norms)
-                encoding = net.encode(surface_samples_src)
+                encoding = net.encode(surface_samples_src, queries=queries)
             if len(query_sets) == 1:
-                return [net.decode(query_sets[0], encoding)]
-            out = net.decode(torch.cat(list(query_sets), dim=1), encoding)
+                return [net.decode(queries, encoding)]
+            out = net.decode(queries, encoding)
             return list(torch.split(out, [q.shape[1] for q in query_sets], dim=1))
 
     def deform_input(self, surf_src2cano, surface_samples_tgt, cano_handle_sample_mask):

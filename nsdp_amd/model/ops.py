@@ -39,6 +39,21 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+def geometry_stream(device):
+    """The stream geometry_pyramid enqueues on (None when there is none yet)."""
+    return _side_streams.get((device.type, device.index))
+
+
+_prefetch_streams = {}
+
+
+def prefetch_stream(device):
+    key = (device.type, device.index)
+    if key not in _prefetch_streams:
+        _prefetch_streams[key] = torch.cuda.Stream(device=device)
+    return _prefetch_streams[key]
+
+
 @torch.no_grad()
 def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
     """Every index tensor of the encoder's down-sampling pyramid depends on coordinates only:
