@@ -120,6 +120,13 @@ int nsdp_knn(const float *query, const float *source, int B, int n, int m, int k
 /* index_points(points(B,N,C), idx(B,S)) -> (B,S,C) (row gather; model/utils.py:58-70) */
 int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int C, int S, float *out,
                      void *stream);
+/* rel4 (B,n,k,4) = (sign * (query[b,i] - source[b, idx[b,i,j]]), 0): the relative coordinates an attention block feeds to its
+ * position-encoding MLP (model/encoder/blocks.py:104-106, :285-286, model/decoder/blocks.py:72-78: index_points + broadcast
+ * subtraction), already zero-padded to the K = 4 layer's 16-byte rows.  query (B,n,3), source (B,m,3), idx (B,n,k) int32,
+ * sign = +1 (query - source) or -1 (source - query).  One rounding per component, as torch.sub.  No gradient: for coordinates
+ * that need one the host keeps the differentiable gather + subtraction. */
+int nsdp_rel_coords4(const float *query, const float *source, const int32_t *idx, int B, int n, int m, int k, float sign,
+                     float *out4, void *stream);
 /* backward of index_points: grad_points(B,N,C) += scatter of grad_out(B,S,C) (zero-filled first). */
 int nsdp_scatter_add_rows(const float *grad_out, const int32_t *idx, int B, int N, int C, int S,
                           float *grad_points, void *stream);

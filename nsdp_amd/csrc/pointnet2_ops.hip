@@ -784,6 +784,28 @@ __global__ __launch_bounds__(kThreads) void three_nn_quad_kernel(const float *__
   }
 }
 
+// rel4[b, i, j] = (sign * (q[b, i] - s[b, idx[b, i, j]]), 0): the relative coordinates every attention block feeds to its
+// position-encoding MLP (reference model/encoder/blocks.py:104-106, :285-286, model/decoder/blocks.py:72-78: index_points +
+// a broadcast subtraction; here followed by the zero-padding of K = 3 to the K = 4 layer's 16-byte rows) as one kernel with
+// one float4 store per (centre, neighbour) instead of a gather, a subtraction, a fill and a strided copy.  One rounding per
+// component (q - s, exactly negated for sign < 0), as torch.sub.
+__global__ __launch_bounds__(kThreads) void rel_coords4_kernel(const float *__restrict__ q, const float *__restrict__ s,
+                                                              const int32_t *__restrict__ idx, long long total, int n, int m,
+                                                              int k, int negate, float4 *__restrict__ out) {
+  for (long long e = blockIdx.x * static_cast<long long>(kThreads) + threadIdx.x; e < total;
+       e += static_cast<long long>(gridDim.x) * kThreads) {
+    const long long row = e / k;                 // (b, i)
+    const long long b = row / n;
+    const float *qp = q + row * 3;
+    const float *sp = s + (b * m + idx[e]) * 3;
+    float dx = qp[0] - sp[0], dy = qp[1] - sp[1], dz = qp[2] - sp[2];
+    if (negate) {
+      dx = -dx; dy = -dy; dz = -dz;
+    }
+    out[e] = make_float4(dx, dy, dz, 0.f);
+  }
+}
+
 int g_search_quad = 1;      // nsdp_debug_set(12, v), NSDP_SEARCH_QUAD: 0 = the one-lane-per-query kernels (A/B)
 
 // out[b,l,j] = sum_t points[b,l,idx[b,j,t]] * weight[b,j,t]  (interpolate_gpu.cu:72-101), LDS-staged like the gathers:
@@ -1232,6 +1254,20 @@ int nsdp_gather_rows(const float *points, const int32_t *idx, int B, int N, int 
                        idx, total, N, C, S, out);
   }
   return nsdp::launch_status("gather_rows_kernel");
+}
+
+int nsdp_rel_coords4(const float *query, const float *source, const int32_t *idx, int B, int n, int m, int k, float sign,
+                     float *out4, void *stream) {
+  const long long total = static_cast<long long>(B) * n * k;
+  if (total <= 0) return 0;
+  NSDP_REQUIRE(query && source && idx && out4 && m > 0, "rel_coords4: bad argument");
+  NSDP_REQUIRE(sign == 1.f || sign == -1.f, "rel_coords4: sign must be +1 or -1");
+  NSDP_REQUIRE(reinterpret_cast<uintptr_t>(out4) % 16 == 0, "rel_coords4: output must be 16-byte aligned");
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kGatherRows, st, 0.0, 4.0 * (5.0 * total + 3.0 * B * (n + m)));
+  hipLaunchKernelGGL(rel_coords4_kernel, dim3(grid_for(total)), dim3(kThreads), 0, st, query, source, idx, total, n, m, k,
+                     sign < 0.f ? 1 : 0, reinterpret_cast<float4 *>(out4));
+  return nsdp::launch_status("rel_coords4_kernel");
 }
 
 int nsdp_scatter_add_rows(const float *grad_out, const int32_t *idx, int B, int N, int C, int S,

@@ -667,9 +667,15 @@ class _LinearFn(torch.autograd.Function):
             ctx.grad_sum = grad_sum
         K = x.shape[-1]
         N = w.shape[0]
+        if K != w.shape[1]:
+            # relative coordinates that arrive zero-padded to the K = 4 kernels' 16-byte rows (ops.relative_coords) against the
+            # layer's [N, 3] weight: nothing to pad here; every gradient shape below follows the WEIGHT
+            if not (K == 4 and w.shape[1] == 3) or ctx.needs_input_grad[0]:
+                raise ValueError(f"linear: input width {K} against a [{N}, {w.shape[1]}] weight")
         x2 = x.reshape(-1, K)
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
-        if K % 4:  # K = 3 (relative coordinates): zero-pad the reduction dimension (the weight pack pads itself)
+        K = w.shape[1]
+        if K % 4 and x2.shape[1] % 4:  # K = 3 (relative coordinates): zero-pad the reduction dimension (the weight pack pads itself)
             x2 = _pad_cols(x2)
         res2 = None
         if residual is not None:

@@ -203,10 +203,13 @@ class _LinearK4B16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, relu_out, w_param, b_param):
         ctx.w_param, ctx.b_param = w_param, b_param
-        K = x.shape[-1]
+        Kx = x.shape[-1]
+        K = w.shape[1]                         # the layer's own width: x may arrive zero-padded to 4 already (ops.relative_coords)
+        if Kx != K and not (Kx == 4 and K == 3 and not ctx.needs_input_grad[0]):
+            raise ValueError(f"linear_k4: input width {Kx} against a [{w.shape[0]}, {K}] weight")
         N = w.shape[0]
-        x2 = x.reshape(-1, K)
-        x2 = torch.nn.functional.pad(x2, (0, 4 - K)) if K < 4 else (x2 if x2.is_contiguous() else x2.contiguous())
+        x2 = x.reshape(-1, Kx)
+        x2 = torch.nn.functional.pad(x2, (0, 4 - Kx)) if Kx < 4 else (x2 if x2.is_contiguous() else x2.contiguous())
         w4 = None
         if w_param is not None and K < 4:      # the zero-padded [N,4] weight is a cache of the parameter, like the packs
             key = hip_linear._pack_key(w_param)

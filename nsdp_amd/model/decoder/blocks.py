@@ -48,7 +48,7 @@ class CrossTransformerBlock(nn.Module):
             s.wait_stream(after)
         with torch.cuda.stream(s):
             idx = ops.knn_indices(xyz_q, xyz, self.nneigh)
-            rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)
+            rel = ops.relative_coords(xyz_q, xyz, idx)
             # (the position-encoding GEMM is a persistent full-chip kernel: it leaves PREFETCH_RESERVE_CUS compute units to the
             # encoder's chain, like the weight-gradient kernels of the backward pass do)
             hip_linear.lib().nsdp_debug_set(9, PREFETCH_RESERVE_CUS)
@@ -75,7 +75,7 @@ class CrossTransformerBlock(nn.Module):
         kf = ops.linear(points, self.w_ks)                                   # [B,A,D] anchor tables
         vf = ops.linear(points, self.w_vs)
         if pos is None:
-            rel = xyz_q.unsqueeze(2) - ops.index_points(xyz, idx)            # xyz_q - a_j
+            rel = ops.relative_coords(xyz_q, xyz, idx)                       # xyz_q - a_j
         logit_g = ops.mlp2(q - k_g, self.fc_gamma)                           # [B,D]: identical for all queries
         res, _ = ops.vector_attention(rel, q.unsqueeze(1), kf, vf, idx, self.fc_delta,
                                       self.fc_gamma, a_g=logit_g, v_g=v_g, pos=pos)

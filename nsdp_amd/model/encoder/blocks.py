@@ -44,7 +44,7 @@ class TransformerBlock(nn.Module):
             idx = torch.arange(n, device=xyz.device, dtype=torch.int32).view(1, 1, n).expand(B, n, n).contiguous()
         else:
             idx = ops.knn_indices(xyz, xyz, self.k)
-        rel = xyz.unsqueeze(2) - ops.index_points(xyz, idx)          # xyz_i - xyz_j
+        rel = ops.relative_coords(xyz, xyz, idx)                     # xyz_i - xyz_j
         if self.pos_only:
             res, _ = ops.vector_attention(rel, None, None, None, idx, self.fc_delta, self.fc_gamma)
         else:
@@ -109,7 +109,7 @@ class TransformerSetAbstraction(nn.Module):
             fps_idx = ops.fps_indices(xyz, self.npoint)                   # [B, npoint] int32
             new_xyz = ops.index_points(xyz.detach(), fps_idx)             # detached centres (no_grad in ref)
             idx = ops.knn_indices(new_xyz, xyz, self.nneigh)              # [B, npoint, k]
-        rel = ops.index_points(xyz, idx) - new_xyz.unsqueeze(2)           # xyz_j - c  (sign opposite to PTB)
+        rel = ops.relative_coords(new_xyz, xyz, idx, sign=-1.0)           # xyz_j - c  (sign opposite to PTB)
 
         # the reference projects all N points with w_qs and then gathers the centres; gathering first
         # is the same values with N/npoint fewer rows through the GEMM

@@ -122,6 +122,21 @@ def index_points(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return _GatherRows.apply(points, idx)
 
 
+REL4 = os.environ.get("NSDP_REL4", "1") != "0"     # (A/B knob: 0 = gather + subtraction, the K = 3 layer pads its input itself)
+
+
+def relative_coords(query: torch.Tensor, source: torch.Tensor, idx: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """sign * (query_i - source[idx_ij]) for idx [B, n, k]: the input of a position-encoding MLP.  Where no coordinate needs a
+    gradient (always, except in FlowArbitrary's second network) this is ONE launch that writes the K = 4 layer's zero-padded
+    16-byte rows [B, n, k, 4] directly (pu.rel_coords4) -- the reference's index_points + subtraction, and the pad in front of
+    the layer, are four; `linear` takes the padded rows as they are (K = 4 against a [N, 3] weight)."""
+    if (REL4 and query.is_cuda and query.dtype is torch.float32 and source.dtype is torch.float32 and idx.dim() == 3
+            and not (torch.is_grad_enabled() and (query.requires_grad or source.requires_grad))):
+        return pu.rel_coords4(query.detach().contiguous(), source.detach().contiguous(), idx.contiguous(), sign)
+    d = query.unsqueeze(2) - index_points(source, idx)
+    return d if sign > 0 else -d
+
+
 # ---------------------------------------------------------------------------------------------
 # dense layers
 # ---------------------------------------------------------------------------------------------

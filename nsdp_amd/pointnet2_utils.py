@@ -64,6 +64,17 @@ def gather_rows(points: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rel_coords4(query: torch.Tensor, source: torch.Tensor, idx: torch.Tensor, sign: float = 1.0) -> torch.Tensor:
+    """(sign * (query_i - source[idx_ij]), 0) as [B, n, k, 4] (nsdp_rel_coords4): no gradient."""
+    B, n, _ = query.shape
+    m, k = source.shape[1], idx.shape[2]
+    out = torch.empty((B, n, k, 4), dtype=torch.float32, device=query.device)
+    with on_device(query):
+        check(lib().nsdp_rel_coords4(fptr(query, "query"), fptr(source, "source"), iptr(idx, "idx"), _c_int(B), _c_int(n),
+                                     _c_int(m), _c_int(k), ctypes.c_float(sign), fptr(out), stream_ptr()), "nsdp_rel_coords4")
+    return out
+
+
 # index_points' backward: gather-reduce over inverse index lists (csrc/segment.hip: deterministic, every row read once at
 # stream rate) instead of global fp32 atomics (1.0-1.25 TB/s) wherever the lists can be built -- they are cached on the index
 # tensor, so an index set that is reused (two gathers of one kNN set, several steps over fixed geometry) builds them once.
