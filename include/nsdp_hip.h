@@ -279,6 +279,27 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
                                  float *db, long long M, int N, int K, int accumulate, float *workspace,
                                  size_t workspace_bytes, void *stream);
 
+/* The same weight gradient in two halves, for callers that reduce the partial sums of MANY layers in one launch (the
+ * weight gradients of a train step sit on a side stream, where 98 tiny reduce launches per step wait for compute units behind
+ * the critical chain's kernels: 8.6 us each alone, 33 us in the step):
+ *   _partials_f32       runs the row kernel only; `workspace` then holds the per-workgroup partials and must stay untouched
+ *                       until the reduce; *desc_out describes the pending reduction (workspace, targets, partial count, tiles)
+ *   _reduce_batched     dW (+)= the fixed-order sum of the partials, db likewise, for `count` descriptors (host array, copied
+ *                       into the kernel arguments, 48 per launch).  The sums are those of nsdp_linear_wgrad_bf16x3_f32, bit for
+ *                       bit.  Two descriptors of one launch must not share a target (`accumulate` reads what is there). */
+typedef struct {
+  const float *ws;
+  float *dW, *db;      /* db may be NULL */
+  int S, nta, ktb;     /* partials, tile classes of the row kernel (filled by _partials_f32) */
+  int N, K;
+  int accumulate;
+  int reserved;
+} NsdpWgradReduceDesc;
+int nsdp_linear_wgrad_bf16x3_partials_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                                          float *db, long long M, int N, int K, int accumulate, float *workspace,
+                                          size_t workspace_bytes, NsdpWgradReduceDesc *desc_out, void *stream);
+int nsdp_wgrad_bf16x3_reduce_batched(const NsdpWgradReduceDesc *descs, int count, void *stream);
+
 /* bf16-storage variants of the attention glue (csrc/attention.hip, same kernels instantiated for a bf16 storage type):
  * q, kf, vf, pos, u, a, y, residual, a_g, v_g and the activation gradients du, dy, da, dpos, dpos_acc are bf16 tensors;
  * lse and the scatter / reduction outputs dq, dkf, dvf, da_g, dv_g are fp32.  Arithmetic is fp32 throughout. */

@@ -504,6 +504,58 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_kernel(const float *_
   }
 }
 
+// The same sums for up to kReduceBatch layers in ONE launch (descriptors by value in the kernel arguments, grid.y = layer,
+// grid.x covers the largest layer): element order, partial ranges and the combination are those of the kernel above, so a
+// gradient does not depend on which of the two reduced it.
+constexpr int kReduceBatch = 48;
+struct ReduceBatch {
+  NsdpWgradReduceDesc d[kReduceBatch];
+};
+__global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_batched_kernel(ReduceBatch b) {
+  __shared__ float part[8][32];
+  const NsdpWgradReduceDesc &e = b.d[blockIdx.y];
+  const int N = e.N, K = e.K, S = e.S, NTA = e.nta, KTB = e.ktb;
+  const long long nw = static_cast<long long>(N) * K;
+  const long long ne = nw + (e.db ? N : 0);
+  if (static_cast<long long>(blockIdx.x) * 32 >= ne) return;      // (uniform per workgroup)
+  const float *__restrict__ ws = e.ws;
+  const int el = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const long long el_g = static_cast<long long>(blockIdx.x) * 32 + el;
+  const size_t stride = static_cast<size_t>(NTA) * KTB * 256 + NTA * 16;
+  size_t idx = 0;
+  bool valid = true;
+  if (el_g < nw) {
+    const int n = static_cast<int>(el_g / K), kg = static_cast<int>(el_g % K);
+    const int kpart = kg / (KTB * 16), k = kg - kpart * KTB * 16;
+    const int nl = n & 15, kl = k & 15;
+    idx = static_cast<size_t>(kpart) * S * stride +
+          (static_cast<size_t>(n >> 4) * KTB + (k >> 4)) * 256 + (16 * (nl >> 2) + kl) * 4 + (nl & 3);
+  } else if (el_g < nw + N && e.db) {
+    idx = static_cast<size_t>(NTA) * KTB * 256 + (el_g - nw);
+  } else {
+    valid = false;
+  }
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (valid) {
+    const int per = (S + 7) / 8;
+    int s = q * per;
+    const int s_end = s + per < S ? s + per : S;
+    for (; s + 4 <= s_end; s += 4) {
+      s0 += ws[idx + (s + 0) * stride]; s1 += ws[idx + (s + 1) * stride];
+      s2 += ws[idx + (s + 2) * stride]; s3 += ws[idx + (s + 3) * stride];
+    }
+    for (; s < s_end; ++s) s0 += ws[idx + s * stride];
+  }
+  part[q][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && valid) {
+    const float t = ((part[0][el] + part[1][el]) + (part[2][el] + part[3][el])) +
+                    ((part[4][el] + part[5][el]) + (part[6][el] + part[7][el]));
+    if (el_g < nw) e.dW[el_g] = e.accumulate ? e.dW[el_g] + t : t;
+    else e.db[el_g - nw] = e.accumulate ? e.db[el_g - nw] + t : t;
+  }
+}
+
 int g_wg3_reserve = 0;
 
 struct X3Plan {
@@ -609,6 +661,52 @@ size_t nsdp_linear_wgrad_bf16x3_workspace_bytes(long long M, int N, int K) {
   return plan_x3(M, N, K).ws_floats * sizeof(float);
 }
 
+int nsdp_linear_wgrad_bf16x3_partials_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
+                                          float *db, long long M, int N, int K, int accumulate, float *workspace,
+                                          size_t workspace_bytes, NsdpWgradReduceDesc *desc_out, void *stream) {
+  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_supported(M, N, K),
+               "linear_wgrad_bf16x3_partials: shape M=%lld N=%d K=%d outside the kernel's range", M, N, K);
+  NSDP_REQUIRE(dY && X && dW && workspace && desc_out, "linear_wgrad_bf16x3_partials: null pointer");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K),
+               "linear_wgrad_bf16x3_partials: workspace too small");
+  const X3Plan pl = plan_x3(M, N, K);
+  WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr, pl.kparts};
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kWgradX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
+  if (pl.nta == 8 && pl.ktb == 8) launch_wg<8, 8>(p, pl.grid, st);
+  else if (pl.nta == 8) launch_wg<8, 13>(p, pl.grid, st);
+  else if (pl.nta == 16) launch_wg<16, 8>(p, pl.grid, st);
+  else if (pl.ktb == 8) launch_wg<13, 8>(p, pl.grid, st);
+  else launch_wg<13, 13>(p, pl.grid, st);
+  *desc_out = NsdpWgradReduceDesc{workspace, dW, db, pl.grid, pl.nta, pl.ktb, N, K, accumulate ? 1 : 0, 0};
+  return nsdp::launch_status("wgrad_bf16x3_kernel");
+}
+
+int nsdp_wgrad_bf16x3_reduce_batched(const NsdpWgradReduceDesc *descs, int count, void *stream) {
+  if (count <= 0) return 0;
+  NSDP_REQUIRE(descs, "wgrad_bf16x3_reduce_batched: null descriptor array");
+  hipStream_t st = nsdp::as_stream(stream);
+  for (int base = 0; base < count; base += kReduceBatch) {
+    ReduceBatch b;
+    const int n = count - base < kReduceBatch ? count - base : kReduceBatch;
+    long long blocks = 1;
+    for (int i = 0; i < n; ++i) {
+      const NsdpWgradReduceDesc &e = descs[base + i];
+      NSDP_REQUIRE(e.ws && e.dW && e.S > 0 && e.N > 0 && e.K > 0 && e.nta > 0 && e.ktb > 0,
+                   "wgrad_bf16x3_reduce_batched: bad descriptor %d", base + i);
+      b.d[i] = e;
+      const long long ne = static_cast<long long>(e.N) * e.K + (e.db ? e.N : 0);
+      blocks = (ne + 31) / 32 > blocks ? (ne + 31) / 32 : blocks;
+    }
+    for (int i = n; i < kReduceBatch; ++i) b.d[i] = b.d[0];      // never indexed (grid.y = n)
+    NSDP_TRACE("wgrad_bf16x3_reduce_batched x%d", n);
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_batched_kernel, dim3(static_cast<unsigned>(blocks), n), dim3(256), 0, st, b);
+    const int rc = nsdp::launch_status("wgrad_bf16x3_reduce_batched_kernel");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW,
                                  float *db, long long M, int N, int K, int accumulate, float *workspace,
                                  size_t workspace_bytes, void *stream) {
@@ -631,6 +729,10 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
     if (rc) return rc;
   }
   const long long ne = static_cast<long long>(N) * K + N;
+  // (ablation, timing only, wrong results: NSDP_WG3_SKIP_REDUCE=1 drops the reduce launch -- the ceiling of what folding or
+  // batching the 98 reduce launches of a step could buy)
+  static const bool skip_reduce = getenv("NSDP_WG3_SKIP_REDUCE") && atoi(getenv("NSDP_WG3_SKIP_REDUCE")) != 0;
+  if (skip_reduce) return 0;
   hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
                      workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
   return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");

@@ -159,6 +159,37 @@ def _wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     return dw, db
 
 
+class _ReduceDesc(ctypes.Structure):      # NsdpWgradReduceDesc (include/nsdp_hip.h)
+    _fields_ = [("ws", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("S", ctypes.c_int),
+                ("nta", ctypes.c_int), ("ktb", ctypes.c_int), ("N", ctypes.c_int), ("K", ctypes.c_int),
+                ("accumulate", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+# The partial sums of the side stream's bf16x3 weight gradients are reduced in batches: up to this many layers per reduce
+# launch (NSDP_WGRAD_BATCH_REDUCE; 0 = one reduce launch behind every layer's row kernel).  The 98 tiny reduce launches of a
+# B = 32 step take 8.6 us each alone and 33 us in the step, where they wait for compute units behind the critical chain;
+# dropping them altogether (ablation NSDP_WG3_SKIP_REDUCE=1, wrong gradients) is worth 0.65 ms at B = 32 and 0.8 ms at B = 8.
+# Not one batch per step: the partials of a batch stay in HBM until its reduce (~20 MB per layer), and the LAST batch is
+# reduced at the very tail of the backward pass, where nothing runs beside it.
+BATCH_REDUCE = int(os.environ.get("NSDP_WGRAD_BATCH_REDUCE", "16"))
+_cur_reduce = None      # the pending batch of the backward pass whose side-stream section is executing (see _wgrad_deferred)
+
+
+def _new_reduce_batch():
+    return {"descs": [], "keep": [], "targets": set()}
+
+
+def _flush_reduce(batch):
+    """Launch the batched reduce of everything pending (current stream = the one the row kernels ran on)."""
+    n = len(batch["descs"])
+    if n:
+        arr = (_ReduceDesc * n)(*batch["descs"])
+        check(lib().nsdp_wgrad_bf16x3_reduce_batched(arr, _ci(n), stream_ptr()), "nsdp_wgrad_bf16x3_reduce_batched")
+    batch["descs"].clear()
+    batch["keep"].clear()
+    batch["targets"].clear()
+
+
 def _wgrad_x3(dy2, x2, mask, relu_x, want_db, out=None):
     """_wgrad on the bf16 matrix pipe (3-way split of both operands, nsdp_linear_wgrad_bf16x3_f32)."""
     M, N = dy2.shape
@@ -168,6 +199,26 @@ def _wgrad_x3(dy2, x2, mask, relu_x, want_db, out=None):
     nbytes = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
     dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
+    batch = _cur_reduce
+    if batch is not None and BATCH_REDUCE > 0:
+        # row kernel now, reduction with the batch: dw / db hold NOTHING until _flush_reduce ran (the end-of-backward callback
+        # flushes before it publishes; _wgrad_deferred flushes before it touches a buffer itself)
+        ptrs = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+        if ptrs & batch["targets"]:          # a parameter used twice in the graph: its first reduction must land first
+            with on_device(dy2):
+                _flush_reduce(batch)
+        desc = _ReduceDesc()
+        with on_device(dy2):
+            check(L.nsdp_linear_wgrad_bf16x3_partials_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
+                                                          optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
+                                                          ctypes.c_size_t(nbytes), ctypes.byref(desc), stream_ptr()),
+                  "nsdp_linear_wgrad_bf16x3_partials_f32")
+            batch["descs"].append(desc)
+            batch["keep"].append((ws, dw, db))
+            batch["targets"] |= ptrs
+            if len(batch["descs"]) >= BATCH_REDUCE:
+                _flush_reduce(batch)
+        return dw, db
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_bf16x3_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
                                              optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
@@ -203,6 +254,7 @@ SIDE_RESERVE_CUS = int(os.environ.get("NSDP_WGRAD_RESERVE_CUS", "48"))
 _overlap_now = {}                # (device index, graph task) -> decision for that backward pass
 _side = {}
 _pending = {}          # (device index, graph task) -> {id(param): [param, grad tensor living on the side stream]}
+_reduce_batches = {}   # (device index, graph task) -> the pass's pending batch of weight-gradient reductions (_new_reduce_batch)
 # Per-backward state is keyed by the autograd graph task that created it: a pass that died with an exception never runs
 # its end-of-backward callback, and its leftovers must not be published by (or suppress the callback of) the next pass.
 
@@ -230,6 +282,10 @@ def _publish(device, key):
     """End-of-backward callback: join the streams, then hand the pending gradients to the parameters."""
     _overlap_now.pop(key, None)
     todo = _pending.pop(key, {})
+    batch = _reduce_batches.pop(key, None)
+    if batch is not None and batch["descs"]:
+        with torch.cuda.device(device), torch.cuda.stream(_side_stream(device)):
+            _flush_reduce(batch)
     if not todo:
         return
     main = torch.cuda.current_stream(device)
@@ -358,12 +414,23 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
         # workgroups (one 512-register wave per SIMD) leave SIDE_RESERVE_CUS compute units to it
         L = lib()
         L.nsdp_debug_set(_ci(9), _ci(SIDE_RESERVE_CUS))
+        global _cur_reduce
+        batch = _reduce_batches.get(key)
+        if batch is None:
+            batch = _reduce_batches[key] = _new_reduce_batch()
+        _cur_reduce = batch if fn is None else None     # (other storage precisions / fused routines reduce for themselves)
+        if out is not None and batch["targets"] and (
+                out[0].data_ptr() in batch["targets"] or (out[1] is not None and out[1].data_ptr() in batch["targets"])):
+            # a parameter used twice in the graph (fc_gamma: the neighbours' logits and the global token's) whose first
+            # gradient is still a pending reduction: it must land before anything accumulates into the same buffer
+            _flush_reduce(batch)
         try:
             if fn is None:
                 dw, db = _wgrad_sliced(dy2, x2, mask, relu_x, b_param is not None, k_orig, out)
             else:
                 dw, db = fn(dy2, x2, mask, relu_x, b_param is not None, out)
         finally:
+            _cur_reduce = None
             L.nsdp_debug_set(_ci(9), _ci(0))
         if out is None or dw is not out[0]:
             for param, g in ((w_param, dw), (b_param, db)):
@@ -374,6 +441,7 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
                 if ent is None:
                     slot[id(param)] = [param, g]
                 else:
+                    _flush_reduce(batch)      # (g may still be a pending reduction)
                     ent[1].add_(g)     # (shapes the kernels cannot accumulate in place: the padded K = 3 layers)
     for t in (dy2, x2, mask):
         if t is not None:
