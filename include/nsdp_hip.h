@@ -38,6 +38,8 @@ const char *nsdp_last_error(void);
  * 9 is a HOST HINT, not an ablation: the number of compute units nsdp_linear_wgrad_bf16x3_f32 leaves free (its persistent
  * one-wave-per-SIMD workgroups otherwise hold every CU until the kernel ends); the host sets it around weight-gradient
  * launches that run on a side stream next to the critical chain and resets it to 0 (the workspace query sees the same value).
+ * The hint is THREAD-LOCAL: it applies to launches made by the host thread that set it (set / query / launch / reset happen on
+ * one thread; another device's backward thread cannot clobber it).
  * 10: 0 = immediate-insertion kNN kernel; 11: 0 = three-launch BatchNorm forms (A/B against the one-launch slab kernels), 2 = slab kernels up to 16384 rows;
  * 12: 0 = one-lane-per-query ball_query / three_nn kernels (A/B against the four-lane plane-tile scans). */
 void nsdp_debug_set(int key, int value);

@@ -15,6 +15,10 @@
 //   v  = v * beta2 + ((1 - beta2) * g') * g'
 //   p  = p + ((-lr / (1 - beta1^t)) * m) / (sqrt(v) / sqrt(1 - beta2^t) + eps)
 // with the scalars formed in double and rounded to fp32 where torch hands them to an fp32 tensor op.
+// WHICH torch: the CPU, non-capturable, single-tensor path -- torch.optim.Adam(foreach=False) on CPU tensors -- is the sequence
+// restated here and what tests/test_adam_gpu.py compares with (moments to a few ulp of the largest term, parameters to one).
+// torch's CUDA / ROCm kernels (foreach, fused, capturable: bias corrections in fp32, addcdiv as a + alpha * (m / denom)) may
+// differ from it -- and hence from this kernel -- in the last place: nobody should rely on bit-equality with a GPU torch run.
 // The step counter t is one fp32 scalar per tensor in device memory (torch's `capturable` layout: state["step"]); every
 // chunk reads it, the LAST chunk of a tensor to finish stores t + 1 (a per-tensor arrival counter that the same workgroup
 // resets) -- no second launch, and the value never depends on the order in which the chunks ran.

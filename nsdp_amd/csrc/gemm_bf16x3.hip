@@ -42,7 +42,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 int g_x3_dbg = 0;
-int g_x3_side_reserve = 0;      // compute units a K = 4 tail launch leaves free (host hint 9: it runs on the weight-gradient side stream)
+thread_local int g_x3_side_reserve = 0;      // (per host thread) compute units a side-stream launch leaves free (host hint 9: it runs on the weight-gradient side stream)
 
 #ifdef NSDP_X3_TIMING
 // phase timers (s_memtime ticks summed over waves): 0 steps, 1 bottom wait, 2 barrier, 3 epilogue, 4 tile prologue, 5 total

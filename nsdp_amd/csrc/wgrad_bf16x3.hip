@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_reduce_batched_kernel(Reduce
   }
 }
 
-int g_wg3_reserve = 0;
+thread_local int g_wg3_reserve = 0;      // host hint 9: per host thread (autograd runs one backward thread per device)
 
 struct X3Plan {
   int nta, ktb, kparts, grid;

@@ -65,10 +65,10 @@ def _bury():
     if not _graveyard or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
         return
     while _graveyard:
-        handle, graph = _graveyard.pop()
+        handle, graph, pinned = _graveyard.pop()
         if handle:
             lib().nsdp_graph_exec_destroy(handle)
-        del graph
+        del graph, pinned      # (the graph first: its copy nodes read the pinned buffers)
 
 
 class GraphedStep:
@@ -112,13 +112,22 @@ class GraphedStep:
         # making HIP calls while this thread captures
         gc_was_on = gc.isenabled()
         gc.disable()      # (no collection, hence no finalizer of some unrelated object, between the capture's begin and end)
+        from . import hip_adam
+        self._pinned = []      # pinned table buffers the captured optimizer step copies from: they live as long as this graph
+        hip_adam._capture_hosts = self._pinned
         try:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self.fn()
         finally:
+            hip_adam._capture_hosts = None
             if gc_was_on:
                 gc.enable()
         torch.cuda.synchronize()
+        # A pack first created INSIDE the capture is cached as valid for the current epoch although its pack kernel was only
+        # recorded, never executed: an eager forward between capture() and the first replay would read uninitialised memory.
+        # Stale again after the capture, whatever the step did (a captured optimizer step bumps the epoch itself).
+        if self.weights_change:
+            hip_linear.invalidate_weight_packs()
         _bury()
         raw = graph.raw_cuda_graph()
         L = lib()
@@ -163,9 +172,10 @@ class GraphedStep:
         # the middle of a capture too (a GraphedTrainOnBatch and the lambda of its step form a cycle): the process aborted
         # there.  While a capture is in progress the remains are parked and freed at the next safe point.
         if self._handle or self._graph is not None:
-            _graveyard.append((self._handle, self._graph))
+            _graveyard.append((self._handle, self._graph, getattr(self, "_pinned", None)))
             self._handle = ctypes.c_void_p(0)
             self._graph = None
+            self._pinned = None
         _bury()
 
     def __del__(self):

@@ -29,6 +29,12 @@ _DESC_DTYPE = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), (
 assert _DESC_DTYPE.itemsize == ctypes.sizeof(_AdamDesc)
 
 
+# While nsdp_amd.graph_step.GraphedStep captures a step this is ITS list: a pinned table buffer that a captured optimizer step
+# copies from belongs to that graph and is released when the graph is closed (outside a GraphedStep capture -- plain
+# torch.cuda.graph -- the buffers stay with the optimizer for its lifetime, HipAdam._graph_hosts).
+_capture_hosts = None
+
+
 class HipAdam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, maximize=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize,
@@ -114,7 +120,9 @@ class HipAdam(torch.optim.Adam):
             if host is None or host.numel() < blob.size:
                 host = torch.empty(blob.size, dtype=torch.uint8).pin_memory()      # (fails loudly if the runtime refuses)
             host[:blob.size] = torch.from_numpy(blob)
-            self._graph_hosts.append(host)
+            # Invariant the captured graph relies on: EVERY replay re-uploads the table from this buffer (a copy node) and
+            # re-zeroes `done` (a memset node), so an eager step that later overwrites self._plans[gi] cannot disturb it.
+            (_capture_hosts if _capture_hosts is not None else self._graph_hosts).append(host)
             table = torch.empty(blob.size, dtype=torch.uint8, device=dev)
             table.copy_(host[:blob.size], non_blocking=True)
         else:
