@@ -341,6 +341,21 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
                            long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                            void *stream);
 
+/* nsdp_linear_wgrad_bf16 in two halves, like nsdp_linear_wgrad_bf16x3_partials_f32 / nsdp_wgrad_bf16x3_reduce_batched: the row
+ * kernel now (an all-zero *desc_out -- ws == NULL -- means the call had nothing to do), the fixed-order sums of many layers'
+ * partials in one launch later (bit-identical to the one-call form; two descriptors of a launch must not share a target). */
+typedef struct {
+  const float *ws;     /* [S][N * K + N] partials */
+  float *dW, *db;      /* db may be NULL */
+  int S, N, K;
+  int accumulate;
+  int reserved;
+} NsdpWgradB16ReduceDesc;
+int nsdp_linear_wgrad_bf16_partials(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
+                                    long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                    NsdpWgradB16ReduceDesc *desc_out, void *stream);
+int nsdp_wgrad_bf16_reduce_batched(const NsdpWgradB16ReduceDesc *descs, int count, void *stream);
+
 /* bf16-storage variants of the BatchNorm kernels (x, addend, y, dy, dx bf16; statistics and affine parameters fp32). */
 int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,
                        float *running_mean, float *running_var, float *mean, float *invstd, float *workspace,

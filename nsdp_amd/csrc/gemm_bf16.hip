@@ -627,6 +627,32 @@ __global__ __launch_bounds__(256) void reduce_b16_kernel(const float *__restrict
   else if (db) db[e - nw] = accumulate ? db[e - nw] + s : s;
 }
 
+// the same sums for up to kReduceBatchB16 layers in one launch (descriptors by value, grid.y = layer): see
+// nsdp_wgrad_bf16_reduce_batched -- the element order and the eight chains are those of reduce_b16_kernel (bit-identical)
+constexpr int kReduceBatchB16 = 48;
+struct ReduceBatchB16 {
+  NsdpWgradB16ReduceDesc d[kReduceBatchB16];
+};
+__global__ __launch_bounds__(256) void reduce_b16_batched_kernel(ReduceBatchB16 b) {
+  const NsdpWgradB16ReduceDesc &d = b.d[blockIdx.y];
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  const long long nw = static_cast<long long>(d.N) * d.K, nb = d.db ? d.N : 0;
+  if (e >= nw + nb) return;
+  const float *__restrict__ ws = d.ws;
+  const long long stride = nw + d.N;
+  const int S = d.S;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 8 <= S; c += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] += ws[(c + u) * stride + e];
+  }
+  for (; c < S; ++c) acc[0] += ws[c * stride + e];
+  const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  if (e < nw) d.dW[e] = d.accumulate ? d.dW[e] + s : s;
+  else d.db[e - nw] = d.accumulate ? d.db[e - nw] + s : s;
+}
+
 // out[b][e] = sum over the S partials of shape b (one-hot scatter tables)
 __global__ __launch_bounds__(256) void reduce_tables_kernel(const float *__restrict__ ws, int S, long long stride, long long nw,
                                                             float *__restrict__ out) {
@@ -1069,8 +1095,49 @@ size_t nsdp_linear_wgrad_bf16_workspace_bytes(long long M, int N, int K) {
   return (a > b ? a : b) * sizeof(float);
 }
 
+static int wgrad_bf16_impl(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db, long long M, int N,
+                           int K, int accumulate, float *workspace, size_t workspace_bytes, NsdpWgradB16ReduceDesc *desc_out,
+                           void *stream);
+
 int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
                            long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                           void *stream) {
+  return wgrad_bf16_impl(dY, X, mask, relu_x, dW, db, M, N, K, accumulate, workspace, workspace_bytes, nullptr, stream);
+}
+
+int nsdp_linear_wgrad_bf16_partials(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
+                                    long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                    NsdpWgradB16ReduceDesc *desc_out, void *stream) {
+  NSDP_REQUIRE(desc_out, "linear_wgrad_bf16_partials: null descriptor");
+  desc_out->ws = nullptr;
+  return wgrad_bf16_impl(dY, X, mask, relu_x, dW, db, M, N, K, accumulate, workspace, workspace_bytes, desc_out, stream);
+}
+
+int nsdp_wgrad_bf16_reduce_batched(const NsdpWgradB16ReduceDesc *descs, int count, void *stream) {
+  if (count <= 0) return 0;
+  NSDP_REQUIRE(descs, "wgrad_bf16_reduce_batched: null descriptor array");
+  hipStream_t st = nsdp::as_stream(stream);
+  for (int base = 0; base < count; base += kReduceBatchB16) {
+    ReduceBatchB16 b;
+    const int n = count - base < kReduceBatchB16 ? count - base : kReduceBatchB16;
+    long long blocks = 1;
+    for (int i = 0; i < n; ++i) {
+      const NsdpWgradB16ReduceDesc &e = descs[base + i];
+      NSDP_REQUIRE(e.ws && e.dW && e.S > 0 && e.N > 0 && e.K > 0, "wgrad_bf16_reduce_batched: bad descriptor %d", base + i);
+      b.d[i] = e;
+      const long long ne = static_cast<long long>(e.N) * e.K + e.N;
+      blocks = (ne + 255) / 256 > blocks ? (ne + 255) / 256 : blocks;
+    }
+    for (int i = n; i < kReduceBatchB16; ++i) b.d[i] = b.d[0];
+    hipLaunchKernelGGL(reduce_b16_batched_kernel, dim3(static_cast<unsigned>(blocks), n), dim3(256), 0, st, b);
+    const int rc = nsdp::launch_status("reduce_b16_batched_kernel");
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static int wgrad_bf16_impl(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db, long long M, int N,
+                           int K, int accumulate, float *workspace, size_t workspace_bytes, NsdpWgradB16ReduceDesc *desc_out,
                            void *stream) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   NSDP_REQUIRE(dY && X && dW && workspace, "linear_wgrad_bf16: null pointer");
@@ -1094,6 +1161,10 @@ int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int 
   } else if (tn <= 2 && tk <= 2) rc = launch_wg16<2, 2, 1>(p, pl.grid, st);
   else rc = launch_wg16<4, 4, 1>(p, pl.grid, st);
   if (rc) return rc;
+  if (desc_out) {      // the caller reduces this layer's partials with a batch (nsdp_wgrad_bf16_reduce_batched)
+    *desc_out = NsdpWgradB16ReduceDesc{workspace, dW, db, pl.grid, N, K, accumulate ? 1 : 0, 0};
+    return 0;
+  }
   const long long nw = static_cast<long long>(N) * K, nb = db ? N : 0;
   hipLaunchKernelGGL(reduce_b16_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0, st, workspace,
                      pl.grid, nw + N, nw, dW, static_cast<long long>(nb), db, accumulate);

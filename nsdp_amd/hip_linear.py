@@ -175,8 +175,13 @@ BATCH_REDUCE = int(os.environ.get("NSDP_WGRAD_BATCH_REDUCE", "16"))
 _cur_reduce = None      # the pending batch of the backward pass whose side-stream section is executing (see _wgrad_deferred)
 
 
+class _ReduceDescB16(ctypes.Structure):      # NsdpWgradB16ReduceDesc (bf16-storage weight gradients, hip_linear_bf16.wgrad)
+    _fields_ = [("ws", ctypes.c_void_p), ("dW", ctypes.c_void_p), ("db", ctypes.c_void_p), ("S", ctypes.c_int),
+                ("N", ctypes.c_int), ("K", ctypes.c_int), ("accumulate", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 def _new_reduce_batch():
-    return {"descs": [], "keep": [], "targets": set()}
+    return {"descs": [], "descs_b16": [], "keep": [], "targets": set()}
 
 
 def _flush_reduce(batch):
@@ -185,7 +190,12 @@ def _flush_reduce(batch):
     if n:
         arr = (_ReduceDesc * n)(*batch["descs"])
         check(lib().nsdp_wgrad_bf16x3_reduce_batched(arr, _ci(n), stream_ptr()), "nsdp_wgrad_bf16x3_reduce_batched")
+    n = len(batch["descs_b16"])
+    if n:
+        arr = (_ReduceDescB16 * n)(*batch["descs_b16"])
+        check(lib().nsdp_wgrad_bf16_reduce_batched(arr, _ci(n), stream_ptr()), "nsdp_wgrad_bf16_reduce_batched")
     batch["descs"].clear()
+    batch["descs_b16"].clear()
     batch["keep"].clear()
     batch["targets"].clear()
 
@@ -216,7 +226,7 @@ def _wgrad_x3(dy2, x2, mask, relu_x, want_db, out=None):
             batch["descs"].append(desc)
             batch["keep"].append((ws, dw, db))
             batch["targets"] |= ptrs
-            if len(batch["descs"]) >= BATCH_REDUCE:
+            if len(batch["descs"]) + len(batch["descs_b16"]) >= BATCH_REDUCE:
                 _flush_reduce(batch)
         return dw, db
     with on_device(dy2):
@@ -283,7 +293,7 @@ def _publish(device, key):
     _overlap_now.pop(key, None)
     todo = _pending.pop(key, {})
     batch = _reduce_batches.pop(key, None)
-    if batch is not None and batch["descs"]:
+    if batch is not None and (batch["descs"] or batch["descs_b16"]):
         with torch.cuda.device(device), torch.cuda.stream(_side_stream(device)):
             _flush_reduce(batch)
     if not todo:
@@ -418,7 +428,9 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
         batch = _reduce_batches.get(key)
         if batch is None:
             batch = _reduce_batches[key] = _new_reduce_batch()
-        _cur_reduce = batch if fn is None else None     # (other storage precisions / fused routines reduce for themselves)
+        # (fused routines -- the K = 4 tail, the K = 4 remask kernel -- reduce for themselves; a routine that takes part in the
+        # batch says so: hip_linear_bf16's weight gradient)
+        _cur_reduce = batch if (fn is None or getattr(fn, "batched_reduce", False)) else None
         if out is not None and batch["targets"] and (
                 out[0].data_ptr() in batch["targets"] or (out[1] is not None and out[1].data_ptr() in batch["targets"])):
             # a parameter used twice in the graph (fc_gamma: the neighbours' logits and the global token's) whose first

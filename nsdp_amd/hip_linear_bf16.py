@@ -69,6 +69,25 @@ def wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     nbytes = int(L.nsdp_linear_wgrad_bf16_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
     dw, db, acc = hip_linear.wgrad_out(out, N, K, want_db, dy2.device)
+    batch = hip_linear._cur_reduce
+    if batch is not None and hip_linear.BATCH_REDUCE > 0:
+        # the row kernel now, the reduction with the pass's batch (see hip_linear._wgrad_x3: same protocol)
+        ptrs = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+        with on_device(dy2):
+            if ptrs & batch["targets"]:
+                hip_linear._flush_reduce(batch)
+            desc = hip_linear._ReduceDescB16()
+            check(L.nsdp_linear_wgrad_bf16_partials(hptr(dy2, "dy"), hptr(x2, "x"), opthptr(mask, "mask"), _ci(int(relu_x)),
+                                                    fptr(dw), optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
+                                                    ctypes.c_size_t(nbytes), ctypes.byref(desc), stream_ptr()),
+                  "nsdp_linear_wgrad_bf16_partials")
+            if desc.ws:
+                batch["descs_b16"].append(desc)
+                batch["keep"].append((ws, dw, db, dy2, x2, mask))
+                batch["targets"] |= ptrs
+                if len(batch["descs"]) + len(batch["descs_b16"]) >= hip_linear.BATCH_REDUCE:
+                    hip_linear._flush_reduce(batch)
+        return dw, db
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_bf16(hptr(dy2, "dy"), hptr(x2, "x"), opthptr(mask, "mask"), _ci(int(relu_x)), fptr(dw),
                                        optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws), ctypes.c_size_t(nbytes),
@@ -86,8 +105,15 @@ def _wgrad_any(dy2, x2, y_mask, relu_x, want_db, out=None):
     kp = (-K) % 4
     if kp:
         xf = torch.nn.functional.pad(xf, (0, kp))
-    dw, db = hip_linear._wgrad(dyf.contiguous(), xf.contiguous(), mk, relu_x, want_db, None if kp else out)
+    prev, hip_linear._cur_reduce = hip_linear._cur_reduce, None      # (the slice below reads dw at once: no pending reduction)
+    try:
+        dw, db = hip_linear._wgrad(dyf.contiguous(), xf.contiguous(), mk, relu_x, want_db, None if kp else out)
+    finally:
+        hip_linear._cur_reduce = prev
     return (dw[:, :K].contiguous() if kp else dw), db
+
+
+_wgrad_any.batched_reduce = True      # (hip_linear._wgrad_deferred: this routine hands its reduction to the pass's batch)
 
 
 class _LinearB16Fn(torch.autograd.Function):
