@@ -149,8 +149,9 @@ class GraphedStep:
         # parameters afterwards.  Declare them stale, so that the next EAGER forward (validate_on_batch, an odd-shape batch
         # of GraphedTrainOnBatch) repacks; the next replay repacks anyway.  One integer increment.
         if self.weights_change:
-            from . import hip_linear
+            from . import hip_batchnorm, hip_linear
             hip_linear.invalidate_weight_packs()
+            hip_batchnorm.invalidate_inference_constants()      # (the replayed norms rewrote their running statistics)
         return self._out
 
     def timed_replay(self, name_substr: str):
@@ -162,8 +163,9 @@ class GraphedStep:
         check(lib().nsdp_graph_exec_launch_timed(self._handle, stream_ptr(), name_substr.encode(), ctypes.byref(n),
                                                  ctypes.byref(ms)), "nsdp_graph_exec_launch_timed")
         if self.weights_change:
-            from . import hip_linear
+            from . import hip_batchnorm, hip_linear
             hip_linear.invalidate_weight_packs()
+            hip_batchnorm.invalidate_inference_constants()
         return int(n.value), float(ms.value)
 
     def close(self):

@@ -11,6 +11,14 @@ import torch
 from ._lib import check, fptr, lib, on_device, optptr, stream_ptr
 
 _RUNNING_UPDATES = 1
+_stats_epoch = 0        # advanced by every training-mode norm: keys the cached inference constants (batch_norm)
+
+
+def invalidate_inference_constants():
+    """Declare every cached 1 / sqrt(running_var + eps) stale.  Training-mode norms do it themselves; a REPLAY of a captured
+    train step runs them without any Python (nsdp_amd.graph_step calls this after every replay, next to the weight packs)."""
+    global _stats_epoch
+    _stats_epoch += 1
 
 
 @contextlib.contextmanager
@@ -54,7 +62,8 @@ def _ws(C, device):
 
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt=None, updates=1):
+    def forward(ctx, x, addend, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt=None, updates=1,
+                infer=None):
         shape = x.shape
         C = shape[-1]
         x2 = x.reshape(-1, C)
@@ -81,7 +90,7 @@ class _BatchNormFn(torch.autograd.Function):
                       "nsdp_bn_train_fwd")
             else:
                 mean = running_mean
-                invstd = torch.rsqrt(running_var + eps)
+                invstd = infer if infer is not None else torch.rsqrt(running_var + eps)
                 check(_fn("nsdp_bn_apply", dt)(_p(x2, dt), _p(a2, dt), fptr(mean), fptr(invstd), fptr(gamma, "weight"),
                                                fptr(beta, "bias"), _ll(R), _ci(C), _ci(int(relu)), _p(y, dt), stream_ptr()),
                       "nsdp_bn_apply")
@@ -107,7 +116,7 @@ class _BatchNormFn(torch.autograd.Function):
                                               fptr(gamma), _ll(R), _ci(C), _ci(int(ctx.training)), _p(dx, dt), fptr(dgamma),
                                               fptr(dbeta), fptr(_ws(C, dev)), stream_ptr()), "nsdp_bn_backward")
         dx = dx.reshape(ctx.shape)
-        return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, (dx if ctx.has_addend else None), dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
@@ -130,5 +139,23 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
         momentum = 1.0 / max(1.0, float(bn.num_batches_tracked)) if (bn.training and bn.track_running_stats) else 0.0
     else:
         momentum = float(bn.momentum)
+    infer = None
+    if training:
+        global _stats_epoch
+        _stats_epoch += 1          # (the kernels rewrite the running statistics behind the tensors' version counters)
+    elif not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+        # inference: 1 / sqrt(running_var + eps) is a constant of the module until its buffers change -- computed once (by the
+        # same two torch kernels as ever: FlowArbitrary's second network turns a one-ulp difference in the first one's norms into
+        # flipped neighbours), cached on the module, instead of an add + rsqrt launch in front of each of the 35 norms of every
+        # forward.  (Inside a capture the cache is only READ: a tensor created there lives in the graph's pool.)
+        key = (rv.data_ptr(), rv._version, _stats_epoch, float(bn.eps))
+        hit = bn.__dict__.get("_nsdp_invstd")
+        if hit is None or hit[0] != key:
+            hit = bn.__dict__["_nsdp_invstd"] = (key, torch.rsqrt(rv + float(bn.eps)))
+        infer = hit[1]
+    elif not torch.is_grad_enabled():
+        hit = bn.__dict__.get("_nsdp_invstd")
+        if hit is not None and hit[0] == (rv.data_ptr(), rv._version, _stats_epoch, float(bn.eps)):
+            infer = hit[1]
     return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, momentum, float(bn.eps), bool(relu), nbt,
-                              updates)
+                              updates, infer)

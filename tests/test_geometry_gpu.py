@@ -266,6 +266,22 @@ def test_three_nn_four_lane_scan_matches_oracle(kind, B, n, m):
         assert "three_nn_quad" in names, names
 
 
+@pytest.mark.parametrize("B,n,m,k,sign", [(2, 300, 1000, 16, 1.0), (3, 100, 100, 100, 1.0), (2, 64, 500, 7, -1.0), (1, 1, 5, 3, -1.0)])
+def test_rel_coords4_equals_gather_and_subtract(B, n, m, k, sign):
+    """nsdp_rel_coords4 against the reference's index_points + broadcast subtraction (model/encoder/blocks.py:104-106,
+    :285-286, model/decoder/blocks.py:72-78), bit for bit, with the fourth column zero."""
+    from nsdp_amd import pointnet2_utils as pu
+    q, s_ = _cloud(61 + n, B, n), _cloud(62 + m, B, m)
+    idx = (synth.uniform01(63, "i", (B, n, k)) * m).astype(np.int32)
+    got = pu.rel_coords4(_dev(q), _dev(s_), _dev(idx), sign).cpu().numpy()
+    gathered = np.take_along_axis(s_[:, None, :, :].repeat(n, 1), idx[..., None].astype(np.int64), axis=2)
+    want = q[:, :, None, :] - gathered
+    if sign < 0:
+        want = gathered - q[:, :, None, :]
+    np.testing.assert_array_equal(got[..., :3], want)
+    assert not got[..., 3].any()
+
+
 def test_three_nn_and_interpolate_match_oracle():
     from nsdp_amd import pointnet2_utils as pu
     unknown, known = _cloud(31, 2, 700), _cloud(32, 2, 1300)

@@ -220,3 +220,30 @@ def test_a_step_closed_while_another_one_is_captured_is_freed_afterwards():
     torch.cuda.synchronize()
     assert float(y[0]) == 2.0
     new.close()
+
+
+def test_timed_replay_measures_a_kernel_class_and_leaves_the_step_intact():
+    """GraphedStep.timed_replay (bench.py's roofline.frac_replayed): a replay with event pairs around the kernels of one name --
+    it counts the launches of that class, returns a positive duration, and is a replay like any other: the sequence
+    replay, timed replay, replay equals three eager steps bit for bit."""
+    from helpers import nondeterministic_knobs
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = to_dev(synth.make_batch(93, 2, 256, 128), DEV)
+    model_e, opt_e, step_e = _make(cfg, 93, data)
+    capturable_adam(opt_e)
+    eager = [float(step_e()) for _ in range(4)]
+    model_g, opt_g, step_g = _make(cfg, 93, data)
+    capturable_adam(opt_g)
+    first = float(step_g())                      # (creates the optimizer state eagerly, as GraphedTrainOnBatch does)
+    gs = GraphedStep(step_g).capture(warmup=0)
+    got = [first, float(gs())]
+    n, ms = gs.timed_replay("linear_nt_kernel")
+    got.append(float(gs._out))
+    got.append(float(gs()))
+    torch.cuda.synchronize()
+    assert n > 20 and ms > 0.0, (n, ms)
+    assert gs.timed_replay("no_such_kernel_name")[0] == 0
+    if not nondeterministic_knobs():
+        assert got == eager, (got, eager)
+    gs.close()

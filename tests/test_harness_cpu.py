@@ -143,3 +143,24 @@ def test_main_passes_all_three_weight_files_to_build_model(tmp_path, monkeypatch
     except SystemExit:
         pass
     assert seen["args"] == (None, "F", "B")
+
+
+def test_loader_side_sharding_equals_every_world_th_batch():
+    """DataParallel.shard: a loader's own shard(rank, world) (SyntheticLoader) and the lazy every-world-th fallback over a plain
+    iterable hand every rank the same batches, drop the trailing partial group, and the fallback holds one batch at a time."""
+    import types
+    from nsdp_amd.parallel import DataParallel
+    loader = train.SyntheticLoader(3, 7, 1, n_surf=8, n_query=4)
+    model = torch.nn.Linear(2, 2)
+    for world in (1, 2, 3):
+        for rank in range(world):
+            dp = DataParallel(model, rank, world)
+            own = list(dp.shard(loader))
+            lazy = dp.shard(iter(loader.batches))              # no shard() method: the fallback
+            assert isinstance(lazy, types.GeneratorType)
+            lazy = list(lazy)
+            assert len(own) == len(lazy) == 7 // world
+            for a, b in zip(own, lazy):
+                assert a is b
+            ids = [id(b) for b in loader.batches]
+            assert [ids.index(id(a)) for a in own] == [g * world + rank for g in range(7 // world)]

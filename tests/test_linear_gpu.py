@@ -470,3 +470,80 @@ def test_k4_tail_weight_gradient_out_of_the_dx_gemm(k, d, M, bias):
     (ops.mlp2(x, seq) * t).sum().backward()
     for p, b0, r in zip(seq.parameters(), before, ref):
         assert float((p.grad.double() - 2 * r).abs().max()) <= 4e-5 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_batched_weight_gradient_reduce_is_bit_equal_to_the_one_call_form(dtype):
+    """nsdp_linear_wgrad_bf16x3_partials_f32 / nsdp_linear_wgrad_bf16_partials + one *_reduce_batched launch over several layers
+    against the one-call forms: the SAME bits, fresh targets and accumulated ones, with and without a bias gradient -- and through
+    the autograd wrapper: a backward pass with NSDP_WGRAD_BATCH_REDUCE = 16 / 3 / 0 leaves identical gradients, including a
+    parameter used twice in the graph (its pending reduction must land before the second use accumulates into it)."""
+    import ctypes
+    from nsdp_amd import _lib, hip_linear, precision
+    L = _lib.lib()
+    torch.manual_seed(11)
+    shapes = [(40000, 200, 200, True), (8192, 128, 120, False), (70001, 256, 256, True), (4096, 120, 128, True)]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    p = (lambda t: ctypes.c_void_p(t.data_ptr()))
+    descs, keep, want = [], [], []
+    Desc = hip_linear._ReduceDescB16 if dtype == "bf16" else hip_linear._ReduceDesc
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dy = torch.randn(M, N, device=DEV).to(tdt)
+        x = torch.randn(M, K, device=DEV).to(tdt)
+        acc = i % 2                                        # every other layer accumulates into what is there
+        base_w, base_b = torch.randn(N, K, device=DEV), torch.randn(N, device=DEV)
+        outs = []
+        for form in ("one", "batched"):
+            dw, db = base_w.clone(), (base_b.clone() if bias else None)
+            if dtype == "bf16":
+                L.nsdp_linear_wgrad_bf16_workspace_bytes.restype = ctypes.c_size_t
+                nb = int(L.nsdp_linear_wgrad_bf16_workspace_bytes(ctypes.c_longlong(M), N, K))
+            else:
+                L.nsdp_linear_wgrad_bf16x3_workspace_bytes.restype = ctypes.c_size_t
+                nb = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(ctypes.c_longlong(M), N, K))
+            ws = torch.empty(nb // 4, device=DEV)
+            args = (p(dy), p(x), None, 0, p(dw), p(db) if bias else None, ctypes.c_longlong(M), N, K, acc, p(ws), ctypes.c_size_t(nb))
+            if form == "one":
+                fn = L.nsdp_linear_wgrad_bf16 if dtype == "bf16" else L.nsdp_linear_wgrad_bf16x3_f32
+                _lib.check(fn(*args, _lib.stream_ptr()), "one-call weight gradient")
+            else:
+                d = Desc()
+                fn = L.nsdp_linear_wgrad_bf16_partials if dtype == "bf16" else L.nsdp_linear_wgrad_bf16x3_partials_f32
+                _lib.check(fn(*args, ctypes.byref(d), _lib.stream_ptr()), "partials")
+                descs.append(d)
+                keep.append(ws)
+            outs.append((dw, db))
+        want.append(outs)
+    arr = (Desc * len(descs))(*descs)
+    fn = L.nsdp_wgrad_bf16_reduce_batched if dtype == "bf16" else L.nsdp_wgrad_bf16x3_reduce_batched
+    _lib.check(fn(arr, len(descs), _lib.stream_ptr()), "batched reduce")
+    torch.cuda.synchronize()
+    for (one, bat), shp in zip(want, shapes):
+        assert torch.equal(one[0], bat[0]), shp
+        if shp[3]:
+            assert torch.equal(one[1], bat[1]), shp
+
+    # through autograd: three layers on the side stream, the first one used TWICE (large rows, then a few rows)
+    lins = [torch.nn.Linear(200, 200).to(DEV), torch.nn.Linear(200, 128).to(DEV), torch.nn.Linear(128, 128).to(DEV)]
+    x_big, x_small = torch.randn(40000, 200, device=DEV), torch.randn(16, 200, device=DEV)
+    grads = {}
+    was_o, was_b = hip_linear._OVERLAP_WGRAD, hip_linear.BATCH_REDUCE
+    hip_linear._OVERLAP_WGRAD = True
+    try:
+        for batch in (16, 3, 0):
+            hip_linear.BATCH_REDUCE = batch
+            for l in lins:
+                l.weight.grad = l.bias.grad = None
+            with precision.storage(dtype):
+                c = (lambda t: t.to(tdt))
+                h = hip_linear.linear(c(x_big), lins[0].weight, lins[0].bias, relu_out=True, params=True)
+                h = hip_linear.linear(h, lins[1].weight, lins[1].bias, relu_out=True, params=True)
+                h = hip_linear.linear(h, lins[2].weight, lins[2].bias, params=True)
+                g = hip_linear.linear(c(x_small), lins[0].weight, lins[0].bias, params=True)
+                (h.float().square().sum() + g.float().square().sum()).backward()
+            torch.cuda.synchronize()
+            grads[batch] = [t.grad.clone() for l in lins for t in (l.weight, l.bias)]
+    finally:
+        hip_linear._OVERLAP_WGRAD, hip_linear.BATCH_REDUCE = was_o, was_b
+    for a, b, c3 in zip(grads[16], grads[3], grads[0]):
+        assert torch.equal(a, c3) and torch.equal(b, c3)
