@@ -112,15 +112,16 @@ def decoder_forward(dec, xyz_q: torch.Tensor, encoding: dict) -> torch.Tensor:
     with torch.no_grad(), _lib.on_device(xyz_q):
         idx = pointnet2_utils.knn(xyz_q, anchors, ct.nneigh)                    # [B,NQ,k] int32
         tb = pack.tables
-        q = hip_linear.linear(z, tb["w_qs"])                                    # [B,DP] (pad channels = 0)
-        k_g = hip_linear.linear(z, tb["w_kg"])
-        v_g = hip_linear.linear(z, tb["w_vg"]).contiguous()
-        kf = hip_linear.linear(feats, tb["w_ks"])                               # [B,A,DP]
-        vtab = hip_linear.linear(feats, tb["w_vs"]).contiguous()
+        lin = lambda x, w, *a, **k: hip_linear.linear(x, w, *a, pack_owner=w, **k)      # (constant tables: packs cached on them)
+        q = lin(z, tb["w_qs"])                                                  # [B,DP] (pad channels = 0)
+        k_g = lin(z, tb["w_kg"])
+        v_g = lin(z, tb["w_vg"]).contiguous()
+        kf = lin(feats, tb["w_ks"])                                             # [B,A,DP]
+        vtab = lin(feats, tb["w_vs"]).contiguous()
         qk = (q.unsqueeze(1) - kf).contiguous()
         t = pack.tensors
-        h = hip_linear.linear(q - k_g, pack.gamma_rows[0], t[4], relu_out=True)  # global-token logits
-        a_g = hip_linear.linear(h, pack.gamma_rows[1], t[6]).contiguous()
+        h = lin(q - k_g, pack.gamma_rows[0], t[4], relu_out=True)               # global-token logits
+        a_g = lin(h, pack.gamma_rows[1], t[6]).contiguous()
         out = torch.empty(B, NQ, OUT, dtype=torch.float32, device=xyz_q.device)
         _lib.check(_lib.lib().nsdp_decoder_fused_fwd(
             _lib.fptr(xyz_q, "xyz_q"), _lib.fptr(anchors, "anchors"), _lib.iptr(idx, "idx"),

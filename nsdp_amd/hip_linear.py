@@ -893,7 +893,7 @@ def _observed(t):
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
            out_f32=False, premasked=False, mask_dx=False, init_gather=None, residual_sign=1.0,
-           skip_src=None, skip_dst=None, tail_src=None, tail_dst=None):
+           skip_src=None, skip_dst=None, tail_src=None, tail_dst=None, pack_owner=None):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -912,6 +912,10 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
     # the pack cache lives on the layer's leaf parameter whether or not gradients are being recorded (eval / no_grad
     # forward passes would otherwise rebuild every pack at every call); staleness is covered by the cache key
     owner = weight if (params and weight.is_leaf) else None
+    if pack_owner is not None:
+        # a constant weight that is not a parameter (the fused decoder's zero-padded projection tables): `pack_owner` -- normally
+        # the tensor itself -- carries the pack cache, so that the pack is built once instead of at every call
+        owner = pack_owner
     if precision.is_bf16():
         if init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst:
             raise ValueError("init_gather / signed residuals / SkipGrad belong to fp32 storage")

@@ -99,6 +99,12 @@ def roofline(prof, prof_isolated=None, pmc_matches=True, pmc_suffix="", replayed
     out["measured"] = "isolated pass (no cross-stream overlap)" if prof_isolated else "timed region"
     # the committed PMC passes are of the default workload (B = 32 forward.yaml train step) only
     out.update(_pmc_traffic(name, pmc_suffix) if pmc_matches else {"traffic": None})
+    if out.get("traffic") and out["bound"] == "hbm":
+        # how busy HBM is while this kernel runs: the bytes the memory-side counters saw (masks, residuals, gathered tables,
+        # weight re-reads and store read-modify-writes included -- everything `algorithmic_bytes` leaves out) per second of the
+        # kernel's own duration, against the 8 TB/s peak.  `frac` is the contract's figure; this one says how far from the HBM
+        # ceiling the launch really is.
+        out["frac_hbm_busy_by_pmc"] = round(out["traffic"] / (out["avg_launch_ms"] * 1e6) / PEAK_HBM_GBPS, 4)
     if prof_isolated and name in prof:
         ins = _roofline_one(name, prof[name])
         out["in_step"] = {k: ins[k] for k in ("achieved", "frac", "launches", "avg_launch_ms")}
@@ -141,7 +147,8 @@ def _pmc_traffic(name, suffix=""):
         if not n:
             return {"traffic": None}
         total = (2.0 * sum(v[1] for v in fetch) + sum(v[1] for v in write)) * 1024.0
-        return {"traffic": round(total / n), "traffic_unit": f"bytes/launch (PMC, profiles/{os.path.basename(path)})"}
+        return {"traffic": round(total / n), "traffic_unit": f"bytes/launch (PMC, profiles/{os.path.basename(path)})",
+                "traffic_writes": round(sum(v[1] for v in write) * 1024.0 / n)}
     except Exception:
         return {"traffic": None}
 
