@@ -355,6 +355,11 @@ int nsdp_linear_wgrad_bf16_partials(const void *dY, const void *X, const void *m
                                     long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                                     NsdpWgradB16ReduceDesc *desc_out, void *stream);
 int nsdp_wgrad_bf16_reduce_batched(const NsdpWgradB16ReduceDesc *descs, int count, void *stream);
+/* nsdp_linear_wgrad_f32 (the exact-fp32 kernels of the small layers) likewise: its partials have the same [S][N K + N] layout,
+ * its reduce the same eight chains -- the descriptor goes to nsdp_wgrad_bf16_reduce_batched. */
+int nsdp_linear_wgrad_partials_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
+                                   long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                   NsdpWgradB16ReduceDesc *desc_out, void *stream);
 
 /* bf16-storage variants of the BatchNorm kernels (x, addend, y, dy, dx bf16; statistics and affine parameters fp32). */
 int nsdp_bn_stats_bf16(const void *x, const void *addend, long long R, int C, float eps, float momentum,

@@ -18,6 +18,8 @@
 // room for bf16 inputs, and gfx950 has no TF32/xf32 path.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "k4.h"
 #include "pack_bodies.h"
@@ -1099,7 +1101,11 @@ WgradPlan plan_wgrad(long long M, int N, int K) {
   const long long traffic_cap = (M * static_cast<long long>(N + K)) / (8LL * N * K) / slots_per_chunk;
   if (max_chunks > traffic_cap) max_chunks = traffic_cap < 96 / slots_per_chunk ? 96 / slots_per_chunk / pl.grid_y : traffic_cap;
   if (max_chunks < 1) max_chunks = 1;
-  const long long min_rows = 128 * slots_per_chunk;
+  // below ~2048 rows (the 100-anchor level of an 8-shape batch: 800 rows) the kernel is latency-bound, not traffic-bound: a
+  // workgroup walks its 16-row blocks one global round trip at a time, and seven workgroups of 128 rows took 48 us for 0.1 GFLOP.
+  // 32-row chunks: four times the workgroups, a quarter of the chain (the partials are a few MB).
+  static const int small_rows = getenv("NSDP_WGRAD_SMALL_ROWS") ? atoi(getenv("NSDP_WGRAD_SMALL_ROWS")) : 32;      // (experiment knob)
+  const long long min_rows = (M <= 2048 ? small_rows : 128) * slots_per_chunk;
   long long chunks = (M + min_rows - 1) / min_rows;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
@@ -1122,7 +1128,8 @@ size_t nsdp_linear_wgrad_workspace_bytes(long long M, int N, int K) {
 
 static int wgrad_f32_impl(const float *dY, const float *X, const float *mask, const float *remask_W,
                           const float *remask_bias, int relu_x, float *dW, float *db, long long M, int N, int K,
-                          int accumulate, float *workspace, size_t workspace_bytes, void *stream) {
+                          int accumulate, float *workspace, size_t workspace_bytes, void *stream,
+                          NsdpWgradB16ReduceDesc *desc_out = nullptr) {
   if (N <= 0 || K <= 0) return 0;
   NSDP_REQUIRE(dW, "linear_wgrad: null output");
   NSDP_REQUIRE(N <= 256, "linear_wgrad: N=%d > 256 is not supported", N);
@@ -1172,6 +1179,10 @@ static int wgrad_f32_impl(const float *dY, const float *X, const float *mask, co
     int rc = nsdp::launch_status("linear_wgrad_kernel");
     if (rc) return rc;
   }
+  if (desc_out) {      // the caller sums these partials with a batch: same layout ([slots][N K + N]) and the same eight chains
+    *desc_out = NsdpWgradB16ReduceDesc{workspace, dW, db, static_cast<int>(pl.slots), N, K, accumulate ? 1 : 0, 0};
+    return 0;
+  }
   const long long nw = static_cast<long long>(N) * K;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(static_cast<unsigned>((nw + N + 255) / 256)), dim3(256), 0,
                      st, workspace, static_cast<int>(pl.slots), nw + N, nw, dW, static_cast<long long>(N), db,
@@ -1184,6 +1195,16 @@ int nsdp_linear_wgrad_f32(const float *dY, const float *X, const float *mask, in
                           size_t workspace_bytes, void *stream) {
   return wgrad_f32_impl(dY, X, mask, nullptr, nullptr, relu_x, dW, db, M, N, K, accumulate, workspace, workspace_bytes,
                         stream);
+}
+
+int nsdp_linear_wgrad_partials_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
+                                   long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                   NsdpWgradB16ReduceDesc *desc_out, void *stream) {
+  NSDP_REQUIRE(desc_out, "linear_wgrad_partials: null descriptor");
+  desc_out->ws = nullptr;
+  NSDP_REQUIRE(M > 0, "linear_wgrad_partials: M must be positive (the empty case has no partials: call nsdp_linear_wgrad_f32)");
+  return wgrad_f32_impl(dY, X, mask, nullptr, nullptr, relu_x, dW, db, M, N, K, accumulate, workspace, workspace_bytes, stream,
+                        desc_out);
 }
 
 int nsdp_linear_wgrad_k4_remask_f32(const float *dY, const float *X, const float *W, const float *bias, float *dW,

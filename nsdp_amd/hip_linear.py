@@ -152,6 +152,24 @@ def _wgrad(dy2, x2, mask, relu_x, want_db, out=None):
     nbytes = int(L.nsdp_linear_wgrad_workspace_bytes(_ll(M), _ci(N), _ci(K)))
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
     dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
+    batch = _cur_reduce
+    if batch is not None and BATCH_REDUCE > 0 and M > 0:
+        # the small layers' exact-fp32 kernels hand their partials to the pass's batch as well (same protocol as _wgrad_x3)
+        ptrs = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+        with on_device(dy2):
+            if ptrs & batch["targets"]:
+                _flush_reduce(batch)
+            desc = _ReduceDescB16()
+            check(L.nsdp_linear_wgrad_partials_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
+                                                   optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
+                                                   ctypes.c_size_t(nbytes), ctypes.byref(desc), stream_ptr()),
+                  "nsdp_linear_wgrad_partials_f32")
+            batch["descs_b16"].append(desc)
+            batch["keep"].append((ws, dw, db))
+            batch["targets"] |= ptrs
+            if len(batch["descs"]) + len(batch["descs_b16"]) >= BATCH_REDUCE:
+                _flush_reduce(batch)
+        return dw, db
     with on_device(dy2):
         check(L.nsdp_linear_wgrad_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
                                       optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
@@ -312,7 +330,15 @@ def _publish(device, key):
 
 
 def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig, out=None):
-    dw, db = _wgrad(dy2, x2, mask, relu_x, want_db, out if x2.shape[1] == k_orig else None)
+    global _cur_reduce
+    padded = x2.shape[1] != k_orig
+    prev = _cur_reduce
+    if padded:
+        _cur_reduce = None             # (the slice below reads dw at once: no pending reduction for it)
+    try:
+        dw, db = _wgrad(dy2, x2, mask, relu_x, want_db, None if padded else out)
+    finally:
+        _cur_reduce = prev
     if dw.shape[1] != k_orig:          # zero-padded reduction dimension (K = 3)
         dw = dw[:, :k_orig].contiguous()
     return dw, db
