@@ -1,6 +1,8 @@
 """Decoder blocks (state-dict compatible mirror of the reference's model/decoder/blocks.py)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -9,7 +11,8 @@ from .. import ops
 from ... import precision
 
 
-PREFETCH_RESERVE_CUS = int(__import__("os").environ.get("NSDP_PREFETCH_RESERVE_CUS", "0"))
+# compute units the prefetched position-encoding GEMM leaves to the encoder's chain (NSDP_DECODER_PREFETCH=1 only)
+PREFETCH_RESERVE_CUS = int(os.environ.get("NSDP_PREFETCH_RESERVE_CUS", "0"))
 
 
 class CrossTransformerBlock(nn.Module):
