@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void attn_post_bwd_kernel(
       const Quad qs = ldQ<ST>(qsub + pt * s.d, cq, lpp);
       yb.x += qs.x; yb.y += qs.y; yb.z += qs.z; yb.w += qs.w;
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int j = 0; j < s.k; ++j) {
       const long long rj = r0 + static_cast<long long>(j) * s.d;
       const Quad av = ldQ<ST>(a + rj, cq, lpp);
