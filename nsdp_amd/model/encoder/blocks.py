@@ -35,8 +35,9 @@ class TransformerBlock(nn.Module):
         self.k = k
         self.group_all = group_all
 
-    def forward(self, xyz, feats=None, idx=None):
-        """``idx`` [B,n,k] int32: precomputed neighbour indices (geometry pyramid); computed here if None."""
+    def forward(self, xyz, feats=None, idx=None, inv=None):
+        """``idx`` [B,n,k] int32: precomputed neighbour indices (geometry pyramid); computed here if None.
+        ``inv``: the inverse lists of ``idx`` when the pyramid built them as well."""
         B, n, _ = xyz.shape
         if idx is not None:
             pass
@@ -56,7 +57,8 @@ class TransformerBlock(nn.Module):
             # table v + k: the value projection adds k itself (as its residual, a constant of that node)
             fused = ops.fused_pre_applies(idx, feats.shape[-1])
             vf = ops.linear(feats, self.w_vs, grad_sum=fan, residual=kf.detach() if fused else None)
-            res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats, combined=fused)
+            res, _ = ops.vector_attention(rel, q, kf, vf, idx, self.fc_delta, self.fc_gamma, residual=feats, combined=fused,
+                                          inv=inv)
         return ops.batch_norm(res, self.bn)
 
 
@@ -105,7 +107,9 @@ class TransformerSetAbstraction(nn.Module):
         """``geo``: precomputed {fps_idx, new_xyz, sa_idx} of this level (geometry pyramid), else computed here."""
         if geo is not None:
             fps_idx, new_xyz, idx = geo["fps_idx"], geo["new_xyz"], geo["sa_idx"]
+            inv = geo.get("sa_inv")
         else:
+            inv = None
             fps_idx = ops.fps_indices(xyz, self.npoint)                   # [B, npoint] int32
             new_xyz = ops.index_points(xyz.detach(), fps_idx)             # detached centres (no_grad in ref)
             idx = ops.knn_indices(new_xyz, xyz, self.nneigh)              # [B, npoint, k]
@@ -118,7 +122,7 @@ class TransformerSetAbstraction(nn.Module):
         fused = ops.fused_pre_applies(idx, points.shape[-1])        # (see TransformerBlock: then the value table is v + k)
         k1 = ops.linear(points, self.w_ks, grad_sum=fan)
         v1 = ops.linear(points, self.w_vs, grad_sum=fan, residual=k1.detach() if fused else None)
-        res1, pos = ops.vector_attention(rel, q1, k1, v1, idx, self.fc_delta1, self.fc_gamma1, combined=fused)
+        res1, pos = ops.vector_attention(rel, q1, k1, v1, idx, self.fc_delta1, self.fc_gamma1, combined=fused, inv=inv)
         res1 = ops.linear(ops.batch_norm(ops.linear(res1, self.conv1), self.bn1), self.conv2, relu_in=True,
                           residual=res1)
         res1 = ops.batch_norm(res1, self.bnorm0)
@@ -130,12 +134,13 @@ class TransformerSetAbstraction(nn.Module):
             q2 = ops.linear(res1, self.w_qs2, residual=pos.q, residual_sign=-1.0)
             k2 = ops.linear(points, self.w_ks2, grad_sum=fan, residual=pos.kf, residual_sign=-1.0)
             v2 = ops.linear(points, self.w_vs2, grad_sum=fan, residual=pos.kf)
-            res12, _ = ops.vector_attention(None, q2, k2, v2, idx, None, self.fc_gamma2, residual=res1, pos=pos, combined=True)
+            res12, _ = ops.vector_attention(None, q2, k2, v2, idx, None, self.fc_gamma2, residual=res1, pos=pos, combined=True,
+                                            inv=inv)
         else:
             q2 = ops.linear(res1, self.w_qs2)
             res12, _ = ops.vector_attention(None, q2, ops.linear(points, self.w_ks2, grad_sum=fan),
                                             ops.linear(points, self.w_vs2, grad_sum=fan), idx,
-                                            None, self.fc_gamma2, residual=res1, pos=pos)
+                                            None, self.fc_gamma2, residual=res1, pos=pos, inv=inv)
 
         new_points = ops.batch_norm(res12, self.bnorm1)
         return new_xyz, ops.batch_norm(new_points, self.bnorm2, addend=ops.index_points(points, fps_idx))

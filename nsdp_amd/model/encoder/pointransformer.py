@@ -1,6 +1,7 @@
 """Point-Transformer encoder (mirror of the reference's model/encoder/pointransformer.py)."""
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -50,7 +51,8 @@ class PointTransformerEncoder(nn.Module):
         levels, join = ops.geometry_pyramid(
             coords, [td.sa.npoint for td in self.transition_downs],
             [(td.sa.nneigh, None if tb.group_all else tb.k)
-             for td, tb in zip(self.transition_downs, self.transformer_downs)])
+             for td, tb in zip(self.transition_downs, self.transformer_downs)],
+            dims=([self.d_reduced] + [self.d_transformer] * (len(self.transition_downs) - 1)) if torch.is_grad_enabled() else None)
         prefetch = on_anchors(levels[-1]["new_xyz"], ops.geometry_stream(coords.device)) if (on_anchors and levels) else None
         if self.has_features:
             feats = ops.linear(xyz[:, :, 3:], self.enc_sdf)
@@ -62,7 +64,7 @@ class PointTransformerEncoder(nn.Module):
         for i in range(len(self.transition_downs)):
             xyz, feats = self.transition_downs[i](xyz, feats, levels[i])
             feats = self.elementwise_extras[i](feats)
-            feats = self.transformer_downs[i](xyz, feats, idx=levels[i]["blk_idx"])
+            feats = self.transformer_downs[i](xyz, feats, idx=levels[i]["blk_idx"], inv=levels[i].get("blk_inv"))
             if i == 0 and self.d_reduced != self.d_transformer:
                 feats = ops.linear(feats, self.fc1)
             feats = self.elementwise[i](feats)

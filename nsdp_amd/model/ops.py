@@ -30,6 +30,9 @@ def fps_indices(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
 
 
 _side_streams = {}
+# inverse neighbour lists of the pyramid's index sets built on the geometry stream (A/B knob: 0 = by the attention blocks, on
+# the forward chain)
+PYRAMID_LISTS = os.environ.get("NSDP_PYRAMID_LISTS", "1") != "0"
 
 
 def _side_stream(device):
@@ -55,7 +58,7 @@ def prefetch_stream(device):
 
 
 @torch.no_grad()
-def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
+def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True, dims=None):
     """Every index tensor of the encoder's down-sampling pyramid depends on coordinates only:
     FPS level 1 -> centres -> FPS level 2 -> centres, and the kNN sets of the set abstractions and of the
     local attention blocks at each level.  They are produced here in one go on a SIDE STREAM, so the ~600
@@ -63,7 +66,10 @@ def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
     instead of in front of every later block (the reference serialises them, model/encoder/blocks.py:283-288).
 
     xyz [B,N,3]; npoints = [n1, n2, ...]; ks = [(k_sa, k_block), ...] per level.
-    Returns a list of dicts {fps_idx, new_xyz, sa_idx, blk_idx} and the event-free join handle (call
+    ``dims`` = the feature width of each level's attention blocks: where their backward pass will scatter through inverse
+    neighbour lists (hip_attention._use_inverse) the lists are built HERE as well -- they depend on the index sets only, and
+    a list build is one workgroup per shape (48 us at 32 shapes) that the forward chain otherwise waits for.
+    Returns a list of dicts {fps_idx, new_xyz, sa_idx, blk_idx[, sa_inv, blk_inv]} and the event-free join handle (call
     ``join()`` on the consumer stream before the first use)."""
     main = torch.cuda.current_stream(xyz.device)
     side = _side_stream(xyz.device) if overlap else main
@@ -77,7 +83,14 @@ def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
             new_xyz = pu.gather_rows(cur, fps_idx)
             sa_idx = pu.knn(new_xyz, cur, k_sa)
             blk_idx = pu.knn(new_xyz, new_xyz, k_blk) if k_blk is not None else None
-            levels.append({"fps_idx": fps_idx, "new_xyz": new_xyz, "sa_idx": sa_idx, "blk_idx": blk_idx})
+            lv = {"fps_idx": fps_idx, "new_xyz": new_xyz, "sa_idx": sa_idx, "blk_idx": blk_idx}
+            if dims is not None and PYRAMID_LISTS:
+                d = dims[len(levels)]
+                if hip_attention._use_inverse(torch.float32, False, n_new, cur.shape[1], d):
+                    lv["sa_inv"] = hip_attention.inverse_lists(sa_idx, cur.shape[1])
+                if blk_idx is not None and hip_attention._use_inverse(torch.float32, False, n_new, n_new, d):
+                    lv["blk_inv"] = hip_attention.inverse_lists(blk_idx, n_new)
+            levels.append(lv)
             cur = new_xyz
 
     def join():
@@ -85,8 +98,9 @@ def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True):
             torch.cuda.current_stream(xyz.device).wait_stream(side)
             for lv in levels:
                 for t in lv.values():
-                    if t is not None:
-                        t.record_stream(torch.cuda.current_stream(xyz.device))
+                    for u in (t if isinstance(t, tuple) else (t,)):
+                        if u is not None:
+                            u.record_stream(torch.cuda.current_stream(xyz.device))
 
     return levels, join
 
@@ -243,7 +257,8 @@ def fused_pre_applies(idx, d) -> bool:
     return bool(FUSE_PRE and COMBINE_TABLES and not precision.is_bf16() and not PAIR_MASK and hip_linear.gather_init_ok(B * n * k, d, d))
 
 
-def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None, combined=False):
+def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos=None, a_g=None, v_g=None, combined=False,
+                     inv=None):
     """sum_j softmax_j[gamma(q_i - kf[idx_ij] + delta(rel_ij))] * (vf[idx_ij] + delta(rel_ij)) (+ residual),
     softmax over the neighbour axis independently per channel (vector attention).
 
@@ -260,7 +275,7 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         link = hip_attention.pos_grad_link() if y.requires_grad else None
         if link is not None and FUSE_DPOS:
             link.grad_sum = hip_linear.InputGradSum()
-        inv = hip_attention.backward_lists(idx, y.shape[1], kf.shape[1], y.shape[-1])
+        inv = inv if inv is not None else hip_attention.backward_lists(idx, y.shape[1], kf.shape[1], y.shape[-1])
         u = hip_attention.attn_pre(q, kf, y, idx, link, inv) if combined else hip_attention.attn_pre(q - q1, kf - k1, y, idx, link, inv)
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         out = hip_attention.attn_post(logits, vf, y, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv,
@@ -283,7 +298,7 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
         link = hip_attention.pos_grad_link() if y.requires_grad else None
         if link is not None and FUSE_DPOS:
             link.grad_sum = hip_linear.InputGradSum()
-        inv = hip_attention.backward_lists(idx, n, kf.shape[1], d, qb=per_shape)
+        inv = inv if inv is not None else hip_attention.backward_lists(idx, n, kf.shape[1], d, qb=per_shape)
         u = hip_attention.attn_pre(q, kf, y, idx, link, inv, precomputed=y.detach())      # records the backward, launches nothing
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         # (`combined`: vf is already v + k -- the value projection took k as its residual)
@@ -303,7 +318,8 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
             # d(pos) = d(u) + d(pos)|values is formed by the gamma MLP's first dX GEMM (residual operand), see _PosGrad
             link.grad_sum = hip_linear.InputGradSum()
         # (inverse neighbour lists for the scatters of the backward pass: built here, once per index set)
-        inv = hip_attention.backward_lists(idx, pos.shape[1], kf.shape[1], pos.shape[-1], qb=(q.shape[1] == 1 and pos.shape[1] != 1))
+        if inv is None:
+            inv = hip_attention.backward_lists(idx, pos.shape[1], kf.shape[1], pos.shape[-1], qb=(q.shape[1] == 1 and pos.shape[1] != 1))
         u = hip_attention.attn_pre(q, kf, pos, idx, link, inv)      # q_i - kf[idx] + pos, gather fused
         logits = mlp2(u, fc_gamma, grad_sum=link.grad_sum if link is not None else None)
         out = hip_attention.attn_post(logits, vf, pos, idx, a_g=a_g, v_g=v_g, residual=residual, link=link, inv=inv)
