@@ -241,6 +241,17 @@ int nsdp_linear_bf16x3_addend_f32(const float *X, const void *Wp, const float *b
                                   const float *out_mask, const float *addend, float *Y, long long M, int N, int K,
                                   int relu_out, void *stream);
 
+/* Position-encoding MLP fc_delta = Linear(3, K) -> ReLU -> Linear(K, N) (reference model/encoder/blocks.py:86-90, :281-285,
+ * model/decoder/blocks.py:30-34) straight from the coordinates: Y[M,N] = relu(X4 W0^T + b0) W^T + bias.  The hidden tensor [M, K]
+ * is neither written nor read: the GEMM's operand producer evaluates the K = 4 layer for the 16-byte rows X4 [M,4] (zero-padded
+ * coordinates) with the expression of nsdp_linear_f32's K = 4 kernel -- the values are bit for bit those of the two-launch form.
+ * W0 [K,4] row-major zero-padded, b0 [K] or NULL, Wp = nsdp_pack_weight_bf16x3 of W [N,K].  gk != NULL: the gathered addend of
+ * nsdp_linear_bf16x3_gather_f32 joins in the epilogue (gq == NULL: its one-table form).  Shapes: nsdp_linear_bf16x3_h0_supported. */
+int nsdp_linear_bf16x3_h0_supported(long long M, int N, int K);
+int nsdp_linear_bf16x3_h0_f32(const float *X4, const float *W0, const float *b0, const void *Wp, const float *bias,
+                              const float *gq, int g_div, const float *gk, const int32_t *gidx, int g_rows_per_shape, int g_nsrc,
+                              float *Y, long long M, int N, int K, void *stream);
+
 /* dX GEMM of a position-encoding MLP's SECOND layer that takes the FIRST (K = 4) layer's weight gradient along.
  * fc_delta = Linear(3, d) -> ReLU -> Linear(d, d) on relative coordinates (reference model/encoder/blocks.py:86-90, :281-285,
  * model/decoder/blocks.py:30-34); the coordinates need no gradient, so Y = dY W2 -- the gradient of h0 = relu(X4 W0^T + b0) -- has
@@ -340,6 +351,15 @@ int nsdp_linear_wgrad_bf16_takes_mask(long long M, int N, int K);
 int nsdp_linear_wgrad_bf16(const void *dY, const void *X, const void *mask, int relu_x, float *dW, float *db,
                            long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                            void *stream);
+
+/* Weight gradient of the SECOND layer of the same MLP from the coordinates: dW [N,K] = dY^T relu(X4 W0^T + b0), db [N] = column
+ * sums of dY -- nsdp_linear_wgrad_bf16x3_f32 whose X operand is recomputed by the producer (see nsdp_linear_bf16x3_h0_f32) instead
+ * of read from an [M, K] tensor.  Workspace: nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K).  desc_out != NULL: partial sums
+ * only, reduction described for nsdp_wgrad_bf16x3_reduce_batched; NULL: reduced by this call.  Deterministic. */
+int nsdp_linear_wgrad_bf16x3_h0_supported(long long M, int N, int K);
+int nsdp_linear_wgrad_bf16x3_h0_f32(const float *dY, const float *X4, const float *W0, const float *b0, float *dW, float *db,
+                                    long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                    NsdpWgradReduceDesc *desc_out, void *stream);
 
 /* nsdp_linear_wgrad_bf16 in two halves, like nsdp_linear_wgrad_bf16x3_partials_f32 / nsdp_wgrad_bf16x3_reduce_batched: the row
  * kernel now (an all-zero *desc_out -- ws == NULL -- means the call had nothing to do), the fixed-order sums of many layers'

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void linear_nt_lds_kernel(LinearParams p) {
 // row lives (fragment-major pack: row n of the only k block is float4 number (n / 16) * 64 + n % 16).
 // pre-activation of a K = 4 layer: ONE expression for the forward kernel and for the weight-gradient kernel that
 // recomputes the layer's ReLU mask from its 16-byte input rows instead of reading the [M, N] output back
-using nsdp::k4_preact;      // (k4.h)
+using nsdp::k4_preact_n;      // (k4.h: the rounding is pinned per output channel)
 
 template <bool WP>
 __global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
@@ -509,10 +509,10 @@ __global__ __launch_bounds__(256) void linear_k4_fwd_kernel(LinearParams p) {
       float4 xv = x[u];
       if (p.relu_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
       float4 y;
-      y.x = k4_preact(xv, w[0], b.x);
-      y.y = k4_preact(xv, w[1], b.y);
-      y.z = k4_preact(xv, w[2], b.z);
-      y.w = k4_preact(xv, w[3], b.w);
+      y.x = k4_preact_n(xv, w[0], b.x, 0);      // (channel 4 cq + c: its parity is c's)
+      y.y = k4_preact_n(xv, w[1], b.y, 1);
+      y.z = k4_preact_n(xv, w[2], b.z, 0);
+      y.w = k4_preact_n(xv, w[3], b.w, 1);
       if (p.relu_out) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
       if (rr < p.M) *reinterpret_cast<float4 *>(p.Y + rr * N + 4 * cq) = y;
     }
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_k4_kernel(WgradParams p) {
         }
         if (MASK == 2) {
           const float4 xq = make_float4(xv[0], xv[1], xv[2], xv[3]);
-          d[0] = k4_preact(xq, w0[0], b0.x) > 0.f ? d[0] : 0.f; d[1] = k4_preact(xq, w0[1], b0.y) > 0.f ? d[1] : 0.f;
-          d[2] = k4_preact(xq, w0[2], b0.z) > 0.f ? d[2] : 0.f; d[3] = k4_preact(xq, w0[3], b0.w) > 0.f ? d[3] : 0.f;
+          d[0] = k4_preact_n(xq, w0[0], b0.x, 0) > 0.f ? d[0] : 0.f; d[1] = k4_preact_n(xq, w0[1], b0.y, 1) > 0.f ? d[1] : 0.f;
+          d[2] = k4_preact_n(xq, w0[2], b0.z, 0) > 0.f ? d[2] : 0.f; d[3] = k4_preact_n(xq, w0[3], b0.w, 1) > 0.f ? d[3] : 0.f;
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {

@@ -80,6 +80,11 @@ struct X3Params {
   // ReLU mask is recomputed from the 16-byte input rows (k4.h), every wave writes ONE partial (80 floats per n tile) per row tile to t_ws
   const float *t_x4 = nullptr, *t_w0 = nullptr, *t_b0 = nullptr;
   float *t_ws = nullptr;
+  // H0 forms (PRE == 3, nsdp_linear_bf16x3_h0_f32): the activation operand is the hidden layer of a position-encoding MLP,
+  // h0 = relu(x4 W0^T + b0) [M, K], and is never materialised -- the operand producer recomputes it from the 16-byte coordinate
+  // rows (k4.h: the very expression of the K = 4 forward kernel, so the values are the ones that kernel would have stored)
+  // instead of streaming [M, K] floats from HBM.  X is unused.  h_w0 [K, 4] row-major zero-padded, h_b0 [K] or NULL.
+  const float *h_x4 = nullptr, *h_w0 = nullptr, *h_b0 = nullptr;
 };
 
 // two fp32 values -> the packed (lo, hi) bf16 pairs of their three split planes
@@ -199,13 +204,15 @@ __device__ __forceinline__ void store_f4(unsigned byte_off, f32x4 v, float *unif
 // in the same phase).
 template <int MT, int NT, int PRE, int WV, bool XREG = false, int KBM = 2, int GATHER = 0, int TAIL = 0>
 __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3Params p) {
-  static_assert(!GATHER || PRE == 0, "the gathered addend belongs to the plain-prologue forms");
+  static_assert(!GATHER || PRE == 0 || PRE == 3, "the gathered addend belongs to the plain-prologue forms");
   static_assert(!TAIL || (PRE == 0 && !GATHER), "the K = 4 tail belongs to the plain-prologue forms");
   constexpr bool WRES = KBM > 2;
+  // H0: the operand is recomputed from 16-byte coordinate rows (see X3Params::h_x4): no activation DMA, no staging, no raw registers
+  constexpr bool kH0 = PRE == 3;
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
   // in LDS next to the weights and keeps the register path.
-  constexpr bool kXLds = PRE != 1 && !XREG;
+  constexpr bool kXLds = PRE != 1 && !XREG && !kH0;
   // LDS: [weight buffer 0][epilogue extension][weight buffer 1] (streaming form) + the activation staging.
   // STAGED EPILOGUE (streaming form): the output tile of a wave goes to HBM through LDS -- accumulators (lane = row li, four
   // columns) are written row-major into a per-wave piece of the weight buffer that the tile's last k block has just released
@@ -218,7 +225,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr bool kTwoPerCu = XREG || (NT <= 8 && WV == 4);                   // (launch_x3: these run two workgroups per CU)
   constexpr int kCap = (kTwoPerCu ? 80 : 160) * 64;                          // LDS budget in u32x4
   constexpr int kBiasLds = NT * 4;                                           // u32x4: the bias vector, staged once per workgroup
-  constexpr int kExtFree = kCap - KBM * kWTile - kXTile - kBiasLds;
+  constexpr int kH0Rows = kH0 ? ((NT * 16 + 31) / 32) * 32 : 0;              // rows of the K = 4 layer's table (whole k blocks)
+  constexpr int kH0XRows = kH0 ? 2 * WV * MT * 16 : 0;                       // coordinate rows of this tile and the next, per wave
+  constexpr int kH0Lds = kH0Rows + kH0Rows / 4 + kH0XRows;                   // u32x4: the K = 4 layer pair-wise (k4.h), its biases, the rows
+  constexpr int kExtFree = kCap - KBM * kWTile - kXTile - kBiasLds - kH0Lds;
   constexpr bool kStage = !WRES && kExtFree >= 0 && !TAIL;                   // (resident weights fill the LDS: direct epilogue; the K = 4 tail stores no tile)
   constexpr int kExtWant = WV * NT * 64 - kWTile;                            // whole 16-row tiles for every wave
   constexpr int kExt = !kStage ? 0 : (kExtWant < 0 ? 0 : (kExtFree < 0 ? 0 : (kExtWant < kExtFree ? kExtWant : kExtFree)));
@@ -234,6 +244,9 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   // of the wave's current tile, DMA'd at the tile's start (one KiB per wave: lane l holds row min(l, MT * 16 - 1))
   __shared__ __attribute__((aligned(16))) f32x4 t_w0lds[TAIL ? NT * 16 : 1];
   __shared__ __attribute__((aligned(16))) f32x4 t_x4lds[TAIL ? WV * 64 : 1];
+  __shared__ __attribute__((aligned(16))) f32x4 h_w0lds[kH0 ? kH0Rows : 1];
+  __shared__ __attribute__((aligned(16))) float h_b0lds[kH0 ? kH0Rows : 4];
+  __shared__ __attribute__((aligned(16))) f32x4 h_x4lds[kH0 ? 2 : 1][kH0 ? WV : 1][kH0 ? MT * 16 : 1];
   static_assert(!TAIL || !WRES, "the K = 4 tail needs 1 KiB of LDS per wave and 272 B per n tile next to the weight buffers");
   static_assert(!TAIL || MT * 16 <= 64, "the K = 4 tail stages one input row per lane");
   // buffer b of the weight ring: the extension sits between buffers 0 and 1, so that whichever of the two is free forms one
@@ -264,6 +277,29 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   };
   set_rows(tile, xa, ma);
   set_rows(tile + stride, xn, mn);
+  // H0: the wave's coordinate rows of the current tile and of the next one (whose first k block is produced inside this tile's
+  // last) sit in LDS -- DMA'd a tile ahead, no registers in flight; h_xs: the rows the producer of the k block being split
+  // works on (lane li: row 16 mt + li), h_par: which of the two row buffers holds the current tile
+  f32x4 h_xs[kH0 ? MT : 1];
+  int h_kb = 0;
+  unsigned h_par = 0;
+  auto h_rows = [&](long long t, unsigned buf) {      // lane l < MT * 16: row l of the wave's tile t
+    if (lane < MT * 16) {
+      long long r = (t * WV + wave) * (MT * 16) + lane;
+      r = r < p.M ? r : (p.M - 1);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(p.h_x4 + r * 4), (lds_ptr_t)(&h_x4lds[buf][wave][0]), 16, 0, 0);
+    }
+  };
+  auto h_take = [&](unsigned buf) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) h_xs[mt] = h_x4lds[buf][wave][mt * 16 + li];
+  };
+  if constexpr (kH0) {
+    h_rows(tile, 0u);
+    h_rows(tile + stride, 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    h_take(0u);
+  }
 
   const char *wlane = static_cast<const char *>(p.Wp) + lane * 16;
   auto stage = [&](int kb, int buf) {   // DMA one k block of weight pieces (1 KiB each), spread over the 4 waves
@@ -281,6 +317,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 16 half + 4 g ..)
   f32x4 raw[kXLds ? 1 : MT][2], rawm[kXLds ? 1 : MT][2];
   auto xissue = [&](const float *const *x, const float *const *m, int kb, unsigned xb) {
+    if constexpr (kH0) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -302,7 +339,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       }
   };
   auto xwait = [&]() {   // all outstanding vector memory operations (DMA included)
-    if constexpr (kXLds) {
+    if constexpr (kXLds || kH0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {   // the raw registers become data-dependent on the wait
 #pragma unroll
@@ -316,6 +353,19 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     u32x4 h[MT], m[MT], l[MT];
   };
   auto convert_pair = [&](Planes &pl, int mt, int pr, unsigned xb) {   // pr = 0..3: values 2 pr, 2 pr + 1 of the lane's 8
+    if constexpr (kH0) {
+      // k = 32 kb + 16 (pr / 2) + 4 g + 2 (pr % 2), + 1: two rows of the K = 4 layer's table (zeros beyond K: h0 = relu(0) = 0 there,
+      // against zero weights).  The row tiles of a pair index share these reads (the pair order below is pr-major)
+      const int k0 = h_kb * 32 + 16 * (pr >> 1) + 4 * g + 2 * (pr & 1);      // (even: one pair of the table)
+      const f32x4 wa = h_w0lds[k0], wb = h_w0lds[k0 + 1];
+      const f32x2 bb = *reinterpret_cast<const f32x2 *>(&h_b0lds[k0]);
+      const float4 xq = make_float4(h_xs[mt][0], h_xs[mt][1], h_xs[mt][2], h_xs[mt][3]);
+      const f32x2 pre = nsdp::k4_preact_pair(xq, f32x2{wa[0], wa[1]}, f32x2{wa[2], wa[3]}, f32x2{wb[0], wb[1]}, f32x2{wb[2], wb[3]}, bb);
+      unsigned h, m, l;
+      split_pair(fmaxf(pre[0], 0.f), fmaxf(pre[1], 0.f), h, m, l);
+      pl.h[mt][pr] = h; pl.m[mt][pr] = m; pl.l[mt][pr] = l;
+      return;
+    }
     f32x4 v;
     if constexpr (kXLds) {
       v = __builtin_bit_cast(f32x4, xbuf[xb][wave][(mt * 2 + (pr >> 1)) * 64 + lane]);
@@ -336,7 +386,15 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
     pl.h[mt][pr] = h; pl.m[mt][pr] = m; pl.l[mt][pr] = l;
   };
 
+  // pair i of a k block's split -> (row tile, value pair): row-tile-major, H0 value-pair-major (see convert_pair)
+  auto pair_mt = [](int i) { return kH0 ? i % MT : i >> 2; };
+  auto pair_pr = [](int i) { return kH0 ? i / MT : i & 3; };
   Planes cur, nxt;
+  if constexpr (kH0) {
+    for (int c = threadIdx.x; c < kH0Rows; c += WV * 64) h_b0lds[c] = (p.h_b0 && c < K) ? p.h_b0[c] : 0.f;
+    for (int j = threadIdx.x; j < kH0Rows / 2; j += WV * 64) nsdp::k4_pair_table(p.h_w0, K, j, h_w0lds[2 * j], h_w0lds[2 * j + 1]);
+    __syncthreads();      // (the prologue below already splits the first k block)
+  }
   if constexpr (kStage) {
     for (int c = threadIdx.x; c < NT * 16; c += WV * 64) bias_lds[c] = (p.bias && c < p.N) ? p.bias[c] : 0.f;      // visible after the prologue's barrier
   }
@@ -379,7 +437,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr int kConvFirst = kXLds ? NT - kConvSteps : 0;     // first n-tile step that carries split work
   constexpr int kPairs = MT * 4;
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
-  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 10 : 9) + 6 * MT - 1) / (6 * MT);
+  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 10 : PRE == 3 ? 21 : 9) + 6 * MT - 1) / (6 * MT);
 
 #ifdef NSDP_X3_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -461,6 +519,11 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         if (x_issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MT * 2) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       };
+      if constexpr (kH0) {      // the block split during this one: this tile's next, or the next tile's first
+        const bool wrap = kb + 1 >= KB;
+        h_kb = wrap ? 0 : kb + 1;
+        if (wrap) h_take(h_par ^ 1u);      // (the rows landed with the first k block's wait)
+      }
       const unsigned wsel = WRES ? static_cast<unsigned>(kb) : buf;
       const unsigned wl_addr = lds0 + wsel * kBufBytes + (wsel >= 1u ? kExtBytes : 0u);
       u32x4 wh, wm, wl;
@@ -478,7 +541,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             nm = nh; nl = nh;
           }
         }
-        if constexpr (!kXLds && nt == kConvFirst + kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
+        if constexpr (!kXLds && !kH0 && nt == kConvFirst + kConvSteps) {   // the raw registers are free again: activations two k blocks ahead
           if (kb + 2 < KB) xissue(xa, ma, kb + 2, 0u);
           else if (next_tile) xissue(xn, mn, kb + 2 - KB, 0u);
         }
@@ -492,7 +555,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #pragma unroll
           for (int i = 0; i < kPerStep; ++i) {
             constexpr int base = (nt - kConvFirst) * kPerStep;
-            if (base + i < kPairs) convert_pair(nxt, (base + i) >> 2, (base + i) & 3, buf ^ 1u);
+            if (base + i < kPairs) convert_pair(nxt, pair_mt(base + i), pair_pr(base + i), buf ^ 1u);
           }
         }
         // smallest products first; the MT accumulators of a product are independent
@@ -524,7 +587,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
           for (int i = 0; i < kPerStep; ++i) {
             constexpr int base = (nt - kConvFirst) * kPerStep;
             if (base + i < kPairs) {
-              const int mt = (base + i) >> 2, pr = (base + i) & 3;
+              const int mt = pair_mt(base + i), pr = pair_pr(base + i);
               asm volatile("" : "+v"(nxt.h[mt][pr]), "+v"(nxt.m[mt][pr]), "+v"(nxt.l[mt][pr]));
             }
           }
@@ -753,7 +816,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
             const bool ok = rvm[mt] && cv;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              const float pre = nsdp::k4_preact(xq, make_float4(w0[c][0], w0[c][1], w0[c][2], w0[c][3]), b0[c]);
+              const float pre = nsdp::k4_preact_n(xq, make_float4(w0[c][0], w0[c][1], w0[c][2], w0[c][3]), b0[c], c);      // (column 16 nt + 4 g + c)
               const float d = (ok && pre > 0.f) ? acc[mt][nt][c] : 0.f;
               ta[16 + c] += d;
 #pragma unroll
@@ -830,6 +893,10 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) { xa[mt] = xn[mt]; ma[mt] = mn[mt]; }
     set_rows(tile + stride, xn, mn);
+    if constexpr (kH0) {      // h_xs already holds the new tile's rows; the buffer of the tile just finished takes the one after
+      h_rows(tile + stride, h_par);
+      h_par ^= 1u;
+    }
   }
 #ifdef NSDP_X3_TIMING
   t_acc[5] = __builtin_readcyclecounter() - t_begin;
@@ -1286,6 +1353,27 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   return nsdp::launch_status("linear_bf16x3_kernel");
 }
 
+// H0 forms (the hidden layer of a position-encoding MLP recomputed in the operand producer): the plain-prologue classes of
+// launch_x3 without their activation staging.  13 n tiles always take the 8-wave form -- two 4-wave workgroups per CU have no
+// room for the K = 4 layer's table next to 2 x 78 KiB of weight planes.
+template <int NT, int GATHER>
+int launch_x3_h0(const X3Params &p, hipStream_t st) {
+  static_assert(NT == 8 || NT == 13 || NT == 16, "H0 forms: 8, 13 or 16 n tiles");
+  nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
+                          4.0 * (static_cast<double>(p.M) * (4 + p.N) + static_cast<double>(p.N) * p.K));
+  if constexpr (NT == 8) {
+    launch_x3_pre<2, 8, 3, 8, false, 4, GATHER>(p, st);      // (K <= 128: resident weight planes)
+  } else if constexpr (NT == 13) {
+    launch_x3_pre<2, 13, 3, 8, false, 2, GATHER>(p, st);
+  } else {
+    const long long cus = nsdp::num_cus();
+    const long long r3 = ((p.M + 191) / 192 + cus - 1) / cus * 192, r2 = ((p.M + 127) / 128 + cus - 1) / cus * 128;
+    if (!(g_x3_dbg & 4096) && r2 * 108 < r3 * 100) launch_x3_pre<2, 16, 3, 4, false, 2, GATHER>(p, st);
+    else launch_x3_pre<3, 16, 3, 4, false, 2, GATHER>(p, st);
+  }
+  return nsdp::launch_status("linear_bf16x3_kernel (h0)");
+}
+
 // K = 4 tail: the forms the position-encoding MLPs of the TDNet step take at scale (their dX GEMMs have square weights)
 constexpr int kTailGrid = 256;      // stage-1 partials
 template <int MT, int NT, int WV, int KBM = 2>
@@ -1418,6 +1506,49 @@ int nsdp_linear_bf16x3_signed_f32(const float *X, const void *Wp, const float *b
   if (nt <= 8) return launch_x3<8>(p, st);
   if (nt <= 13) return launch_x3<13>(p, st);
   return launch_x3<16>(p, st);
+}
+
+// Second layer of a position-encoding MLP Linear(3 or 4, K) -> ReLU -> Linear(K, N) straight from the coordinates:
+// Y[M,N] = relu(X4 W0^T + b0) W^T + bias (+ the gathered addend of nsdp_linear_bf16x3_gather_f32 when gk != NULL; gq == NULL:
+// its one-table form).  The hidden tensor [M, K] is neither written nor read: the operand producer recomputes it (k4.h, the
+// expression of nsdp_linear_k4 / its weight gradient's mask) -- values bit-identical to the two-launch form.  X4 [M,4]
+// zero-padded rows, W0 [K,4] row-major zero-padded, b0 [K] or NULL, Wp the bf16x3 pack of W [N,K].
+int nsdp_linear_bf16x3_h0_supported(long long M, int N, int K) {
+  return M > 0 && M < (1LL << 31) && N > 64 && N <= 256 && N % 4 == 0 && K > 32 && K % 4 == 0 && K <= ((N + 15) / 16) * 16;
+}
+int nsdp_linear_bf16x3_h0_f32(const float *X4, const float *W0, const float *b0, const void *Wp, const float *bias,
+                              const float *gq, int g_div, const float *gk, const int32_t *gidx, int g_rows_per_shape, int g_nsrc,
+                              float *Y, long long M, int N, int K, void *stream) {
+  if (M <= 0 || N <= 0) return 0;
+  NSDP_REQUIRE(X4 && W0 && Wp && Y, "linear_bf16x3_h0: null pointer");
+  NSDP_REQUIRE(nsdp_linear_bf16x3_h0_supported(M, N, K), "linear_bf16x3_h0: unsupported shape M=%lld N=%d K=%d", M, N, K);
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X4) | reinterpret_cast<uintptr_t>(W0) | reinterpret_cast<uintptr_t>(Wp) |
+                 reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gq) |
+                 reinterpret_cast<uintptr_t>(gk)) & 15) == 0,
+               "linear_bf16x3_h0: all operands must be 16-byte aligned");
+  X3Params p{nullptr, Wp, bias, nullptr, nullptr, nullptr, Y, M, N, K, 0, 0, g_x3_dbg};
+  p.h_x4 = X4; p.h_w0 = W0; p.h_b0 = b0;
+  hipStream_t st = nsdp::as_stream(stream);
+  const int nt = (N + 15) / 16;
+  if (!gk) {
+    if (nt <= 8) return launch_x3_h0<8, 0>(p, st);
+    if (nt <= 13) return launch_x3_h0<13, 0>(p, st);
+    return launch_x3_h0<16, 0>(p, st);
+  }
+  NSDP_REQUIRE(gidx && g_div > 0 && g_rows_per_shape > 0 && g_nsrc > 0, "linear_bf16x3_h0: bad row maps");
+  {   // the kernel addresses both tables with 32-bit element offsets
+    const long long q_rows = gq ? (M + g_div - 1) / g_div : 0, k_rows = ((M + g_rows_per_shape - 1) / g_rows_per_shape) * g_nsrc;
+    NSDP_REQUIRE(q_rows * N < (1LL << 31) && k_rows * N < (1LL << 31), "linear_bf16x3_h0: tables beyond 2^31 elements");
+  }
+  p.gq = gq; p.gk = gk; p.gidx = gidx; p.g_div = g_div; p.g_rps = g_rows_per_shape; p.g_nsrc = g_nsrc;
+  if (!gq) {
+    if (nt <= 8) return launch_x3_h0<8, 2>(p, st);
+    if (nt <= 13) return launch_x3_h0<13, 2>(p, st);
+    return launch_x3_h0<16, 2>(p, st);
+  }
+  if (nt <= 8) return launch_x3_h0<8, 1>(p, st);
+  if (nt <= 13) return launch_x3_h0<13, 1>(p, st);
+  return launch_x3_h0<16, 1>(p, st);
 }
 
 // Can the dX GEMM dY [M,K] x W2 [K,N] of a position-encoding MLP's second layer take the first (K = 4) layer's weight gradient

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "k4.h"
 #include "prof.h"
 
 namespace {
@@ -55,6 +56,9 @@ struct WgX3Params {
   long long blocks_per_wg;   // 32-row blocks per workgroup
   int want_db;
   int kparts;                // grid.y: column ranges of X of KTB*16 columns each (K > 208: LDS holds N + K/2 columns)
+  // H0 forms: X [M, 4] holds the 16-byte coordinate rows of a position-encoding MLP and the operand is its hidden layer
+  // relu(X W0^T + b0) [M, K], recomputed by the producer (k4.h) instead of read; h_w0 [K, 4] row-major zero-padded, h_b0 [K] or NULL
+  const float *h_w0 = nullptr, *h_b0 = nullptr;
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
@@ -140,9 +144,14 @@ __device__ __forceinline__ u32x4 frag_vec(const unsigned long long (&q)[2]) {
 // index list (p.dY points at int32 indices), generated by the producer straight into the h plane image -- 1.0 is exact in
 // bf16, so table[a][c] = sum_{r: idx[r] = a} X[r][c] needs the three products 1 x {h, m, l} only and comes out in a fixed
 // summation order (no atomics).  grid.y = shapes, each with its own p.M rows, index list and table.
-template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false>
+// H0 (nsdp_linear_wgrad_bf16x3_h0_f32): the X operand is the hidden layer h0 = relu(x4 W0^T + b0) of a position-encoding MLP,
+// recomputed from the 16-byte coordinate rows: a B slot loads its row's float4 instead of four floats of an [M, K] tensor and
+// evaluates the K = 4 layer for its four columns (table rows from LDS: the 4 KiB the two plane buffers leave free hold 204).
+template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false, bool H0 = false>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   static_assert(!ONEHOT || (!MASK && NTA == 8), "one-hot operand: 128 table rows, no mask");
+  static_assert(!H0 || (!MASK && !ONEHOT), "H0 operand: plain dY");
+  constexpr int kH0Rows = !H0 ? 0 : (KTB == 13 ? 204 : KTB * 16);
   constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
   constexpr int kColsA = NTA * 16, kColsB = KTB * 16, kC4A = NTA * 4, kC4B = KTB * 4;
   constexpr int kPitchA = tr_pitch_bytes(kColsA), kPitchB = tr_pitch_bytes(kColsB);
@@ -150,6 +159,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   constexpr unsigned kBufBytes = 3 * (kPlaneA + kPlaneB);            // [A h, m, l][B h, m, l], row-major images
   constexpr int RA = ONEHOT ? 1 : (32 * kC4A + 255) / 256, RB = (32 * kC4B + 255) / 256;   // float4 slots per lane
   __shared__ __attribute__((aligned(16))) unsigned char planes[2 * kBufBytes];
+  __shared__ __attribute__((aligned(16))) f32x4 h_w0lds[H0 ? kH0Rows : 1];
+  __shared__ __attribute__((aligned(16))) float h_b0lds[H0 ? kH0Rows : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wa = wave >> 1, wb = wave & 1;
@@ -171,7 +182,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   unsigned offA[RA], offB[RB];       // byte offset of the slot's float4 in dY / X for the block loaded next
   unsigned ldsA[RA], ldsB[RB];       // byte offset inside a plane image
   int rowA[RA], rowB[RB];            // image row (TAIL)
-  const unsigned strideA = ONEHOT ? 4u : static_cast<unsigned>(N) * 4u, strideB = static_cast<unsigned>(K) * 4u;
+  int colB[H0 ? RB : 1];             // (H0) first of the slot's four columns, relative to k_off
+  const unsigned strideA = ONEHOT ? 4u : static_cast<unsigned>(N) * 4u, strideB = H0 ? 16u : static_cast<unsigned>(K) * 4u;
+  if constexpr (H0) {      // this column range's rows of the K = 4 layer's table (host contract: Kpart <= kH0Rows)
+    // (pair-wise, k4.h; k_off is a multiple of 16 and Kpart of 4: a pair never straddles the range)
+    for (int c = tid; c < kH0Rows; c += 256) h_b0lds[c] = (p.h_b0 && c < Kpart) ? p.h_b0[k_off + c] : 0.f;
+    for (int j = tid; j < kH0Rows / 2; j += 256)
+      nsdp::k4_pair_table(p.h_w0 + static_cast<long long>(k_off) * 4, Kpart, j, h_w0lds[2 * j], h_w0lds[2 * j + 1]);
+    __syncthreads();
+  }
 #pragma unroll
   for (int r = 0; r < RA; ++r) {
     if constexpr (ONEHOT) {      // thread = (image row tid / 8, 16-column segment tid % 8); the row's index is one dword
@@ -195,7 +214,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     const int row = s / kC4B, c4 = s % kC4B;
     const int col = k_off + (4 * c4 + 4 <= Kpart ? 4 * c4 : Kpart - 4);
     rowB[r] = row;
-    offB[r] = static_cast<unsigned>(((mb0 * 32 + row) * K + col) * 4);
+    if constexpr (H0) {
+      colB[r] = col - k_off;
+      offB[r] = static_cast<unsigned>((mb0 * 32 + row) * 16);
+    } else {
+      offB[r] = static_cast<unsigned>(((mb0 * 32 + row) * K + col) * 4);
+    }
     ldsB[r] = static_cast<unsigned>(3 * kPlaneA + row * kPitchB + c4 * 8);
   }
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&planes[0])));
@@ -289,8 +313,21 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   const float relu_floor = p.relu_x ? 0.f : -__builtin_inff();
   auto produce_b = [&](int r, unsigned buf_off) {
     f32x4 v;
+    if constexpr (H0) {
+      const float4 xq = make_float4(rawB[r][0], rawB[r][1], rawB[r][2], rawB[r][3]);
+      const f32x4 bb = *reinterpret_cast<const f32x4 *>(&h_b0lds[colB[r]]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(rawB[r][c], relu_floor, __builtin_inff());
+      for (int c = 0; c < 4; c += 2) {      // (the slot's first column is a multiple of 4: two pairs of the table)
+        const f32x4 wa = h_w0lds[colB[r] + c], wb = h_w0lds[colB[r] + c + 1];
+        const f32x2 pre = nsdp::k4_preact_pair(xq, f32x2{wa[0], wa[1]}, f32x2{wa[2], wa[3]}, f32x2{wb[0], wb[1]}, f32x2{wb[2], wb[3]},
+                                               f32x2{bb[c], bb[c + 1]});
+        v[c] = fmaxf(pre[0], 0.f);
+        v[c + 1] = fmaxf(pre[1], 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = __builtin_amdgcn_fmed3f(rawB[r][c], relu_floor, __builtin_inff());
+    }
     write3(v, buf_off + ldsB[r], kPlaneB);
   };
   auto rows_in = [&](long long mb) {
@@ -596,6 +633,14 @@ template <int NTA, int KTB>
 void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
   const dim3 g(grid, p.kparts);
   const bool tail = (p.M & 31) != 0;
+  if constexpr ((NTA == 8 && KTB == 8) || (NTA == 13 && KTB == 13) || (NTA == 16 && KTB == 8)) {
+    if (p.h_w0) {
+      NSDP_TRACE("wgrad_bf16x3<%d,%d,h0,%s>", NTA, KTB, tail ? "tail" : "notail");
+      if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, true, false, true>), g, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false, false, true>), g, dim3(256), 0, st, p);
+      return;
+    }
+  }
   NSDP_TRACE("wgrad_bf16x3<%d,%d,%s,%s>", NTA, KTB, p.mask ? "mask" : "plain", tail ? "tail" : "notail");
   if (p.mask) {
     if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, true>), g, dim3(256), 0, st, p);
@@ -680,6 +725,46 @@ int nsdp_linear_wgrad_bf16x3_partials_f32(const float *dY, const float *X, const
   else launch_wg<13, 13>(p, pl.grid, st);
   *desc_out = NsdpWgradReduceDesc{workspace, dW, db, pl.grid, pl.nta, pl.ktb, N, K, accumulate ? 1 : 0, 0};
   return nsdp::launch_status("wgrad_bf16x3_kernel");
+}
+
+// dW [N,K], db [N] of the SECOND layer of a position-encoding MLP Linear(3 or 4, K) -> ReLU -> Linear(K, N) from the gradient
+// dY [M,N] of its output and the 16-byte coordinate rows X4 [M,4]: dW = dY^T relu(X4 W0^T + b0), the hidden tensor recomputed by
+// the operand producer (bit for bit the values of the two-launch forward).  W0 [K,4] zero-padded, b0 [K] or NULL.  Workspace:
+// nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K).  desc_out != NULL: only the partial sums are formed and the reduction is
+// described for nsdp_wgrad_bf16x3_reduce_batched (as nsdp_linear_wgrad_bf16x3_partials_f32); NULL: reduced here.
+int nsdp_linear_wgrad_bf16x3_h0_supported(long long M, int N, int K) {
+  if (!nsdp_linear_wgrad_bf16x3_supported(M, N, K) || K % 4 || N % 4 || M >= (1LL << 27)) return 0;
+  const X3Plan pl = plan_x3(M, N, K);
+  const bool form = (pl.nta == 8 && pl.ktb == 8) || (pl.nta == 13 && pl.ktb == 13) || (pl.nta == 16 && pl.ktb == 8);
+  return form && (pl.ktb == 13 ? K <= 204 : true);
+}
+int nsdp_linear_wgrad_bf16x3_h0_f32(const float *dY, const float *X4, const float *W0, const float *b0, float *dW, float *db,
+                                    long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                    NsdpWgradReduceDesc *desc_out, void *stream) {
+  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_h0_supported(M, N, K),
+               "linear_wgrad_bf16x3_h0: shape M=%lld N=%d K=%d outside the kernel's range", M, N, K);
+  NSDP_REQUIRE(dY && X4 && W0 && dW && workspace, "linear_wgrad_bf16x3_h0: null pointer");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K), "linear_wgrad_bf16x3_h0: workspace too small");
+  NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X4) | reinterpret_cast<uintptr_t>(W0)) & 15) == 0,
+               "linear_wgrad_bf16x3_h0: operands must be 16-byte aligned");
+  const X3Plan pl = plan_x3(M, N, K);
+  WgX3Params p{dY, X4, nullptr, 0, workspace, M, N, K, pl.blocks_per_wg, db != nullptr, pl.kparts};
+  p.h_w0 = W0; p.h_b0 = b0;
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kWgradX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (4 + N)));
+  if (pl.nta == 8) launch_wg<8, 8>(p, pl.grid, st);
+  else if (pl.nta == 16) launch_wg<16, 8>(p, pl.grid, st);
+  else launch_wg<13, 13>(p, pl.grid, st);
+  const int rc = nsdp::launch_status("wgrad_bf16x3_kernel (h0)");
+  if (rc) return rc;
+  if (desc_out) {
+    *desc_out = NsdpWgradReduceDesc{workspace, dW, db, pl.grid, pl.nta, pl.ktb, N, K, accumulate ? 1 : 0, 0};
+    return 0;
+  }
+  const long long ne = static_cast<long long>(N) * K + N;
+  hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
+                     workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
+  return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
 }
 
 int nsdp_wgrad_bf16x3_reduce_batched(const NsdpWgradReduceDesc *descs, int count, void *stream) {

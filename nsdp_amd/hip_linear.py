@@ -734,6 +734,169 @@ def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
     return fn
 
 
+# ------------------------------------------------------------------------------------------------
+# Position-encoding MLPs from the coordinates: the hidden tensor is never materialised
+# ------------------------------------------------------------------------------------------------
+# fc_delta = Linear(3, d) -> ReLU -> Linear(d, d) on [B, n, k, 3] relative coordinates (reference model/encoder/blocks.py:86-90,
+# :281-285, model/decoder/blocks.py:30-34).  Its hidden tensor h0 [rows, d] (1.47 GB in the decoder of a B = 32 step) was written
+# by the K = 4 kernel, read by the second layer's GEMM, kept for the backward pass and read again by the second layer's weight
+# gradient.  With NSDP_H0_RECOMPUTE (default on) the operand producers of those two kernels evaluate the K = 4 layer themselves
+# from the 16-byte coordinate rows (nsdp_linear_bf16x3_h0_f32, nsdp_linear_wgrad_bf16x3_h0_f32: the forward kernel's own
+# expression, so every value is the one that kernel would have stored); the first layer's weight gradient already came out of the
+# second layer's dX GEMM (K4Tail).  What is left of the pair: one GEMM forward, one weight-gradient kernel and the tail GEMM backward.
+# Measured (tools/bench_h0.py, profiles/r5_h0_recompute.txt): these GEMMs are not HBM-bound, and the producer's ~16 VALU operations
+# per value pair cost about what the activation DMA did -- so the time gained is the K = 4 kernel's minus a slower weight gradient:
+# -40 % forward / -13 % forward + backward on the 128-wide blocks, -6 ... -14 % / -2 % on the decoder's 1 M x 200, a LOSS on the
+# 256-wide three-row-tile form (+4 % / +2 %) and on 200-wide layers below ~0.5 M rows.  NSDP_H0_RECOMPUTE: 0 off, 1 (default) the
+# shape classes where it pays, 2 every shape the kernels support.  What it always saves is the hidden tensor itself (1.47 GB kept
+# from forward to backward in the decoder of a B = 32 step).
+H0_RECOMPUTE = int(os.environ.get("NSDP_H0_RECOMPUTE", "1"))
+
+
+def _h0_pays(M, N):
+    nt = (N + 15) // 16
+    if H0_RECOMPUTE >= 2 or nt <= 8:
+        return True
+    if nt <= 13:
+        return M >= (1 << 19)
+    return M <= 65536      # (16 n tiles: the two-row-tile form of the small levels)
+
+
+def _fwd_x3_h0(x4, w4, b0, wp, N, K, b, gather):
+    """relu(x4 w4^T + b0) W^T + b (+ the gathered addend of _fwd_x3_gather) without the hidden tensor (nsdp_linear_bf16x3_h0_f32)."""
+    M = x4.shape[0]
+    gq = gk = gidx = None
+    g_div = rps = nsrc = 0
+    if gather is not None:
+        gq, g_div, gk, gidx, rps, nsrc = gather
+        if (gq is not None and gq.shape[-1] != N) or gk.shape[-1] != N or gidx.numel() != M:
+            raise ValueError("init_gather: table width / index count do not match the layer")
+    y = torch.empty((M, N), dtype=torch.float32, device=x4.device)
+    with on_device(x4):
+        check(lib().nsdp_linear_bf16x3_h0_f32(fptr(x4, "x4"), fptr(w4, "w0"), optptr(b0), ctypes.c_void_p(wp.data_ptr()), optptr(b),
+                                              optptr(gq), _ci(int(g_div)), optptr(gk),
+                                              ctypes.c_void_p(gidx.data_ptr() if gidx is not None else None), _ci(int(rps)),
+                                              _ci(int(nsrc)), fptr(y), _ll(M), _ci(N), _ci(K), stream_ptr()),
+              "nsdp_linear_bf16x3_h0_f32")
+    return y
+
+
+def _wgrad_h0_fn(w4, b0, K):
+    """Weight-gradient routine (the `fn` protocol of wgrad_direct / _wgrad_deferred) of the SECOND layer of a position-encoding
+    MLP whose hidden tensor was never stored: x2 is the [M, 4] coordinate rows, (w4, b0) the first layer."""
+    def fn(dy2, x4, mask, relu_x, want_db, out=None):
+        M, N = dy2.shape
+        L = lib()
+        L.nsdp_linear_wgrad_bf16x3_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(_ll(M), _ci(N), _ci(K)))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+        dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
+        batch = _cur_reduce if BATCH_REDUCE > 0 else None
+        desc = _ReduceDesc() if batch is not None else None
+        with on_device(dy2):
+            if batch is not None:
+                ptrs = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+                if ptrs & batch["targets"]:
+                    _flush_reduce(batch)
+            check(L.nsdp_linear_wgrad_bf16x3_h0_f32(fptr(dy2, "dy"), fptr(x4, "x4"), fptr(w4, "w0"), optptr(b0), fptr(dw), optptr(db),
+                                                    _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws), ctypes.c_size_t(nbytes),
+                                                    ctypes.byref(desc) if desc is not None else None, stream_ptr()),
+                  "nsdp_linear_wgrad_bf16x3_h0_f32")
+            if batch is not None:
+                batch["descs"].append(desc)
+                batch["keep"].append((ws, dw, db, x4, w4, b0))
+                batch["targets"] |= ptrs
+                if len(batch["descs"]) + len(batch["descs_b16"]) >= BATCH_REDUCE:
+                    _flush_reduce(batch)
+        return dw, db
+    fn.batched_reduce = True
+    return fn
+
+
+class _PosMlpFn(torch.autograd.Function):
+    """y = relu(x4 W0^T + b0) W1^T + b1 (+ gathered addend) with direct publication of all four parameter gradients; x4 needs no
+    gradient.  Saved for the backward pass: the coordinate rows, the padded first layer and the W1^T pack -- not the hidden tensor."""
+
+    @staticmethod
+    def forward(ctx, x4, w4, b0, w1, b1, wp, wpt, init_gather, k_orig0, w0_param, b0_param, w1_param, b1_param):
+        N, K = w1.shape
+        y = _fwd_x3_h0(x4, w4, b0, wp, N, K, b1, init_gather)
+        ctx.save_for_backward(x4, w4, b0, wpt)
+        ctx.params = (w0_param, b0_param, w1_param, b1_param)
+        ctx.k_orig0, ctx.n_out, ctx.hidden = k_orig0, N, K
+        ctx.fwd_key = (_pack_key(w0_param), None if b0_param is None else _pack_key(b0_param))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x4, w4, b0, wpt = ctx.saved_tensors
+        w0_param, b0_param, w1_param, b1_param = ctx.params
+        if ctx.fwd_key != (_pack_key(w0_param), None if b0_param is None else _pack_key(b0_param)):
+            raise RuntimeError("position-encoding MLP: its first layer changed between forward and backward; the hidden tensor "
+                               "is recomputed from the parameters (NSDP_H0_RECOMPUTE=0 keeps it)")
+        N, K = ctx.n_out, ctx.hidden
+        dy2 = dy.reshape(-1, N)
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        link = K4Tail()
+        link.x4, link.w_param, link.b_param, link.k_orig = x4, w0_param, b0_param, ctx.k_orig0
+        fn1 = _wgrad_h0_fn(w4, b0, K)
+        tfn = _k4tail_fn(link, wpt, K, "x3", None)
+        if _use_side_stream(dy2):
+            _wgrad_deferred(dy2, x4, None, False, K, w1_param, b1_param, fn=fn1)
+            if K4_TAIL_SIDE:
+                _wgrad_deferred(dy2, x4, None, False, ctx.k_orig0, w0_param, b0_param, fn=tfn)
+                wpt.record_stream(_side_stream(dy2.device))
+            else:
+                wgrad_direct(dy2, x4, None, False, ctx.k_orig0, w0_param, b0_param, fn=tfn)
+        else:
+            wgrad_direct(dy2, x4, None, False, K, w1_param, b1_param, fn=fn1)
+            wgrad_direct(dy2, x4, None, False, ctx.k_orig0, w0_param, b0_param, fn=tfn)
+        return (None,) * 13
+
+
+def pos_mlp(x, weight0, bias0, weight1, bias1, init_gather=None):
+    """Linear(3 or 4, d) -> ReLU -> Linear(d, N) on coordinates that need no gradient, without the hidden tensor (see above).
+    The four arguments are the layers' leaf nn.Parameters (bias0 / bias1 may be None).  Returns None where this form does not
+    apply -- the caller then takes the two-layer path: bf16 storage, shapes outside the kernels' range, parameter gradients that
+    must go through autograd (hooks, autograd_param_grads), A/B knobs of the K = 4 tail switched off."""
+    if not H0_RECOMPUTE or precision.is_bf16() or x.dtype is not torch.float32 or x.shape[-1] not in (3, 4):
+        return None
+    grad = torch.is_grad_enabled()
+    if grad and x.requires_grad:
+        return None
+    w0 = weight0.squeeze(-1) if weight0.dim() == 3 else weight0
+    w1 = weight1.squeeze(-1) if weight1.dim() == 3 else weight1
+    N, K = w1.shape
+    if w0.shape[0] != K or w0.shape[1] not in (3, 4) or w0.shape[1] > x.shape[-1] or not (weight0.is_leaf and weight1.is_leaf):
+        return None
+    M = x.numel() // x.shape[-1]
+    L = lib()
+    if not (_x3_ok(M, N, K) and L.nsdp_linear_bf16x3_h0_supported(_ll(M), _ci(N), _ci(K)) and _h0_pays(M, N)):
+        return None
+    needs = [p for p in (weight0, bias0, weight1, bias1) if p is not None and p.requires_grad]
+    train = grad and bool(needs)
+    if train:
+        every = [p for p in (weight0, bias0, weight1, bias1) if p is not None]
+        if (len(needs) != len(every) or not _PARAM_GRADS_DIRECT or any(_observed(p) or not p.is_leaf for p in every)
+                or not (K4_LINK and REMASK_K4) or M < 4096 or not _x3_ok(M, K, N)
+                or not L.nsdp_linear_wgrad_bf16x3_h0_supported(_ll(M), _ci(N), _ci(K))):
+            return None
+    x4 = x.reshape(-1, x.shape[-1])
+    x4 = x4 if x4.is_contiguous() else x4.contiguous()
+    x4 = _pad_cols(x4)
+    w4 = _padded_w4(weight0)
+    b0 = None if bias0 is None else bias0.detach()
+    b1 = None if bias1 is None else bias1.detach()
+    wd = w1.detach()
+    wp = _packs(wd, weight1, "x3", train)[0]
+    if not train:
+        y = _fwd_x3_h0(x4, w4, b0, wp, N, K, b1, init_gather)
+    else:
+        wpt = _packs(wd, weight1, "x3", True)[1]
+        y = _PosMlpFn.apply(x4, w4, b0, wd, b1, wp, wpt, init_gather, int(w0.shape[1]), weight0, bias0, weight1, bias1)
+    return y.reshape(*x.shape[:-1], N)
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,

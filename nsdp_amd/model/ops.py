@@ -167,6 +167,14 @@ def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, resi
                              skip_src=skip_src, skip_dst=skip_dst, tail_src=tail_src, tail_dst=tail_dst)
 
 
+def pos_mlp(x: torch.Tensor, seq: nn.Sequential, init_gather=None):
+    """Position-encoding MLP ``seq`` = Sequential(Linear(3, d), ReLU, Linear(d, d)) on coordinates ``x`` that need no gradient,
+    without its hidden tensor (hip_linear.pos_mlp); None where that form does not apply (the caller takes the two-layer path)."""
+    if PAIR_MASK:
+        return None
+    return hip_linear.pos_mlp(x, seq[0].weight, seq[0].bias, seq[2].weight, seq[2].bias, init_gather=init_gather)
+
+
 def k4_tail(x: torch.Tensor, seq: nn.Sequential):
     """hip_linear.K4Tail for a position-encoding MLP ``seq`` = Sequential(Linear(3 or 4, d), ReLU, Linear(d, d)) applied to
     coordinates ``x`` that need no gradient (None otherwise): the second layer's dX GEMM then produces the first layer's
@@ -203,6 +211,10 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
         return linear(linear(x, seq[0], grad_sum=grad_sum), seq[2], relu_in=True)
     if PAIR_MASK and torch.is_grad_enabled():
         return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, premasked=True), seq[2], mask_dx=True)
+    if grad_sum is None and x.shape[-1] in (3, 4):
+        y = pos_mlp(x, seq)
+        if y is not None:
+            return y
     tl = k4_tail(x, seq) if grad_sum is None else None
     return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, tail_src=tl), seq[2], tail_dst=tl)
 
@@ -292,9 +304,11 @@ def vector_attention(rel, q, kf, vf, idx, fc_delta, fc_gamma, residual=None, pos
             gather = (None, 1, (qd - kd).reshape(-1, d), idx.reshape(-1), n * k, kf.shape[1])
         else:
             gather = (qd.reshape(-1, d).contiguous(), k, kd.reshape(-1, d).contiguous(), idx.reshape(-1), n * k, kf.shape[1])
-        tl = k4_tail(rel, fc_delta)
-        h = linear(rel, fc_delta[0], relu=True, tail_src=tl)
-        y = linear(h, fc_delta[2], init_gather=gather, tail_dst=tl)            # values: u; for autograd this node is `pos`
+        y = pos_mlp(rel, fc_delta, init_gather=gather)                         # values: u; for autograd this node is `pos`
+        if y is None:
+            tl = k4_tail(rel, fc_delta)
+            h = linear(rel, fc_delta[0], relu=True, tail_src=tl)
+            y = linear(h, fc_delta[2], init_gather=gather, tail_dst=tl)
         link = hip_attention.pos_grad_link() if y.requires_grad else None
         if link is not None and FUSE_DPOS:
             link.grad_sum = hip_linear.InputGradSum()

@@ -547,3 +547,84 @@ def test_batched_weight_gradient_reduce_is_bit_equal_to_the_one_call_form(dtype)
         hip_linear._OVERLAP_WGRAD, hip_linear.BATCH_REDUCE = was_o, was_b
     for a, b, c3 in zip(grads[16], grads[3], grads[0]):
         assert torch.equal(a, c3) and torch.equal(b, c3)
+
+
+def _pos_mlp_gather(M, d, form, seed):
+    """A gather tuple of hip_linear's init_gather protocol for M rows: form 1 = (queries per point, key table), 2 = one difference table."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    k, nsrc = 16, 100
+    shapes = max(M // 4096, 1)
+    rps = (M + shapes - 1) // shapes
+    rps += (-rps) % k
+    gk = torch.randn(shapes * nsrc, d, generator=g).to(DEV)
+    gidx = torch.randint(0, nsrc, (M,), generator=g, dtype=torch.int32).to(DEV)
+    if form == 2:
+        return (None, 1, gk, gidx, rps, nsrc)
+    gq = torch.randn((M + k - 1) // k, d, generator=g).to(DEV)
+    return (gq, k, gk, gidx, rps, nsrc)
+
+
+@pytest.mark.parametrize("k,d,M,bias,form", [(3, 200, 200_003, True, 2), (4, 256, 100_000, True, 1), (3, 256, 65_536 + 17, False, 0),
+                                             (3, 128, 70_000, True, 1), (3, 200, 40_000, True, 0), (4, 128, 262_144, True, 2),
+                                             (3, 256, 51_200, True, 1)])
+def test_position_encoding_mlp_without_its_hidden_tensor(k, d, M, bias, form, monkeypatch):
+    """hip_linear.pos_mlp: Linear(k, d) -> ReLU -> Linear(d, d) on coordinates that need no gradient, the hidden tensor recomputed
+    inside the second layer's GEMM (nsdp_linear_bf16x3_h0_f32) and inside its weight gradient (nsdp_linear_wgrad_bf16x3_h0_f32).
+    The producers evaluate the K = 4 layer with the forward kernel's own expression: output and all four parameter gradients are
+    BIT-equal to the two-layer path's, with and without the gathered addend, on whole and ragged row counts."""
+    from nsdp_amd import hip_linear
+    from nsdp_amd.model import ops
+    from test_model_gpu import _variant_trace
+    if (ops.PAIR_MASK or not hip_linear._PARAM_GRADS_DIRECT or not hip_linear.K4_LINK or not hip_linear.REMASK_K4
+            or not hip_linear._USE_X3 or not hip_linear.H0_RECOMPUTE):
+        pytest.skip("knob run: the recomputed form is off")
+    monkeypatch.setattr(hip_linear, "H0_RECOMPUTE", 2)      # (every shape the kernels support, not only where it pays)
+    torch.manual_seed(M + d + form)
+    seq = torch.nn.Sequential(torch.nn.Linear(k, d, bias=bias), torch.nn.ReLU(), torch.nn.Linear(d, d)).to(DEV)
+    x = torch.randn(M, k, device=DEV)
+    if k == 3:
+        x = torch.nn.functional.pad(x, (0, 1))      # (ops.relative_coords hands the rows over zero-padded)
+    t = torch.randn(M, d, device=DEV)
+    gather = _pos_mlp_gather(M, d, form, M) if form else None
+
+    def two_layers():
+        tl = ops.k4_tail(x, seq)
+        h = ops.linear(x, seq[0], relu=True, tail_src=tl)
+        return ops.linear(h, seq[2], init_gather=gather, tail_dst=tl)
+
+    with torch.no_grad(), _variant_trace() as names:
+        y_new = ops.pos_mlp(x, seq, init_gather=gather)
+    assert y_new is not None and any(n.startswith("linear_bf16x3<") and n.split("<")[1].split(",")[2] == "3" for n in names), names
+    with torch.no_grad():
+        y_old = two_layers()
+    assert torch.equal(y_new, y_old)
+    grads = []
+    for fn in (lambda: ops.pos_mlp(x, seq, init_gather=gather), two_layers, lambda: ops.pos_mlp(x, seq, init_gather=gather)):
+        seq.zero_grad()
+        y = fn()
+        assert torch.equal(y, y_old)
+        (y * t).sum().backward()
+        torch.cuda.synchronize()
+        grads.append([p.grad.clone() for p in seq.parameters()])
+    for a, b, c in zip(*grads):
+        assert torch.equal(a, b) and torch.equal(a, c), (a.shape, float((a - b).abs().max()))
+    # existing gradients: the launches add to them
+    (ops.pos_mlp(x, seq, init_gather=gather) * t).sum().backward()
+    for p, g in zip(seq.parameters(), grads[0]):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-5, atol=1e-5 * float(g.abs().max()))
+
+
+def test_position_encoding_mlp_falls_back_where_the_recomputed_form_does_not_apply(monkeypatch):
+    from nsdp_amd import hip_linear
+    from nsdp_amd.model import ops
+    if not hip_linear.H0_RECOMPUTE:
+        pytest.skip("knob run: the recomputed form is off")
+    monkeypatch.setattr(hip_linear, "H0_RECOMPUTE", 2)
+    seq = torch.nn.Sequential(torch.nn.Linear(3, 200), torch.nn.ReLU(), torch.nn.Linear(200, 200)).to(DEV)
+    x = torch.randn(70_000, 3, device=DEV)
+    assert ops.pos_mlp(x.clone().requires_grad_(True), seq) is None            # coordinates that need a gradient
+    assert ops.pos_mlp(x[:1000], seq) is None                                  # too few rows for the bf16x3 kernels
+    small = torch.nn.Sequential(torch.nn.Linear(3, 32), torch.nn.ReLU(), torch.nn.Linear(32, 32)).to(DEV)
+    assert ops.pos_mlp(x, small) is None                                       # one k block
+    y = ops.mlp2(x.clone().requires_grad_(True), seq)                          # ... and mlp2 still answers
+    assert y.shape == (70_000, 200) and y.requires_grad
