@@ -713,6 +713,107 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(WgradParams p) {
   }
 }
 
+// Output-stationary weight gradient for FEW rows (the 100-anchor level of an 8-shape batch: 800 rows, 35 layers per step).  The
+// row-split kernels above give every workgroup a chunk of rows and the WHOLE [N, K] output: at 800 rows that is 25 workgroups
+// writing 256 KiB of partial sums each (13 us of a 26 us launch at one CU's share of the HBM write rate) for a second kernel to
+// add up.  Here a workgroup owns a 32 x 32 block of dW and walks ALL rows: its sixteen waves take the 32-row blocks round-robin
+// (operands straight from L2: the two tensors are a few hundred KiB), their accumulators meet in LDS in fixed order, and the
+// block is written once -- no partials, no reduce launch, deterministic.  Exact-fp32 MFMA like the kernels it replaces.
+// Lane (li, g) feeds rows 4 s + g of a block to both operands (v_mfma_f32_16x16x4_f32: A[i = li][g], B[g][j = li]).
+template <bool MASK>
+__global__ __launch_bounds__(1024) void linear_wgrad_direct_kernel(WgradParams p, float *__restrict__ dW, float *__restrict__ db,
+                                                                   int accumulate) {
+  constexpr int WV = 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int N = p.N, K = p.K;
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  int na[2], kb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {      // columns past the edge re-read the last one (their results are never stored)
+    na[t] = n0 + 16 * t + li < N ? n0 + 16 * t + li : N - 1;
+    kb[t] = k0 + 16 * t + li < K ? k0 + 16 * t + li : K - 1;
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbs[2] = {0.f, 0.f};
+  const long long nblk = (p.M + 31) >> 5;
+  // no software pipeline: sixteen waves (four per SIMD) each take whole 32-row blocks -- 32 independent loads, then 32 MFMAs --
+  // and hide each other's L2 round trips; at 800 rows a wave sees one or two blocks
+  for (long long blk = wave; blk < nblk; blk += WV) {
+    float a[2][8], x[2][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const long long r = blk * 32 + 4 * s + g;
+      const bool rv = r < p.M;
+      const long long rc = rv ? r : p.M - 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float v = p.dY[rc * N + na[t]];
+        if constexpr (MASK) v = p.mask[rc * N + na[t]] > 0.f ? v : 0.f;
+        a[t][s] = rv ? v : 0.f;
+        const float xv = p.X[rc * K + kb[t]];
+        x[t][s] = p.relu_x ? fmaxf(xv, 0.f) : xv;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta][s], x[tb][s], acc[ta][tb], 0, 0, 0);
+      dbs[0] += a[0][s];
+      dbs[1] += a[1][s];
+    }
+  }
+  __shared__ f32x4 red[WV][4][64];
+  __shared__ float red_db[WV][32];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) red[wave][a * 2 + b][lane] = acc[a][b];
+  if (p.want_db && blockIdx.y == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float v = dbs[t];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (g == 0) red_db[wave][16 * t + li] = v;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {      // D layout: lane (li, g) of tile (a, b) holds dW[n0 + 16 a + 4 g + r][k0 + 16 b + li], r = 0..3
+    const int tt = threadIdx.x >> 6, l = threadIdx.x & 63;
+    f32x4 t = red[0][tt][l];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) t += red[w][tt][l];      // fixed order: deterministic
+    const int k = k0 + 16 * (tt & 1) + (l & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * (tt >> 1) + 4 * (l >> 4) + r;
+      if (n < N && k < K) {
+        float *o = dW + static_cast<long long>(n) * K + k;
+        *o = accumulate ? *o + t[r] : t[r];
+      }
+    }
+  } else if (threadIdx.x < 288 && p.want_db && blockIdx.y == 0) {
+    const int c = threadIdx.x - 256;
+    float t = red_db[0][c];
+#pragma unroll
+    for (int w = 1; w < WV; ++w) t += red_db[w][c];
+    if (n0 + c < N) db[n0 + c] = accumulate ? db[n0 + c] + t : t;
+  }
+}
+// rows up to which the output-stationary form runs (NSDP_WGRAD_DIRECT_ROWS, 0 = never; read once)
+inline long long wgrad_direct_rows() {
+  static const long long v = getenv("NSDP_WGRAD_DIRECT_ROWS") ? atoll(getenv("NSDP_WGRAD_DIRECT_ROWS")) : 2048;
+  return v;
+}
+inline bool wgrad_direct_ok(long long M, int N, int K) { return M > 0 && M <= wgrad_direct_rows() && K > 4 && N >= 16 && K >= 16; }
+
 int g_wgrad_vec4 = 1;  // nsdp_debug_set(5, v): 1 = float4-operand weight-gradient kernel (default), 0 = dword form
 int g_wgrad_pipe = 0;  // measured on MI355X: the register-lean form wins at every layer shape of the path
                        // (52-65 vs 38-48 TF); 1 = software-pipelined form (nsdp_debug_set(1, v))
@@ -1070,7 +1171,7 @@ struct WgradPlan {
 WgradPlan plan_wgrad(long long M, int N, int K) {
   const int ktiles = (K + 15) / 16;
   WgradPlan pl;
-  pl.vec4 = (g_wgrad_vec4 != 0) && K > 16 && (N % 4 == 0) && (K % 4 == 0) && N >= 4;
+  pl.vec4 = (g_wgrad_vec4 != 0) && K > 16 && K <= 256 && (N % 4 == 0) && (K % 4 == 0) && N >= 4;      // (K > 256: more k parts than the float4 form's eight waves)
   long long slots_per_chunk = 1;
   if (pl.vec4) {
     const int kgroups = (K + 63) / 64;
@@ -1144,6 +1245,16 @@ static int wgrad_f32_impl(const float *dY, const float *X, const float *mask, co
   NSDP_REQUIRE(dY && X && workspace, "linear_wgrad: null pointer");
   NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_workspace_bytes(M, N, K),
                "linear_wgrad: workspace too small");
+  if (!remask_W && wgrad_direct_ok(M, N, K)) {      // few rows: one launch, no partial sums (desc_out: nothing left to reduce, S = 0)
+    WgradParams p{dY, X, mask, relu_x, workspace, M, N, K, 32, db != nullptr};
+    nsdp::prof::Scope scope(nsdp::prof::kWgrad, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
+    const dim3 grid((N + 31) / 32, (K + 31) / 32);
+    NSDP_TRACE("linear_wgrad_direct<%s>", mask ? "mask" : "plain");
+    if (mask) hipLaunchKernelGGL((linear_wgrad_direct_kernel<true>), grid, dim3(1024), 0, st, p, dW, db, accumulate);
+    else hipLaunchKernelGGL((linear_wgrad_direct_kernel<false>), grid, dim3(1024), 0, st, p, dW, db, accumulate);
+    if (desc_out) *desc_out = NsdpWgradB16ReduceDesc{workspace, dW, db, 0, N, K, accumulate ? 1 : 0, 0};
+    return nsdp::launch_status("linear_wgrad_direct_kernel");
+  }
   const WgradPlan pl = plan_wgrad(M, N, K);
   const long long chunks = pl.chunks, rows = pl.rows;
   WgradParams p{dY, X, mask, relu_x, workspace, M, N, K, rows, db != nullptr};

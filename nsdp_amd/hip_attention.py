@@ -73,6 +73,8 @@ def inverse_lists(idx, N):
     capture is running the cache is neither read nor written: the list build must be a node of the graph (a replay sees
     new index contents at the same address and version), and lists built for a capture must not outlive it."""
     capturing = idx.is_cuda and torch.cuda.is_current_stream_capturing()
+    if os.environ.get("NSDP_GEOMETRY_ABLATE", "0") == "1":      # (timing-only ablation, see model/ops.py: lists outlive the capture)
+        capturing = False
     cache = idx.__dict__.setdefault("_nsdp_inverse", {}) if (hasattr(idx, "__dict__") and not capturing) else {}
     key = (N, idx.data_ptr(), idx._version)
     hit = cache.get(key)

@@ -164,6 +164,8 @@ def _wgrad(dy2, x2, mask, relu_x, want_db, out=None):
                                                    optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws),
                                                    ctypes.c_size_t(nbytes), ctypes.byref(desc), stream_ptr()),
                   "nsdp_linear_wgrad_partials_f32")
+            if desc.S == 0:          # few rows: the output-stationary kernel wrote dW / db itself, nothing is pending
+                return dw, db
             batch["descs_b16"].append(desc)
             batch["keep"].append((ws, dw, db))
             batch["targets"] |= ptrs

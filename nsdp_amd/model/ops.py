@@ -19,8 +19,20 @@ from .. import pointnet2_utils as pu
 # ---------------------------------------------------------------------------------------------
 # geometry (hand-written HIP, non-differentiable exactly like the reference's no_grad blocks)
 # ---------------------------------------------------------------------------------------------
+# ABLATION, timing only (NSDP_GEOMETRY_ABLATE=1): every index set is computed once per (input address, shape) and reused -- what a
+# step costs when no search, sampling or list build is on its chain (the ceiling of pipelining the next batch's geometry under
+# the current step).  Results are those of the first batch: never for training.
+_GEOMETRY_ABLATE = os.environ.get("NSDP_GEOMETRY_ABLATE", "0") == "1"
+_ablate_cache = {}
+
+
 @torch.no_grad()
 def knn_indices(query: torch.Tensor, source: torch.Tensor, k: int) -> torch.Tensor:
+    if _GEOMETRY_ABLATE:
+        key = ("knn", tuple(query.shape), tuple(source.shape), k)      # (by shape: the bench feeds the same batch)
+        if key not in _ablate_cache:
+            _ablate_cache[key] = pu.knn(query.detach().contiguous(), source.detach().contiguous(), k)
+        return _ablate_cache[key]
     return pu.knn(query.detach().contiguous(), source.detach().contiguous(), k)
 
 
@@ -71,6 +83,10 @@ def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True, dims=
     a list build is one workgroup per shape (48 us at 32 shapes) that the forward chain otherwise waits for.
     Returns a list of dicts {fps_idx, new_xyz, sa_idx, blk_idx[, sa_inv, blk_inv]} and the event-free join handle (call
     ``join()`` on the consumer stream before the first use)."""
+    if _GEOMETRY_ABLATE:
+        key = ("pyramid", tuple(xyz.shape), tuple(npoints), tuple(ks), None if dims is None else tuple(dims))
+        if key in _ablate_cache:
+            return _ablate_cache[key], (lambda: None)
     main = torch.cuda.current_stream(xyz.device)
     side = _side_stream(xyz.device) if overlap else main
     if overlap:
@@ -92,6 +108,9 @@ def geometry_pyramid(xyz: torch.Tensor, npoints, ks, overlap: bool = True, dims=
                     lv["blk_inv"] = hip_attention.inverse_lists(blk_idx, n_new)
             levels.append(lv)
             cur = new_xyz
+
+    if _GEOMETRY_ABLATE and not torch.cuda.is_current_stream_capturing():
+        _ablate_cache[key] = levels
 
     def join():
         if overlap:

@@ -628,3 +628,33 @@ def test_position_encoding_mlp_falls_back_where_the_recomputed_form_does_not_app
     assert ops.pos_mlp(x, small) is None                                       # one k block
     y = ops.mlp2(x.clone().requires_grad_(True), seq)                          # ... and mlp2 still answers
     assert y.shape == (70_000, 200) and y.requires_grad
+
+
+@pytest.mark.parametrize("M,N,K,mask,relu_x", [(800, 256, 256, False, False), (777, 200, 120, True, False), (33, 40, 24, False, True),
+                                              (2047, 120, 256, True, True), (1, 16, 16, False, False), (1999, 72, 200, False, False)])
+def test_output_stationary_weight_gradient_for_few_rows(M, N, K, mask, relu_x):
+    """linear_wgrad_direct_kernel (csrc/gemm.hip): up to 2048 rows a workgroup owns a 32 x 32 block of dW and walks all rows -- one
+    launch, no partial sums.  Against fp64 on whole and ragged shapes, with the ReLU mask / input ReLU, bias gradient, in-place
+    accumulation; bit-equal between two runs (fixed summation order)."""
+    from nsdp_amd import hip_linear
+    from test_model_gpu import _variant_trace
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N + K)
+    dy = torch.randn(M, N, generator=g).to(DEV)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    mk = torch.randn(M, N, generator=g).to(DEV) if mask else None
+    with _variant_trace() as names:
+        dw, db = hip_linear._wgrad(dy, x, mk, relu_x, True)
+    if os.environ.get("NSDP_WGRAD_DIRECT_ROWS", "2048") != "0":
+        assert any(n.startswith("linear_wgrad_direct") for n in names), names
+    dyr = dy.double() * (mk > 0) if mask else dy.double()
+    xr = x.double().clamp_min(0) if relu_x else x.double()
+    rw, rb = dyr.t() @ xr, dyr.sum(0)
+    assert float((dw.double() - rw).abs().max()) <= 2e-6 * (float(rw.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 8)
+    assert float((db.double() - rb).abs().max()) <= 2e-6 * (float(rb.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 8)
+    dw2, db2 = hip_linear._wgrad(dy, x, mk, relu_x, True)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    acc_w, acc_b = dw.clone(), db.clone()
+    got = hip_linear._wgrad(dy, x, mk, relu_x, True, out=(acc_w, acc_b))
+    assert got[0] is acc_w
+    assert torch.allclose(acc_w, 2 * dw, rtol=1e-6, atol=1e-6 * float(dw.abs().max()))
+    assert torch.allclose(acc_b, 2 * db, rtol=1e-6, atol=1e-6 * float(db.abs().max()))
