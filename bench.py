@@ -263,6 +263,13 @@ def main():
                          "(nsdp_amd/graph_step.py: one C call per step instead of ~1000 Python-enqueued launches; same "
                          "kernels, same stream schedule, same numbers step for step)")
     ap.add_argument("--graph", action="store_true", help="(the default; kept for symmetry with --eager)")
+    ap.add_argument("--geometry", default="inline", choices=["pipelined", "inline"],
+                    help="inline (default): the step searches inside its forward pass, like the reference.  pipelined (replayed "
+                         "TDNet steps): every step computes the NEXT batch's index sets (FPS, kNN, inverse lists: functions of "
+                         "the batch, not of the weights) on a stream of its own beside its forward pass and takes its own from "
+                         "the previous step (nsdp_amd.graph_step.PipelinedGeometry) -- the same searches once per step, results "
+                         "bit-identical.  Measured: eval B = 8 4.40 -> 4.26 ms, train steps unchanged (the searches still cost "
+                         "their chip time; only the sampling chain's latency leaves the critical path)")
     ap.add_argument("--stub-step", action="store_true",
                     help="replace the TDNet step by a tiny CPU model (tests of the launch / rendezvous / all-reduce / "
                          "timing / JSON plumbing on a box without GPUs; the line says so and is not a measurement)")
@@ -362,19 +369,39 @@ def main():
     data = {k: torch.from_numpy(v).to(device)
             for k, v in synth.make_batch(1000 + rank, args.batch, N_SURF, n_query).items()}
 
+    # The next batch's geometry beside the current step (see --geometry).  The synthetic "next batch" is a second static copy of
+    # the same tensors: every step runs the whole search for it, nothing is carried over but the index sets the previous step
+    # computed for THIS one.
+    pipe = data_next = None
+    if (args.geometry == "pipelined" and not args.eager and args.workload != "arbitrary_train" and hasattr(model, "geometry")
+            and not args.stub_step):
+        from nsdp_amd.graph_step import PipelinedGeometry
+        data_next = {k: v.clone() for k, v in data.items()}
+        pipe = PipelinedGeometry(model, lambda d: (d["space_samples_src"], d["surface_samples_inputs"]))
+        pipe.prime(data, training=not is_eval)
+
     def forward():
         if args.workload == "arbitrary_train":
             s_in = data["surface_samples_inputs"]
             return model(data["space_samples_src"], s_in[:, :, 0:3], s_in[:, :, 3:6], s_in[:, :, 6:7])
+        if pipe is not None:
+            return model(data["space_samples_src"], data["surface_samples_inputs"], geometry=pipe.current)
         return model(data["space_samples_src"], data["surface_samples_inputs"])
 
     def infer_step():
+        if pipe is not None:
+            pipe.prefetch(data_next)
         with torch.no_grad():
-            return forward().sum()
+            out = forward().sum()
+        if pipe is not None:
+            pipe.rotate()
+        return out
 
     def step():
         # train_on_batch_with_cano (reference model/deformation_networks.py:63-77); the loss scalar is
         # read back after the timed region instead of per step (loss.item() is a pure host sync).
+        if pipe is not None:
+            pipe.prefetch(data_next)
         if reducer is not None:
             reducer.zero_grad()
         else:
@@ -385,6 +412,8 @@ def main():
         if reducer is not None:
             exchange()
         optimizer.step()
+        if pipe is not None:
+            pipe.rotate()
         return loss
 
     def fence():
@@ -406,7 +435,9 @@ def main():
             if not is_eval:
                 capturable_adam(optimizer)
             if is_eval or reducer is None:
-                graph = GraphedStep(run, weights_change=not is_eval).capture(warmup=3)      # (inference: frozen weights)
+                # (pipelined geometry: a third executor stream -- the search is captured first and would otherwise be taken
+                # for the main chain, leaving the step and its weight gradients to share the one side stream)
+                graph = GraphedStep(run, weights_change=not is_eval, max_streams=3 if pipe is not None else None).capture(warmup=3)      # (inference: frozen weights)
                 run = graph
                 graph_note = "graph replay, multi-stream executor: " + json.dumps(graph.info)
             else:
@@ -414,11 +445,15 @@ def main():
                     step()
 
                 def fwd_bwd():
+                    if pipe is not None:
+                        pipe.prefetch(data_next)
                     reducer.zero_grad()
                     loss = compute_l2_error(forward(), data["space_samples_tgt"])
                     loss.backward()
+                    if pipe is not None:
+                        pipe.rotate()
                     return loss
-                g1 = GraphedStep(fwd_bwd).capture(warmup=0)
+                g1 = GraphedStep(fwd_bwd, max_streams=3 if pipe is not None else None).capture(warmup=0)
                 reducer.all_reduce_mean()
                 g2 = GraphedStep(lambda: optimizer.step()).capture(warmup=0)
                 graph = g1
@@ -576,6 +611,9 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * t_enqueued / args.steps, 3),
             "host_enqueue_unblocked_ms": round(1e3 * host_unblocked, 3),
             "step_launch": graph_note,
+            "geometry": ("pipelined: every step computes the next batch's index sets (FPS, kNN, inverse lists) beside its forward "
+                         "pass and uses the ones the previous step computed for it" if pipe is not None else
+                         "inline: searched inside the step's forward pass"),
             "cpu_mask": cpu_mask,
             "parity_l2_vs_fp32": parity,
             "comm": {"backend": (dist.get_backend() if dist.is_initialized() else None),

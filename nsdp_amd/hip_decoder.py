@@ -107,10 +107,13 @@ def decoder_forward(dec, xyz_q: torch.Tensor, encoding: dict) -> torch.Tensor:
     ct = dec.ct1
     B, NQ, _ = xyz_q.shape
     A = anchors.shape[1]
+    xyz_q_in = xyz_q
     xyz_q = xyz_q.contiguous().float()
     anchors = anchors.contiguous().float()
     with torch.no_grad(), _lib.on_device(xyz_q):
-        idx = pointnet2_utils.knn(xyz_q, anchors, ct.nneigh)                    # [B,NQ,k] int32
+        idx = encoding.get("query_idx") if encoding.get("query_points") is xyz_q_in else None      # (searched ahead: Deformation_Networks.geometry)
+        if idx is None:
+            idx = pointnet2_utils.knn(xyz_q, anchors, ct.nneigh)                # [B,NQ,k] int32
         tb = pack.tables
         lin = lambda x, w, *a, **k: hip_linear.linear(x, w, *a, pack_owner=w, **k)      # (constant tables: packs cached on them)
         q = lin(z, tb["w_qs"])                                                  # [B,DP] (pad channels = 0)

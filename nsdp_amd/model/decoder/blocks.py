@@ -61,7 +61,9 @@ class CrossTransformerBlock(nn.Module):
                 hip_linear.lib().nsdp_debug_set(9, 0)
         return {"xyz_q": xyz_q, "xyz": xyz, "idx": idx, "rel": rel, "pos": pos, "stream": s}
 
-    def forward(self, xyz_q, lat_rep, xyz, points, prefetched=None):
+    def forward(self, xyz_q, lat_rep, xyz, points, prefetched=None, idx=None):
+        """``idx`` [B,NQ,k] int32: the queries' anchor neighbours when the caller searched ahead of this pass
+        (Deformation_Networks.geometry), else searched here."""
         assert lat_rep.dim() == 2, "per-query latent codes are not used by any NSDP configuration"
         pos = None
         if prefetched is not None and prefetched["xyz_q"] is xyz_q and prefetched["xyz"] is xyz:
@@ -70,7 +72,7 @@ class CrossTransformerBlock(nn.Module):
             idx, rel, pos = prefetched["idx"], prefetched["rel"], prefetched["pos"]
             for t in (idx, rel, pos):
                 t.record_stream(main)
-        else:
+        elif idx is None:
             idx = ops.knn_indices(xyz_q, xyz, self.nneigh)                   # [B,NQ,k]
         q = ops.linear(lat_rep, self.w_qs)                                   # [B,D]  (shared by all queries)
         k_g = ops.linear(lat_rep, self.w_k_global)

@@ -33,12 +33,24 @@ class CrossTransformerDecoder(nn.Module):
             return None
         return self.ct1.prefetch(xyz_q, anchors, after)
 
+    @staticmethod
+    def _query_idx(xyz_q, encoding):
+        """The anchor neighbours searched ahead of the pass (encoding['query_idx'], Deformation_Networks.geometry) if they are
+        these queries' (encoding['query_points'] is xyz_q)."""
+        return encoding.get("query_idx") if encoding.get("query_points") is xyz_q else None
+
+    @torch.no_grad()
+    def geometry(self, xyz_q, anchors):
+        """The index set forward() derives from coordinates alone: each query's nearest anchors."""
+        return {"query_idx": ops.knn_indices(xyz_q, anchors, self.ct1.nneigh)}
+
     def forward(self, xyz_q, encoding):
         if (hip_decoder.ENABLED and not torch.is_grad_enabled() and hip_decoder.supported(self)
                 and not precision.is_bf16()):
             # inference: kNN + one fused kernel (18 dense layers + softmax in registers), nsdp_decoder_fused_fwd
             return hip_decoder.decoder_forward(self, xyz_q, encoding)
-        lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"], prefetched=encoding.get("prefetch"))
+        lat = self.ct1(xyz_q, encoding["z"], encoding["anchors"], encoding["anchor_feats"], prefetched=encoding.get("prefetch"),
+                       idx=self._query_idx(xyz_q, encoding))
         if precision.is_bf16() and TRUNK_F32:
             # bf16 storage keeps the [B, NQ, 7, 200] tensors of the attention block in bf16 -- 7 x the rows and 1.6 x the width
             # of the trunk -- while the residual stream `net` (128 wide, one row per query: the tensor that accumulates six

@@ -38,13 +38,32 @@ class Deformation_Networks(nn.Module):
             has_features=has_features, inp_feat_dim=inp_feat_dim, **cfg["model"]["encoder_kwargs"])
         self.decoder = decoder_dict[cfg["model"]["decoder"]](**cfg["model"]["decoder_kwargs"])
 
-    def encode(self, surface_samples_inputs, queries=None):
+    @torch.no_grad()
+    def geometry(self, points, surface_samples_inputs, training=None):
+        """Every index set forward(points, surface_samples_inputs) derives from its two coordinate inputs alone (the encoder's
+        sampling / grouping pyramid and neighbour sets, the queries' anchor neighbours, the inverse lists of the backward pass
+        when ``training``), on the current stream.  forward(geometry=) takes it instead of searching: a host that knows the next
+        batch computes this beside the current step (nsdp_amd.graph_step.PipelinedGeometry) -- FPS is a chain of ~600 dependent
+        iterations that no batch size shortens.  ``points`` must be the very tensor forward() is then called with."""
+        x = surface_samples_inputs[:, :, 0:3].contiguous() if self.no_input_corr else surface_samples_inputs
+        if not (hasattr(self.encoder, "geometry") and hasattr(self.decoder, "geometry")):
+            raise NotImplementedError("geometry(): this encoder / decoder pair searches inside its forward pass only")
+        g = {"encoder": self.encoder.geometry(x, training)}
+        g.update(self.decoder.geometry(points, g["encoder"]["anchors"]))
+        g["query_points"] = points
+        return g
+
+    def encode(self, surface_samples_inputs, queries=None, geometry=None):
         """The encoding {'z', 'anchors', 'anchor_feats'} of a surface cloud -- the half of forward() that does not depend on
         the query points.  Callers that decode several query sets against ONE cloud (FlowArbitrary, the dense-inference step
         functions) encode once and call decode() per set; the reference re-runs the whole module each time.
         ``queries``: the points decode() will be called with next -- the decoder's anchor-only work is then launched beside the
         encoder's forward chain (CrossTransformerDecoder.prefetch, NSDP_DECODER_PREFETCH=0 switches it off)."""
         x = surface_samples_inputs[:, :, 0:3].contiguous() if self.no_input_corr else surface_samples_inputs
+        if geometry is not None:
+            enc = self.encoder(x, geometry=geometry["encoder"])
+            enc["query_idx"], enc["query_points"] = geometry["query_idx"], geometry["query_points"]
+            return enc
         if (DECODER_PREFETCH and queries is not None and queries.is_cuda and hasattr(self.decoder, "prefetch")
                 and "on_anchors" in inspect.signature(self.encoder.forward).parameters):
             return self.encoder(x, on_anchors=lambda anchors, after: self.decoder.prefetch(queries, anchors, after))
@@ -53,22 +72,26 @@ class Deformation_Networks(nn.Module):
     def decode(self, points, encoding):
         return self.decoder(points, encoding)
 
-    def forward(self, points, surface_samples_inputs):
+    def forward(self, points, surface_samples_inputs, geometry=None):
         points = points if points.is_contiguous() else points.contiguous()
-        return self.decoder(points, self.encode(surface_samples_inputs, queries=points))
+        return self.decoder(points, self.encode(surface_samples_inputs, queries=points, geometry=geometry))
 
 
-def _loss_with_cano(model, data_dict, config):
-    """forward + l2 loss of train_on_batch_with_cano (reference :66-72), as a tensor."""
-    pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
+def _loss_with_cano(model, data_dict, config, geometry=None):
+    """forward + l2 loss of train_on_batch_with_cano (reference :66-72), as a tensor.  ``geometry``: model.geometry() of this
+    batch's inputs, computed ahead of the step."""
+    if geometry is not None:
+        pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"], geometry=geometry)
+    else:
+        pred = model(data_dict["space_samples_src"], data_dict["surface_samples_inputs"])
     return compute_l2_error(pred, data_dict["space_samples_tgt"])
 
 
-def _train_step_with_cano(model, optimizer, data_dict, config):
+def _train_step_with_cano(model, optimizer, data_dict, config, geometry=None):
     """The step of train_on_batch_with_cano up to (not including) the host read-back of the loss: everything that is
     enqueued on the GPU.  This is what nsdp_amd.graph_step captures and replays."""
     optimizer.zero_grad()
-    loss = _loss_with_cano(model, data_dict, config)
+    loss = _loss_with_cano(model, data_dict, config, geometry)
     loss.backward()
     optimizer.step()
     return loss

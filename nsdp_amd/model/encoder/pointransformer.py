@@ -41,25 +41,61 @@ class PointTransformerEncoder(nn.Module):
         self.final_elementwise = nn.ModuleList(
             [ElementwiseMLP(dim=d_transformer) for _ in range(nfinal_transformers)])
 
-    def forward(self, xyz, on_anchors=None):
+    def _pyramid_args(self):
+        return ([td.sa.npoint for td in self.transition_downs],
+                [(td.sa.nneigh, None if tb.group_all else tb.k) for td, tb in zip(self.transition_downs, self.transformer_downs)],
+                [self.d_reduced] + [self.d_transformer] * (len(self.transition_downs) - 1))
+
+    @torch.no_grad()
+    def geometry(self, xyz, training=None):
+        """Every index set forward() derives from the COORDINATES alone -- the first block's neighbours, the sampling / grouping
+        pyramid, the final blocks' neighbours and (``training``: default = grad mode) the inverse lists their backward passes
+        scatter through -- computed on the current stream, as a dict forward(geometry=) takes instead of searching itself.
+        Nothing in it depends on a parameter: a host that knows the NEXT batch computes it beside the current step
+        (nsdp_amd.graph_step.PipelinedGeometry); the reference searches inside every forward (model/encoder/blocks.py:97-99,
+        :283-288)."""
+        training = torch.is_grad_enabled() if training is None else bool(training)
+        coords = (xyz[:, :, :3] if self.has_features else xyz).detach().contiguous()
+        npoints, ks, dims = self._pyramid_args()
+        g = {}
+        tb = self.transformer_begin
+        if not tb.group_all:
+            g["begin_idx"] = ops.knn_indices(coords, coords, tb.k)
+            if training and not tb.pos_only:
+                g["begin_inv"] = ops.attention_lists(g["begin_idx"], coords.shape[1], coords.shape[1], self.d_reduced)
+        levels, _ = ops.geometry_pyramid(coords, npoints, ks, overlap=False, dims=dims if training else None)
+        g["levels"] = levels
+        last = levels[-1]["new_xyz"] if levels else coords
+        blk = next((b for b in self.final_transformers if not b.group_all), None)
+        if blk is not None:
+            g["final_idx"] = ops.knn_indices(last, last, blk.k)
+            if training:
+                g["final_inv"] = ops.attention_lists(g["final_idx"], last.shape[1], last.shape[1], self.d_transformer)
+        g["anchors"] = last
+        return g
+
+    def forward(self, xyz, on_anchors=None, geometry=None):
         """``on_anchors(anchors, after)``: called as soon as the anchor coordinates (the last level of the geometry pyramid) are
         ENQUEUED -- on the pyramid's stream ``after``, ~1 ms into a step -- so that work which needs nothing else of the encoding
         (the decoder's anchor search and position encoding, CrossTransformerDecoder.prefetch) can be launched beside the
         encoder's forward chain.  Whatever it returns travels in the encoding as ``'prefetch'``."""
         coords = xyz[:, :, :3].contiguous() if self.has_features else xyz
         # all FPS / kNN index tensors of the pyramid, launched on a side stream under transformer_begin
-        levels, join = ops.geometry_pyramid(
-            coords, [td.sa.npoint for td in self.transition_downs],
-            [(td.sa.nneigh, None if tb.group_all else tb.k)
-             for td, tb in zip(self.transition_downs, self.transformer_downs)],
-            dims=([self.d_reduced] + [self.d_transformer] * (len(self.transition_downs) - 1)) if torch.is_grad_enabled() else None)
-        prefetch = on_anchors(levels[-1]["new_xyz"], ops.geometry_stream(coords.device)) if (on_anchors and levels) else None
+        begin = {}
+        if geometry is not None:      # (geometry(): the index sets were computed ahead of this pass)
+            levels, join = geometry["levels"], (lambda: None)
+            begin = {"idx": geometry.get("begin_idx"), "inv": geometry.get("begin_inv")}
+        else:
+            npoints, ks, dims = self._pyramid_args()
+            levels, join = ops.geometry_pyramid(coords, npoints, ks, dims=dims if torch.is_grad_enabled() else None)
+        prefetch = (on_anchors(levels[-1]["new_xyz"], ops.geometry_stream(coords.device))
+                    if (on_anchors and levels and geometry is None) else None)
         if self.has_features:
             feats = ops.linear(xyz[:, :, 3:], self.enc_sdf)
             xyz = coords
-            feats = self.transformer_begin(xyz, feats)
+            feats = self.transformer_begin(xyz, feats, **begin)
         else:
-            feats = self.transformer_begin(xyz)
+            feats = self.transformer_begin(xyz, **begin)
         join()
         for i in range(len(self.transition_downs)):
             xyz, feats = self.transition_downs[i](xyz, feats, levels[i])
@@ -68,11 +104,13 @@ class PointTransformerEncoder(nn.Module):
             if i == 0 and self.d_reduced != self.d_transformer:
                 feats = ops.linear(feats, self.fc1)
             feats = self.elementwise[i](feats)
-        final_idx = None      # the final blocks all search the same cloud with the same k: one kNN (and one inverse list) for all
+        # the final blocks all search the same cloud with the same k: one kNN (and one inverse list) for all
+        final_idx = geometry.get("final_idx") if geometry is not None else None
+        final_inv = geometry.get("final_inv") if geometry is not None else None
         for blk, mlp in zip(self.final_transformers, self.final_elementwise):
             if final_idx is None and not blk.group_all:
                 final_idx = ops.knn_indices(xyz, xyz, blk.k)
-            feats = mlp(blk(xyz, feats, idx=final_idx))
+            feats = mlp(blk(xyz, feats, idx=None if blk.group_all else final_idx, inv=None if blk.group_all else final_inv))
         lat_vec = feats.max(dim=1)[0]
         enc = {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}
         if prefetch is not None:

@@ -41,6 +41,15 @@ def fps_indices(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
     return pu.furthest_point_sample(xyz.detach().contiguous(), npoint)
 
 
+def attention_lists(idx: torch.Tensor, n: int, N: int, d: int, per_shape_query: bool = False):
+    """The inverse neighbour lists the BACKWARD pass of a d-wide attention block over ``idx`` [B,n,k] (sources: N) scatters
+    through (hip_attention._use_inverse decides whether it uses any), or None -- for callers that prepare a block's geometry
+    outside its forward pass, where grad mode says nothing."""
+    if not hip_attention._use_inverse(torch.float32, per_shape_query, n, N, d):
+        return None
+    return hip_attention.inverse_lists(idx, N)
+
+
 _side_streams = {}
 # inverse neighbour lists of the pyramid's index sets built on the geometry stream (A/B knob: 0 = by the attention blocks, on
 # the forward chain)

@@ -68,9 +68,16 @@ def fit(model, fns, lr_scheduler, optimizer, train_loader, val_loader, config, e
         adjust_learning_rate(lr_scheduler, optimizer, i)
         model.train()
         avg = _Average()
-        for b, sample in enumerate(train_loader if dp is None else dp.shard(train_loader)):
-            sample = {k: v.to(device) for k, v in sample.items()}
-            avg.add(train_on_batch(model, optimizer, sample, config))
+        if getattr(train_on_batch, "accepts_next_batch", False):
+            # one batch of look-ahead: the step computes the NEXT batch's index sets beside itself (graph_step.PipelinedGeometry)
+            nxt = None
+            for sample in _with_next(train_loader if dp is None else dp.shard(train_loader), device):
+                cur, nxt = sample
+                avg.add(train_on_batch(model, optimizer, cur, config, next_data_dict=nxt))
+        else:
+            for b, sample in enumerate(train_loader if dp is None else dp.shard(train_loader)):
+                sample = {k: v.to(device) for k, v in sample.items()}
+                avg.add(train_on_batch(model, optimizer, sample, config))
         epoch_loss = avg.value if dp is None else dp.mean(avg.value, device)
         if main:
             log("epoch: {} - batches: {} - loss: {:.5f}".format(i + 1, avg.count, epoch_loss))
@@ -95,6 +102,20 @@ def fit(model, fns, lr_scheduler, optimizer, train_loader, val_loader, config, e
                     save_best_checkpoints(i, model, experiment_directory, val_loss)
                 args.best_val_loss = val_loss
     return history
+
+
+def _with_next(loader, device):
+    """(batch, next batch or None) pairs of ``loader``, both on ``device``."""
+    it = iter(loader)
+    try:
+        cur = {k: v.to(device) for k, v in next(it).items()}
+    except StopIteration:
+        return
+    for sample in it:
+        nxt = {k: v.to(device) for k, v in sample.items()}
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
 
 
 class SyntheticLoader:

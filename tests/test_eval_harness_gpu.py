@@ -151,3 +151,48 @@ def test_prepare_batch_matches_oracle(inverse, noise_level):
         np.testing.assert_array_equal(out["space_samples_src"][b].cpu().numpy(), src_space)
     # every index set is a permutation prefix: unique rows
     assert all(len(set(surf_idx[b].tolist())) == 512 for b in range(B))
+
+
+@pytest.mark.gpu
+def test_harness_with_the_next_batch_s_geometry_pipelined_under_the_step(tmp_path):
+    """GraphedTrainOnBatch(pipeline_geometry=): every replay takes its index sets (FPS, kNN, inverse lists) from
+    graph_step.PipelinedGeometry and computes the NEXT batch's on a stream of its own; fit() looks one batch ahead.  The searches
+    are the same searches -- only when they run changes -- so the loop is held EQUAL, epoch loss by epoch loss, to the eager
+    loop: across epoch boundaries (no next batch announced: the step primes eagerly), odd-shape eager batches and validation
+    passes in between."""
+    from helpers import nondeterministic_knobs
+    if nondeterministic_knobs():
+        pytest.skip("the step is not bit-reproducible under " + ", ".join(nondeterministic_knobs()))
+    from nsdp_amd.graph_step import GraphedTrainOnBatch, capturable_adam
+    from nsdp_amd.model import build_model, optimizer_factory
+    cfg = model_cfg("forward", [256, 64, 16])
+    cfg["training"] = {"epochs": 4, "save_frequency": 2, "optimizer": "Adam", "lr": 5e-4, "lr_step": 2,
+                       "lr_decay": 0.1, "weight_decay": 0.0}
+    cfg["validation"] = {"frequency": 2}
+    hists, fns = [], []
+    for mode in ("eager", "piped"):
+        train.seed_everything(27)
+        model, train_fn, val_fn, _ = build_model(cfg, device=DEV)
+        sched, opt = optimizer_factory(cfg["training"], model.parameters())
+        loader = train.SyntheticLoader(3, 4, 2, n_surf=256, n_query=128)
+        odd = train.SyntheticLoader(9, 1, 1, n_surf=256, n_query=128)
+        both = list(loader)[:2] + list(odd) + list(loader)[2:]          # the odd-shape batch in the MIDDLE of every epoch
+        capturable_adam(opt)
+        fn = train_fn if mode == "eager" else GraphedTrainOnBatch(
+            train_fn, pipeline_geometry=lambda d: (d["space_samples_src"], d["surface_samples_inputs"]))
+        args = argparse.Namespace(continue_from_epoch=0, best_val_loss=float("inf"))
+        sub = tmp_path / mode
+        sub.mkdir()
+        hists.append(train.fit(model, (fn, val_fn), sched, opt, both, loader, cfg, str(sub), args, DEV, log=lambda *_: None))
+        fns.append(fn)
+    fn = fns[1]
+    assert fn.accepts_next_batch and fn._pipe is not None
+    assert fn.replays == 4 * 4 - 1 and fn.eager_calls == 4 + 1
+    # announced: batch 2 of an epoch (after batch 1) and batch 4 (after batch 3, announced through the odd one? no: the odd batch
+    # is announced to batch 2's replay and does not match the static shapes) -- what matters is that every unannounced batch primed
+    assert 1 <= fn.unannounced <= fn.replays
+    e = [h[2] for h in hists[0] if h[0] == "train"]
+    g = [h[2] for h in hists[1] if h[0] == "train"]
+    assert len(e) == len(g) == 4 and e == g, (e, g)
+    ve, vg = [h[2] for h in hists[0] if h[0] == "val"], [h[2] for h in hists[1] if h[0] == "val"]
+    assert ve == vg and len(ve) >= 1, (ve, vg)
