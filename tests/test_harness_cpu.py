@@ -164,3 +164,32 @@ def test_loader_side_sharding_equals_every_world_th_batch():
                 assert a is b
             ids = [id(b) for b in loader.batches]
             assert [ids.index(id(a)) for a in own] == [g * world + rank for g in range(7 // world)]
+
+
+def test_one_batch_look_ahead_and_the_geometry_hand_over_protocol():
+    """Host logic of the pipelined-geometry step (graph_step.PipelinedGeometry / GraphedTrainOnBatch, train._with_next): the
+    look-ahead pairs every batch with its successor; a bundle's tensors are enumerated once each in a fixed order with the query
+    points (an INPUT) left out; an announced batch is recognised by identity AND version."""
+    import torch
+    from nsdp_amd import train
+    from nsdp_amd.graph_step import GraphedTrainOnBatch, _geometry_tensors
+    batches = [{"a": torch.full((2,), float(i))} for i in range(4)]
+    pairs = list(train._with_next(batches, torch.device("cpu")))
+    assert [int(c["a"][0]) for c, _ in pairs] == [0, 1, 2, 3]
+    assert [None if n is None else int(n["a"][0]) for _, n in pairs] == [1, 2, 3, None]
+    assert all(pairs[i][1] is pairs[i + 1][0] for i in range(3))          # the announced dict IS the next call's batch
+    assert list(train._with_next([], torch.device("cpu"))) == []
+    t = [torch.zeros(3, dtype=torch.int32) for _ in range(5)]
+    q = torch.zeros(2)
+    g = {"query_points": q, "query_idx": t[0],
+         "encoder": {"levels": [{"fps_idx": t[1], "new_xyz": t[2], "sa_inv": (t[3], t[4]), "blk_idx": None}], "anchors": t[2]}}
+    flat = _geometry_tensors(g)
+    assert len(flat) == 5 and all(any(f is x for f in flat) for x in t) and not any(f is q for f in flat)
+    assert [id(x) for x in _geometry_tensors(g)] == [id(x) for x in flat]          # a fixed order
+    d = {"x": torch.zeros(2), "y": torch.ones(2), "tag": "meta"}
+    ann = {k: (v, v._version) for k, v in d.items() if torch.is_tensor(v)}
+    assert GraphedTrainOnBatch._same_batch(ann, d)
+    assert not GraphedTrainOnBatch._same_batch(ann, {"x": d["x"].clone(), "y": d["y"], "tag": "meta"})
+    d["x"].add_(1)                                                                   # refilled in place: another batch
+    assert not GraphedTrainOnBatch._same_batch(ann, d)
+    assert not GraphedTrainOnBatch._same_batch(None, d)
