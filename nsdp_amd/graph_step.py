@@ -123,6 +123,9 @@ class GraphedStep:
             if gc_was_on:
                 gc.enable()
         torch.cuda.synchronize()
+        # the rebuild of the weight packs captured at the head of the step covers EVERY registered layer of the process: keep what
+        # it reads and writes alive as long as this graph may be replayed (hip_linear.registered_packs)
+        self._pack_refs = hip_linear.registered_packs(torch.device("cuda", torch.cuda.current_device()))
         # A pack first created INSIDE the capture is cached as valid for the current epoch although its pack kernel was only
         # recorded, never executed: an eager forward between capture() and the first replay would read uninitialised memory.
         # Stale again after the capture, whatever the step did (a captured optimizer step bumps the epoch itself).
@@ -178,6 +181,7 @@ class GraphedStep:
             self._handle = ctypes.c_void_p(0)
             self._graph = None
             self._pinned = None
+            self._pack_refs = None
         _bury()
 
     def __del__(self):
@@ -384,6 +388,17 @@ class GraphedTrainOnBatch:
                     if torch.is_tensor(v):
                         self._static_next[k].copy_(v, non_blocking=True)
                 self._announced = {k: (v, v._version) for k, v in next_data_dict.items() if torch.is_tensor(v)}
+        if self._pipe is not None and os.environ.get("NSDP_PIPE_VERIFY") == "1":      # (debug: is `current` this batch's geometry?)
+            torch.cuda.synchronize()
+            fresh = _geometry_tensors(model.geometry(*self.pipeline_inputs(self._static), training=True))
+            for i, (a, b) in enumerate(zip(_geometry_tensors(self._pipe.current), fresh)):
+                if not torch.equal(a, b):
+                    same_in = all(torch.equal(self._static[k], self._static_next[k]) for k in self._static if torch.is_tensor(self._static[k]))
+                    again = _geometry_tensors(model.geometry(*self.pipeline_inputs(self._static_next), training=True))[i]
+                    raise AssertionError(f"pipelined geometry: tensor {i} {tuple(a.shape)} {a.dtype} differs before replay {self.replays}: "
+                                         f"{int((a != b).sum())} of {a.numel()} elements; static == static_next: {same_in}; "
+                                         f"geometry(static_next) == current: {torch.equal(again, a)}; == fresh: {torch.equal(again, b)}; "
+                                         f"current[:8] {a.flatten()[:8].tolist()} fresh[:8] {b.flatten()[:8].tolist()}")
         self.replays += 1
         loss = self._step()
         if self.reducer is not None:

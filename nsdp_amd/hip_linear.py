@@ -280,7 +280,13 @@ _OVERLAP_MIN_ROWS = 131072       # rows of dY at the model's output layer (batch
 # (same box per comparison, two boxes): 0 -> 41.80 / 43.35 ms, 32 -> 41.30 / 42.93, 48 -> 42.90, 64 -> 42.86, 96 -> 42.99,
 # 128 -> 43.27: the critical chain's small kernels (the encoder's 100-point levels, BatchNorm, reductions) no longer wait
 # for a whole persistent kernel to end before they get a compute unit.
-SIDE_RESERVE_CUS = int(os.environ.get("NSDP_WGRAD_RESERVE_CUS", "48"))
+# Re-swept at the end of round 5 (profiles/r5_small_wgrad_and_sweeps.txt): B = 32 32 / 48 / 64 / 80 -> 39.74 / 39.78 / 39.93 / 40.3 ms;
+# B = 8 32 / 48 / 64 / 96 -> 13.78 / 13.75 / 13.62 / 13.76: a small batch's critical chain is made of kernels that fill a fraction of
+# the chip, and leaving them a quarter of it is worth 0.12 ms.  Unset, the figure follows the pass's size: 64 below
+# _RESERVE_SMALL_ROWS rows of dY at the model's output (batch x query points: 65 536 at B = 8), 48 from there on.
+SIDE_RESERVE_CUS = int(os.environ["NSDP_WGRAD_RESERVE_CUS"]) if "NSDP_WGRAD_RESERVE_CUS" in os.environ else None
+_RESERVE_SMALL_ROWS = 131072
+_reserve_now = {}                # (device index, graph task) -> compute units this pass's side-stream launches leave free
 _overlap_now = {}                # (device index, graph task) -> decision for that backward pass
 _side = {}
 _pending = {}          # (device index, graph task) -> {id(param): [param, grad tensor living on the side stream]}
@@ -311,6 +317,7 @@ def _side_stream(device):
 def _publish(device, key):
     """End-of-backward callback: join the streams, then hand the pending gradients to the parameters."""
     _overlap_now.pop(key, None)
+    _reserve_now.pop(key, None)
     todo = _pending.pop(key, {})
     batch = _reduce_batches.pop(key, None)
     if batch is not None and (batch["descs"] or batch["descs_b16"]):
@@ -451,7 +458,11 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
         # these launches share the chip with the critical chain on the main stream: the persistent bf16x3 weight-gradient
         # workgroups (one 512-register wave per SIMD) leave SIDE_RESERVE_CUS compute units to it
         L = lib()
-        L.nsdp_debug_set(_ci(9), _ci(SIDE_RESERVE_CUS))
+        reserve = _reserve_now.get(key)
+        if reserve is None:          # the pass's first weight gradient: the model's output layer
+            reserve = _reserve_now[key] = (SIDE_RESERVE_CUS if SIDE_RESERVE_CUS is not None
+                                           else (64 if dy2.shape[0] < _RESERVE_SMALL_ROWS else 48))
+        L.nsdp_debug_set(_ci(9), _ci(reserve))
         global _cur_reduce
         batch = _reduce_batches.get(key)
         if batch is None:
@@ -582,6 +593,17 @@ def _repack_all(device):
             cache = prm.__dict__["_nsdp_pack"] = {"key": key}
         cache[kind] = (wp, wpt)
     return True
+
+
+def registered_packs(device):
+    """Strong references to everything a batched rebuild on ``device`` touches right now: (parameter, pack, W^T pack) of every
+    registered layer of every LIVE model of the process.  A captured step contains that rebuild as a node with these addresses
+    baked in -- whoever keeps the graph must keep them (GraphedStep does): a model of the same process that dies later (another
+    test's, a discarded candidate's) would otherwise leave the replays writing packs into freed memory."""
+    reg = _pack_registry.get(device.index if device.index is not None else torch.cuda.current_device())
+    if reg is None:
+        return []
+    return [(ent[0](), ent[2], ent[3]) for ent in reg["entries"].values() if ent[0]() is not None]
 
 
 def refresh_weight_packs(device):

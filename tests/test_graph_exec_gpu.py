@@ -247,3 +247,39 @@ def test_timed_replay_measures_a_kernel_class_and_leaves_the_step_intact():
     if not nondeterministic_knobs():
         assert got == eager, (got, eager)
     gs.close()
+
+
+def test_replays_leave_the_memory_of_a_model_that_died_after_the_capture_alone():
+    """The rebuild of the weight packs at the head of a captured step is ONE launch over every registered layer of the process --
+    another live model's too.  When that model dies after the capture, the replays must not go on packing its (freed) weights
+    into its (freed) pack buffers: whoever owns that memory by then -- here canary tensors; in the pipelined harness it was the
+    NEXT batch, resident while the step ran -- would be overwritten.  The graph keeps what it touches alive
+    (hip_linear.registered_packs)."""
+    import gc
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = to_dev(synth.make_batch(5, 2, 256, 128), DEV)
+    other, _, other_step = _make(cfg, 3, data)
+    other_step()                                   # registers the other model's packs
+    model, opt, step = _make(cfg, 4, data)
+    capturable_adam(opt)
+    step()
+    g = GraphedStep(step).capture(warmup=1)
+    g()
+    torch.cuda.synchronize()
+    del other, other_step, _
+    gc.collect()
+    torch.cuda.synchronize()
+    # an eager pass in between (a validation batch, an odd-shape batch): its pack rebuild drops the dead model's entries from the
+    # registry -- from here on only the graph's own references keep those buffers
+    with torch.no_grad():
+        model(data["space_samples_src"], data["surface_samples_inputs"])
+    torch.cuda.synchronize()
+    # grab whatever the dead model released: many tensors of the sizes its weights and packs had
+    canaries = [torch.full((n,), 12345.0, device=DEV) for n in (256, 1024, 4096, 16384, 65536, 262144) for _ in range(40)]
+    for _ in range(3):
+        g()
+    torch.cuda.synchronize()
+    bad = [i for i, c in enumerate(canaries) if not bool((c == 12345.0).all())]
+    assert not bad, f"{len(bad)} of {len(canaries)} canary tensors were written by the replays"
+    g.close()
