@@ -370,9 +370,12 @@ class GraphedTrainOnBatch:
 
                 def fwd_bwd():
                     red.zero_grad()
-                    loss = piped_fn(lambda g: self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {})))
-                    loss.backward()
-                    return loss
+
+                    def inner(g):      # (the hand-over overwrites the index sets the backward pass reads: backward first)
+                        loss = self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {}))
+                        loss.backward()
+                        return loss
+                    return piped_fn(inner)
                 self._step = GraphedStep(fwd_bwd, streams).capture(warmup=0)
                 self._update = GraphedStep(lambda: optimizer.step(), self.max_streams).capture(warmup=0)
         for k, v in data_dict.items():

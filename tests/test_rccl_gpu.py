@@ -79,3 +79,42 @@ def test_rccl_broadcast_and_barrier_world1(rccl_world1):
     dist.barrier(device_ids=[0])
     torch.cuda.synchronize()
     assert float(t[-1]) == float((1 << 20) - 1)
+
+
+def test_two_graph_step_around_the_exchange_with_pipelined_geometry_equals_the_eager_loop(rccl_world1):
+    """GraphedTrainOnBatch(reducer=, pipeline_geometry=): [zero the bucket, next batch's index sets beside forward + loss +
+    backward, hand-over] and [optimizer step] as two replayed graphs around the one-rank RCCL all-reduce -- the data-parallel
+    form of the pipelined step.  Losses equal the plain eager loop's, step for step (the exchange over one rank is the identity)."""
+    from helpers import nondeterministic_knobs
+    if nondeterministic_knobs():
+        pytest.skip("the step is not bit-reproducible under " + ", ".join(nondeterministic_knobs()))
+    from nsdp_amd import train
+    from nsdp_amd.graph_step import GraphedTrainOnBatch, capturable_adam
+    from nsdp_amd.model import build_model, optimizer_factory
+    from nsdp_amd.parallel import GradAllReducer
+    cfg = model_cfg("forward", [256, 64, 16])
+    cfg["training"] = {"optimizer": "Adam", "lr": 5e-4, "lr_step": 100, "lr_decay": 0.1, "weight_decay": 0.0}
+    batches = [{k: v.to(DEV) for k, v in b.items()} for b in train.SyntheticLoader(5, 3, 2, n_surf=256, n_query=128)]
+    seq = [batches[i % 3] for i in range(7)]
+    losses = []
+    for mode in ("eager", "piped"):
+        train.seed_everything(31)
+        model, train_fn, _, _ = build_model(cfg, device=DEV)
+        model.train()
+        _, opt = optimizer_factory(cfg["training"], model.parameters())
+        capturable_adam(opt)
+        fn = train_fn
+        if mode == "piped":
+            red = GradAllReducer(model, 1, always_exchange=True)
+            fn = GraphedTrainOnBatch(train_fn, reducer=red,
+                                     pipeline_geometry=lambda d: (d["space_samples_src"], d["surface_samples_inputs"]))
+        out = []
+        for i, b in enumerate(seq):
+            if mode == "piped":
+                out.append(fn(model, opt, b, cfg, next_data_dict=seq[i + 1] if i + 1 < len(seq) else None))
+            else:
+                out.append(fn(model, opt, b, cfg))
+        losses.append(out)
+        if mode == "piped":
+            assert fn.replays == len(seq) - 1 and fn._pipe is not None and getattr(fn, "unannounced", 0) == 0
+    assert losses[0] == losses[1], losses
