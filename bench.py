@@ -268,8 +268,8 @@ def main():
                          "TDNet steps): every step computes the NEXT batch's index sets (FPS, kNN, inverse lists: functions of "
                          "the batch, not of the weights) on a stream of its own beside its forward pass and takes its own from "
                          "the previous step (nsdp_amd.graph_step.PipelinedGeometry) -- the same searches once per step, results "
-                         "bit-identical.  Measured: eval B = 8 4.40 -> 4.26 ms, train steps unchanged (the searches still cost "
-                         "their chip time; only the sampling chain's latency leaves the critical path)")
+                         "bit-identical.  Measured: eval B = 8 4.42 -> 4.24 ms, train B = 8 13.62 -> 13.37, B = 32 39.12 -> 38.95 "
+                         "(the searches still cost their chip time; only the sampling chain's latency leaves the critical path)")
     ap.add_argument("--stub-step", action="store_true",
                     help="replace the TDNet step by a tiny CPU model (tests of the launch / rendezvous / all-reduce / "
                          "timing / JSON plumbing on a box without GPUs; the line says so and is not a measurement)")
@@ -373,6 +373,7 @@ def main():
     # the same tensors: every step runs the whole search for it, nothing is carried over but the index sets the previous step
     # computed for THIS one.
     pipe = data_next = None
+    PIPE_STREAMS = int(os.environ["NSDP_PIPE_STREAMS"]) if "NSDP_PIPE_STREAMS" in os.environ else None      # (A/B: executor streams of a pipelined step)
     if (args.geometry == "pipelined" and not args.eager and args.workload != "arbitrary_train" and hasattr(model, "geometry")
             and not args.stub_step):
         from nsdp_amd.graph_step import PipelinedGeometry
@@ -435,9 +436,7 @@ def main():
             if not is_eval:
                 capturable_adam(optimizer)
             if is_eval or reducer is None:
-                # (pipelined geometry: a third executor stream -- the search is captured first and would otherwise be taken
-                # for the main chain, leaving the step and its weight gradients to share the one side stream)
-                graph = GraphedStep(run, weights_change=not is_eval, max_streams=3 if pipe is not None else None).capture(warmup=3)      # (inference: frozen weights)
+                graph = GraphedStep(run, weights_change=not is_eval, max_streams=PIPE_STREAMS if pipe is not None else None).capture(warmup=3)      # (inference: frozen weights)
                 run = graph
                 graph_note = "graph replay, multi-stream executor: " + json.dumps(graph.info)
             else:
@@ -453,7 +452,7 @@ def main():
                     if pipe is not None:
                         pipe.rotate()
                     return loss
-                g1 = GraphedStep(fwd_bwd, max_streams=3 if pipe is not None else None).capture(warmup=0)
+                g1 = GraphedStep(fwd_bwd, max_streams=PIPE_STREAMS if pipe is not None else None).capture(warmup=0)
                 reducer.all_reduce_mean()
                 g2 = GraphedStep(lambda: optimizer.step()).capture(warmup=0)
                 graph = g1

@@ -220,6 +220,19 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
   std::vector<std::vector<int>> dpos(n);           // dependencies as replay positions
   for (size_t p = 0; p < n; ++p)
     for (int d : deps[order[p]]) dpos[p].push_back(pos[d]);
+  // Which successor continues a node's stream: the one with the LONGEST chain behind it (its "heir"), not the one that happened
+  // to be captured first -- a short branch captured ahead of the step (the next batch's geometry of a pipelined step) otherwise
+  // takes the main chain's stream and hangs the step and its weight gradients on one side stream (44.0 against 40.3 ms at B = 32).
+  // NSDP_GRAPH_HEIR=0: first come, first served (rounds 3-4).
+  static const bool by_height = !(getenv("NSDP_GRAPH_HEIR") && atoi(getenv("NSDP_GRAPH_HEIR")) == 0);
+  std::vector<int> height(n, 1), heir(n, -1);
+  for (size_t q = n; q-- > 0;)
+    for (int d : dpos[q]) {      // q is a successor of d; positions are topological, so height[q] is final here
+      if (height[q] + 1 > height[d]) height[d] = height[q] + 1;
+    }
+  for (size_t q = 0; q < n; ++q)
+    for (int d : dpos[q])
+      if (heir[d] < 0 || height[q] > height[heir[d]]) heir[d] = static_cast<int>(q);
   int used = 1, rr = 0;
   for (size_t p = 0; p < n; ++p) {
     ExecNode &x = g->nodes[p];
@@ -229,7 +242,7 @@ int nsdp_graph_exec_create(void *graph_v, int max_streams, void **out) {
     } else {
       for (int c = 0; c < used && s < 0; ++c)
         for (int d : dpos[p])
-          if (tail[c] == d) { s = c; break; }
+          if (tail[c] == d && (!by_height || heir[d] == static_cast<int>(p))) { s = c; break; }
     }
     if (s < 0) {                                   // a fork: a fresh side stream, else round-robin over the side streams
       if (used < max_streams) s = used++;

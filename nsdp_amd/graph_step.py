@@ -218,8 +218,9 @@ class PipelinedGeometry:
     next batch (every loader does) therefore runs ``model.geometry(next batch)`` on a stream of its own under the current
     step's forward pass, and the next step starts with its index sets in place: the same searches, once per batch, the same
     results bit for bit; only WHEN they run changes.  Measured (profiles/r5_small_wgrad_and_sweeps.txt): the evaluation pass at
-    B = 8 4.40 -> 4.26 ms; train steps at B = 8 / 32 unchanged -- the searches still cost their chip time (a timing-only ablation
-    that SKIPS them is worth 0.44 ms at B = 8), only the sampling chain's latency leaves the critical path.  Opt-in.
+    B = 8 4.42 -> 4.24 ms, the train step 13.62 -> 13.37 ms at B = 8 and 39.12 -> 38.95 ms at B = 32 -- the searches still cost
+    their chip time (a timing-only ablation that SKIPS them is worth 0.44 ms at B = 8), only the sampling chain's latency leaves
+    the critical path.  Opt-in.
 
         pipe = PipelinedGeometry(model, inputs=lambda d: (d["space_samples_src"], d["surface_samples_inputs"]))
         pipe.prime(static_batch, training=True)                  # eager, once: the first batch's sets
@@ -259,9 +260,9 @@ class PipelinedGeometry:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=dev)
             self._tick = torch.zeros(1, dtype=torch.int32, device=dev)
-        # one trivial launch on the step's own stream first, so that the search is a fork of the step and not a root of its own.
-        # (The graph executor still continues the chain with whichever successor was captured first -- the search: replay a
-        # pipelined step with THREE executor streams, or the step shares one side stream with its weight gradients.)
+        # one trivial launch on the step's own stream first, so that the search is a fork of the step and not a root of its own:
+        # the graph executor then gives the step (the longer chain behind the fork) the main stream and the search the side
+        # stream, which it shares with the weight gradients of the backward pass -- idle until then
         self._tick.add_(1)
         self._stream.wait_stream(main)
         with torch.cuda.stream(self._stream):
@@ -352,7 +353,7 @@ class GraphedTrainOnBatch:
                 self._pipe.prime(self._static, training=True)
                 self._announced = {k: (v, v._version) for k, v in data_dict.items() if torch.is_tensor(v)}
 
-            streams = self.max_streams if (self.max_streams is not None or not piped) else 3      # (see PipelinedGeometry.prefetch)
+            streams = self.max_streams
 
             def piped_fn(step):      # next batch's index sets beside the step, then next -> current
                 if not piped:
