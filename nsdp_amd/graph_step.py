@@ -379,11 +379,14 @@ class GraphedTrainOnBatch:
                     return piped_fn(inner)
                 self._step = GraphedStep(fwd_bwd, streams).capture(warmup=0)
                 self._update = GraphedStep(lambda: optimizer.step(), self.max_streams).capture(warmup=0)
+        announced = self._pipe is not None and self._same_batch(self._announced, data_dict)
         for k, v in data_dict.items():
             if torch.is_tensor(v):
-                self._static[k].copy_(v, non_blocking=True)
+                # (an announced batch was copied into the static "next" tensors when it was announced, and its index sets were
+                # computed from THAT copy: the step reads the same bytes, whatever happened to the caller's tensors since)
+                self._static[k].copy_(self._static_next[k] if announced else v, non_blocking=True)
         if self._pipe is not None:
-            if not self._same_batch(self._announced, data_dict):
+            if not announced:
                 self._pipe.prime(self._static, training=True)      # not the batch the last replay prepared: search now, eagerly
                 self.unannounced = getattr(self, "unannounced", 0) + 1
             self._announced = None
