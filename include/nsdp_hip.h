@@ -361,6 +361,29 @@ int nsdp_linear_wgrad_bf16x3_h0_f32(const float *dY, const float *X4, const floa
                                     long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
                                     NsdpWgradReduceDesc *desc_out, void *stream);
 
+/* G16 layout: a tensor T[M, C] (M % 16 == 0, C % 4 == 0) stored as [M / 16][C / 4][16 rows][4 floats] -- groups of 16 rows,
+ * channel-quad-major inside a group; the same bytes, permuted.  It is the layout of the wide intermediates that ONLY the dense-layer
+ * kernels touch: the hidden layer of every Linear -> ReLU -> Linear pair over per-(centre, neighbour) rows (fc_gamma of the attention
+ * blocks, reference model/encoder/blocks.py:86-124, model/decoder/blocks.py:30-91) and its gradient -- written by one GEMM, read by
+ * the next, by one weight gradient and as a ReLU mask.  In it every wave-wide activation load and every 16 x 16 output tile's store of
+ * the bf16x3 kernels is ONE contiguous KiB (row-major: 16 runs of 64 B at the row pitch), and outputs need no staging through LDS.
+ *   nsdp_layout_g16_f32            dst = src re-laid out (to_g16 != 0: row-major -> G16, else back); out of place.
+ *   nsdp_linear_bf16x3_g16_f32     nsdp_linear_bf16x3_f32 (+ the addend of nsdp_linear_bf16x3_addend_f32) with `layout` = 1: X and
+ *                                  mask in G16 (no input ReLU), or 2: Y in G16 (no mask, residual, out_mask, addend).  Everything else
+ *                                  stays row-major.  Same arithmetic element for element: bit-identical to the row-major call.
+ *   nsdp_linear_wgrad_bf16x3_g16_f32   nsdp_linear_wgrad_bf16x3_f32 / _partials_f32 (desc_out != NULL: partial sums only) with
+ *                                  `layout` = 1: dY and mask in G16, or 2: X in G16 (no mask).  dW, db bit-identical to the row-major call.
+ * The *_supported predicates say which (shape, layout, operands) combinations are instantiated. */
+int nsdp_layout_g16_f32(const float *src, float *dst, long long M, int C, int to_g16, void *stream);
+int nsdp_linear_bf16x3_g16_supported(long long M, int N, int K, int layout, int has_mask, int relu_in);
+int nsdp_linear_bf16x3_g16_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,
+                               const float *out_mask, const float *addend, float *Y, long long M, int N, int K, int relu_in,
+                               int relu_out, int layout, void *stream);
+int nsdp_linear_wgrad_bf16x3_g16_supported(long long M, int N, int K, int layout, int has_mask);
+int nsdp_linear_wgrad_bf16x3_g16_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
+                                     long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                     NsdpWgradReduceDesc *desc_out, int layout, void *stream);
+
 /* nsdp_linear_wgrad_bf16 in two halves, like nsdp_linear_wgrad_bf16x3_partials_f32 / nsdp_wgrad_bf16x3_reduce_batched: the row
  * kernel now (an all-zero *desc_out -- ws == NULL -- means the call had nothing to do), the fixed-order sums of many layers'
  * partials in one launch later (bit-identical to the one-call form; two descriptors of a launch must not share a target). */

@@ -38,6 +38,7 @@ PER_FILE = {
     # subtractions) costs more issue time beside MFMAs than the two scalar operations it replaces (MI355X_MICROARCH.md): without
     # it the forward / dX GEMMs run 0.5-3 % faster alone and the B = 32 step 0.26 ms (three interleaved rounds), bit-identical
     "gemm_bf16x3.hip": FAST + ["-fno-slp-vectorize"],
+    "gemm_bf16x3_g16.hip": FAST + ["-fno-slp-vectorize"],      # (the same kernel template, x3_kernel.h: its G16-layout instantiations)
 }
 
 

@@ -147,10 +147,16 @@ __device__ __forceinline__ u32x4 frag_vec(const unsigned long long (&q)[2]) {
 // H0 (nsdp_linear_wgrad_bf16x3_h0_f32): the X operand is the hidden layer h0 = relu(x4 W0^T + b0) of a position-encoding MLP,
 // recomputed from the 16-byte coordinate rows: a B slot loads its row's float4 instead of four floats of an [M, K] tensor and
 // evaluates the K = 4 layer for its four columns (table rows from LDS: the 4 KiB the two plane buffers leave free hold 204).
-template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false, bool H0 = false>
+// LAY (nsdp_linear_wgrad_bf16x3_g16_f32): bit 0 = dY (and the mask), bit 1 = X stored in the G16 layout of gemm_bf16x3_g16.hip
+// ([M / 16][C / 4][16 rows][4 floats]).  Only the producer's slot -> (row, float4 column) map and its addresses change: a slot of a
+// G16 operand walks the rows of one channel quad first (one contiguous KiB per wave instruction), the plane images, the MFMA order
+// and the bias sums are the row-major kernel's -- dW and db come out bit-identical.
+template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false, bool H0 = false, int LAY = 0>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   static_assert(!ONEHOT || (!MASK && NTA == 8), "one-hot operand: 128 table rows, no mask");
   static_assert(!H0 || (!MASK && !ONEHOT), "H0 operand: plain dY");
+  static_assert(!LAY || (!ONEHOT && !H0), "G16 operands: the plain / masked forms");
+  constexpr bool kAG = (LAY & 1) != 0, kBG = (LAY & 2) != 0;
   constexpr int kH0Rows = !H0 ? 0 : (KTB == 13 ? 204 : KTB * 16);
   constexpr int TA = (NTA + 1) / 2, TB = (KTB + 1) / 2;
   constexpr int kColsA = NTA * 16, kColsB = KTB * 16, kC4A = NTA * 4, kC4B = KTB * 4;
@@ -200,10 +206,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     } else {
       int s = tid + 256 * r;
       s = s < 32 * kC4A ? s : s - 256;
-      const int row = s / kC4A, c4 = s % kC4A;
+      // (G16: 16 consecutive slots = the 16 rows of one channel quad of a row group)
+      const int row = kAG ? (s / (16 * kC4A)) * 16 + (s & 15) : s / kC4A, c4 = kAG ? (s % (16 * kC4A)) >> 4 : s % kC4A;
       const int col = 4 * c4 + 4 <= N ? 4 * c4 : N - 4;      // padding columns re-read the last real ones (never reduced)
       rowA[r] = row;
-      offA[r] = static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
+      offA[r] = kAG ? static_cast<unsigned>(((mb0 * 32 + (row & 16)) * N + col * 16 + (row & 15) * 4) * 4)
+                    : static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
       ldsA[r] = static_cast<unsigned>(row * kPitchA + c4 * 8);
     }
   }
@@ -211,12 +219,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   for (int r = 0; r < RB; ++r) {
     int s = tid + 256 * r;
     s = s < 32 * kC4B ? s : s - 256;
-    const int row = s / kC4B, c4 = s % kC4B;
+    const int row = kBG ? (s / (16 * kC4B)) * 16 + (s & 15) : s / kC4B, c4 = kBG ? (s % (16 * kC4B)) >> 4 : s % kC4B;
     const int col = k_off + (4 * c4 + 4 <= Kpart ? 4 * c4 : Kpart - 4);
     rowB[r] = row;
     if constexpr (H0) {
       colB[r] = col - k_off;
       offB[r] = static_cast<unsigned>((mb0 * 32 + row) * 16);
+    } else if constexpr (kBG) {
+      offB[r] = static_cast<unsigned>(((mb0 * 32 + (row & 16)) * K + col * 16 + (row & 15) * 4) * 4);
     } else {
       offB[r] = static_cast<unsigned>(((mb0 * 32 + row) * K + col) * 4);
     }
@@ -234,7 +244,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     unsigned off = offA[r];
     if (TAIL && mb * 32 + 32 > Mrows) {           // rows past M: re-read row M - 1 (zeroed in the split)
       const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
-      if (rowA[r] > last_row) off -= static_cast<unsigned>(rowA[r] - last_row) * strideA;
+      if constexpr (kAG) {                        // (M % 16 == 0: the second row group is missing -- re-read the first)
+        if (rowA[r] > last_row) off -= 16u * strideA;
+      } else {
+        if (rowA[r] > last_row) off -= static_cast<unsigned>(rowA[r] - last_row) * strideA;
+      }
     }
     if constexpr (ONEHOT) {
       gload_i32(rawI, dYp, off);
@@ -247,7 +261,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     unsigned off = offB[r];
     if (TAIL && mb * 32 + 32 > Mrows) {
       const int last_row = static_cast<int>(Mrows - 1 - mb * 32);
-      if (rowB[r] > last_row) off -= static_cast<unsigned>(rowB[r] - last_row) * strideB;
+      if constexpr (kBG) {
+        if (rowB[r] > last_row) off -= 16u * strideB;
+      } else {
+        if (rowB[r] > last_row) off -= static_cast<unsigned>(rowB[r] - last_row) * strideB;
+      }
     }
     gload4(rawB[r], Xp, off);
   };
@@ -484,7 +502,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int s = tid + 256 * r;
-      if (s < 32 * kC4A) *reinterpret_cast<f32x4 *>(dbl + (s / kC4A) * kColsA + 4 * (s % kC4A)) = dbsum[r];
+      const int srow = kAG ? (s / (16 * kC4A)) * 16 + (s & 15) : s / kC4A, sc4 = kAG ? (s % (16 * kC4A)) >> 4 : s % kC4A;
+      if (s < 32 * kC4A) *reinterpret_cast<f32x4 *>(dbl + srow * kColsA + 4 * sc4) = dbsum[r];
     }
     __syncthreads();
     for (int c = tid; c < kColsA; c += 256) {
@@ -649,6 +668,18 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
     if (tail) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, true>), g, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false>), g, dim3(256), 0, st, p);
   }
+}
+
+// G16 operands (LAY of the kernel): the square tile classes of the attention MLPs' hidden layers, whole 32-row blocks
+template <int NTA, int KTB>
+bool launch_wg_g16(const WgX3Params &p, int layout, int grid, hipStream_t st) {
+  const dim3 g(grid, p.kparts);
+  NSDP_TRACE("wgrad_bf16x3<%d,%d,%s,notail> g16:%s", NTA, KTB, p.mask ? "mask" : "plain", layout == 1 ? "dy" : layout == 2 ? "x" : "dy,x");
+  if (layout == 1 && p.mask) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, false, false, false, 1>), g, dim3(256), 0, st, p);
+  else if (layout == 1) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false, false, false, 1>), g, dim3(256), 0, st, p);
+  else if (layout == 2 && !p.mask) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false, false, false, 2>), g, dim3(256), 0, st, p);
+  else return false;
+  return true;
 }
 
 // table[b][n][k] = sum over the S partials of shape b (fragment order, see wgrad_bf16x3_reduce_kernel), fixed order
@@ -818,6 +849,41 @@ int nsdp_linear_wgrad_bf16x3_f32(const float *dY, const float *X, const float *m
   // batching the 98 reduce launches of a step could buy)
   static const bool skip_reduce = getenv("NSDP_WG3_SKIP_REDUCE") && atoi(getenv("NSDP_WG3_SKIP_REDUCE")) != 0;
   if (skip_reduce) return 0;
+  hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
+                     workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
+  return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");
+}
+
+// nsdp_linear_wgrad_bf16x3_f32 / _partials_f32 with operands in the G16 layout (gemm_bf16x3_g16.hip): layout bit 0 = dY and the
+// mask, bit 1 = X.  dW, db bit-identical to the row-major call on the same values.  desc_out != NULL: partial sums only (the
+// reduction is described for nsdp_wgrad_bf16x3_reduce_batched); NULL: reduced here.
+int nsdp_linear_wgrad_bf16x3_g16_supported(long long M, int N, int K, int layout, int has_mask) {
+  if (!nsdp_linear_wgrad_bf16x3_supported(M, N, K) || M % 32 || N % 4 || K % 4) return 0;
+  if (!(layout == 1 || (layout == 2 && !has_mask))) return 0;
+  const X3Plan pl = plan_x3(M, N, K);
+  return (pl.nta == 8 && pl.ktb == 8) || (pl.nta == 13 && pl.ktb == 13) || (pl.nta == 16 && pl.ktb == 8);
+}
+int nsdp_linear_wgrad_bf16x3_g16_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
+                                     long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
+                                     NsdpWgradReduceDesc *desc_out, int layout, void *stream) {
+  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_g16_supported(M, N, K, layout, mask != nullptr),
+               "linear_wgrad_bf16x3_g16: unsupported call M=%lld N=%d K=%d layout=%d mask=%d", M, N, K, layout, mask != nullptr);
+  NSDP_REQUIRE(dY && X && dW && workspace, "linear_wgrad_bf16x3_g16: null pointer");
+  NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K), "linear_wgrad_bf16x3_g16: workspace too small");
+  const X3Plan pl = plan_x3(M, N, K);
+  WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr, pl.kparts};
+  hipStream_t st = nsdp::as_stream(stream);
+  nsdp::prof::Scope scope(nsdp::prof::kWgradX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
+  const bool ok = pl.nta == 8 ? launch_wg_g16<8, 8>(p, layout, pl.grid, st)
+                  : pl.nta == 16 ? launch_wg_g16<16, 8>(p, layout, pl.grid, st) : launch_wg_g16<13, 13>(p, layout, pl.grid, st);
+  NSDP_REQUIRE(ok, "linear_wgrad_bf16x3_g16: form not instantiated");
+  const int rc = nsdp::launch_status("wgrad_bf16x3_kernel (g16)");
+  if (rc) return rc;
+  if (desc_out) {
+    *desc_out = NsdpWgradReduceDesc{workspace, dW, db, pl.grid, pl.nta, pl.ktb, N, K, accumulate ? 1 : 0, 0};
+    return 0;
+  }
+  const long long ne = static_cast<long long>(N) * K + N;
   hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(static_cast<unsigned>((ne + 31) / 32)), dim3(256), 0, st,
                      workspace, pl.grid, pl.nta, pl.ktb, N, K, dW, db, accumulate);
   return nsdp::launch_status("wgrad_bf16x3_reduce_kernel");

@@ -122,6 +122,92 @@ def _fwd_x3_gather(x2, wp, N, b, gather, relu_in, relu_out):
     return y
 
 
+# ------------------------------------------------------------------------------------------------
+# G16 layout of the tensors between two dense layers
+# ------------------------------------------------------------------------------------------------
+# The hidden tensor of a Linear -> ReLU -> Linear pair over [rows, d] per-(centre, neighbour) rows (fc_gamma of every attention
+# block, the decoder's ResnetBlockFC) and its gradient are touched by dense-layer kernels only: written by one GEMM, read by the
+# next, by a weight gradient and as a ReLU mask.  They live in the G16 layout of csrc/gemm_bf16x3_g16.hip
+# ([M / 16][C / 4][16 rows][4 floats]: every wave-wide load / tile store of those kernels is one contiguous KiB, outputs skip the
+# LDS staging) -- same values, permuted; the torch tensor that carries one keeps its logical shape and MUST NOT be read by
+# anything else (ops.mlp2 / ResnetBlockFC keep it private).  NSDP_G16=0: row-major everywhere (A/B knob).
+G16 = os.environ.get("NSDP_G16", "1") != "0"
+LAY_X, LAY_Y = 1, 2
+
+
+def _fwd_x3_g16(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, layout, addend=None):
+    """_fwd_x3 with X (and mask) or Y in the G16 layout (nsdp_linear_bf16x3_g16_f32)."""
+    M, K = x2.shape
+    y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+    with on_device(x2):
+        check(lib().nsdp_linear_bf16x3_g16_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
+                                               optptr(mask), optptr(out_mask), optptr(addend), fptr(y), _ll(M), _ci(N), _ci(K),
+                                               _ci(int(relu_in)), _ci(int(relu_out)), _ci(int(layout)), stream_ptr()),
+              "nsdp_linear_bf16x3_g16_f32")
+    return y
+
+
+def to_g16(t, back=False):
+    """Row-major [M, C] -> G16 (``back``: the other way), out of place -- tests and debugging."""
+    t2 = t.reshape(-1, t.shape[-1]).contiguous()
+    out = torch.empty_like(t2)
+    with on_device(t2):
+        check(lib().nsdp_layout_g16_f32(fptr(t2, "src"), fptr(out), _ll(t2.shape[0]), _ci(t2.shape[1]), _ci(0 if back else 1),
+                                        stream_ptr()), "nsdp_layout_g16_f32")
+    return out.reshape(t.shape)
+
+
+def _wgrad_g16_fn(layout):
+    """Weight-gradient routine (the `fn` protocol of wgrad_direct / _wgrad_deferred) with dY + mask (layout 1) or X (layout 2) in
+    the G16 layout (nsdp_linear_wgrad_bf16x3_g16_f32): the sums of _wgrad_x3, bit for bit."""
+    def fn(dy2, x2, mask, relu_x, want_db, out=None):
+        M, N = dy2.shape
+        K = x2.shape[1]
+        L = lib()
+        L.nsdp_linear_wgrad_bf16x3_workspace_bytes.restype = ctypes.c_size_t
+        nbytes = int(L.nsdp_linear_wgrad_bf16x3_workspace_bytes(_ll(M), _ci(N), _ci(K)))
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dy2.device)
+        dw, db, acc = wgrad_out(out, N, K, want_db, dy2.device)
+        batch = _cur_reduce if BATCH_REDUCE > 0 else None
+        desc = _ReduceDesc() if batch is not None else None
+        with on_device(dy2):
+            if batch is not None:
+                ptrs = {dw.data_ptr()} | ({db.data_ptr()} if db is not None else set())
+                if ptrs & batch["targets"]:
+                    _flush_reduce(batch)
+            check(L.nsdp_linear_wgrad_bf16x3_g16_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
+                                                     optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws), ctypes.c_size_t(nbytes),
+                                                     ctypes.byref(desc) if desc is not None else None, _ci(int(layout)), stream_ptr()),
+                  "nsdp_linear_wgrad_bf16x3_g16_f32")
+            if batch is not None:
+                batch["descs"].append(desc)
+                batch["keep"].append((ws, dw, db))
+                batch["targets"] |= ptrs
+                if len(batch["descs"]) + len(batch["descs_b16"]) >= BATCH_REDUCE:
+                    _flush_reduce(batch)
+        return dw, db
+    fn.batched_reduce = True
+    return fn
+
+
+def g16_pair_ok(M, K, H, N, relu_in0=False, train=True):
+    """Can the hidden tensor [M, H] of Linear(K, H) -> ReLU -> Linear(H, N) (and, when training, its gradient) live in the G16
+    layout?  Every kernel that touches it must have the form: both forward GEMMs, both dX GEMMs, both weight gradients."""
+    if not G16 or precision.is_bf16() or M % 16:
+        return False
+    L = lib()
+    ok = (_x3_ok(M, H, K) and _x3_ok(M, N, H)
+          and L.nsdp_linear_bf16x3_g16_supported(_ll(M), _ci(H), _ci(K), _ci(LAY_Y), _ci(0), _ci(int(relu_in0)))
+          and L.nsdp_linear_bf16x3_g16_supported(_ll(M), _ci(N), _ci(H), _ci(LAY_X), _ci(0), _ci(0)))
+    if not ok or not train:
+        return bool(ok)
+    return bool(_x3_ok(M, H, N) and _x3_ok(M, K, H) and M >= _X3_MIN_ROWS_WGRAD
+                and L.nsdp_linear_bf16x3_g16_supported(_ll(M), _ci(H), _ci(N), _ci(LAY_Y), _ci(0), _ci(0))       # second layer dX
+                and L.nsdp_linear_bf16x3_g16_supported(_ll(M), _ci(K), _ci(H), _ci(LAY_X), _ci(1), _ci(0))       # first layer dX (masked)
+                and L.nsdp_linear_wgrad_bf16x3_g16_supported(_ll(M), _ci(N), _ci(H), _ci(2), _ci(0))
+                and L.nsdp_linear_wgrad_bf16x3_g16_supported(_ll(M), _ci(H), _ci(K), _ci(1), _ci(1)))
+
+
 def gather_init_ok(M, N, K):
     """Can a layer of this shape take ``init_gather`` (it needs the bf16x3 kernel)?"""
     return _x3_ok(M, N, K) and M < 2 ** 31 and not precision.is_bf16()
@@ -660,7 +746,11 @@ def _packs(w, owner, kind, want_t):
     return ent
 
 
-def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None):
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None, lay=0):
+    if lay:        # G16 operands (see _fwd_x3_g16): the caller checked the form (g16_pair_ok)
+        if kind != "x3" or res_sign != 1.0:
+            raise ValueError("G16 layouts belong to the bf16x3 kernels")
+        return _fwd_x3_g16(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, lay, addend=addend)
     if addend is not None:
         if kind == "x3" and mask is not None and out_mask is not None and not relu_in:
             return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, addend=addend)
@@ -924,8 +1014,11 @@ def pos_mlp(x, weight0, bias0, weight1, bias1, init_gather=None):
 class _LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual, relu_in, relu_out, w_param=None, b_param=None, grad_sum=None, owner=None, bw=0,
-                init_gather=None, res_sign=1.0, skip=None, tail=None):
+                init_gather=None, res_sign=1.0, skip=None, tail=None, lay=0):
         # skip: (SkipGrad, is_src) -- see SkipGrad;  tail: (K4Tail, is_src) -- see K4Tail
+        # lay: LAY_Y = this layer's OUTPUT (and the gradient arriving for it) is in the G16 layout, LAY_X = its INPUT (and the
+        # gradient it reports) is -- the two layers around a private hidden tensor (g16_pair_ok)
+        ctx.lay = lay
         ctx.tail = None
         ctx.skip_src = ctx.skip_dst = None
         if skip is not None:
@@ -994,12 +1087,15 @@ class _LinearFn(torch.autograd.Function):
                   and Kp == K and N % 4 == 0 and M == tlink.x4.shape[0]):
                 tlink.taken = True
                 ctx.tail = tlink
+        if lay and (kind != "x3" or init_gather is not None or bw or tail is not None or (lay == LAY_Y and res2 is not None)
+                    or (lay == LAY_X and (grad_sum is not None or ctx.skip_dst is not None))):
+            raise ValueError("G16 layout: a plain bf16x3 layer pair only (g16_pair_ok)")
         if init_gather is not None:
             if kind != "x3" or res2 is not None:
                 raise ValueError("init_gather needs a layer on the bf16x3 kernel (gather_init_ok) without a residual")
             y = _fwd_x3_gather(x2, wp, N, b, init_gather, relu_in, relu_out)
         else:
-            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, res_sign)
+            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, res_sign, lay=lay)
         ctx.res_sign = res_sign
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
@@ -1011,15 +1107,18 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         if dy is None:          # (K4Tail: the next layer's dX GEMM produced this layer's weight gradient itself)
-            return (None,) * 15
+            return (None,) * 16
         x2, wpt, y = ctx.saved_tensors
         N = ctx.n_out
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
         dx = dw = db = dres = None
+        lay = ctx.lay
         if ctx.w_param is not None:
             fn = None
-            if (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
+            if lay:      # LAY_Y: dY (and the mask y) arrive in G16; LAY_X: the input x2 is
+                fn = _wgrad_g16_fn(1 if lay == LAY_Y else 2)
+            elif (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
                     and x2.shape[0] >= 4096 and not ctx.has_res and ctx.fwd_key == _pack_key(ctx.w_param)):
                 # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates.
                 # Only when the recomputed expression IS the forward one: no residual operand (the mask would be that of
@@ -1032,7 +1131,10 @@ class _LinearFn(torch.autograd.Function):
             else:
                 wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
+            if lay:
+                dw, db = _wgrad_g16_fn(1 if lay == LAY_Y else 2)(dy2, x2, y, ctx.relu_in, ctx.has_bias)
+            else:
+                dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         tl = ctx.tail
         if tl is not None and ctx.needs_input_grad[0] and tl.fwd_key == _pack_key(tl.w_param):
             # the dX GEMM with the K = 4 layer's weight gradient in its epilogue: no input gradient to report
@@ -1055,8 +1157,10 @@ class _LinearFn(torch.autograd.Function):
                 addend, ctx.skip_dst.buf = ctx.skip_dst.buf, None
                 if addend is not None and addend.shape[1] != x2.shape[1]:
                     raise RuntimeError("SkipGrad: the skip gradient does not have the layer's input width")
+            # (G16: the gradient of a G16 output arrives in G16 -- this GEMM's X and mask; the gradient of a G16 input leaves in it)
             dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
-                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False, addend=addend)
+                      x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False, addend=addend,
+                      lay=(LAY_X if lay == LAY_Y else LAY_Y if lay == LAY_X else 0))
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
             if link is not None:         # running sum over the layers that share this input
                 link.pending -= 1
@@ -1071,7 +1175,7 @@ class _LinearFn(torch.autograd.Function):
             dres = dres.reshape(dy.shape)
             if ctx.res_sign != 1.0:
                 dres = -dres
-        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 # Direct publication (`params=True`) hands weight gradients to `param.grad` behind autograd's back.  That is what makes
@@ -1106,7 +1210,7 @@ def _observed(t):
 
 def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, params=False, grad_sum=None,
            out_f32=False, premasked=False, mask_dx=False, init_gather=None, residual_sign=1.0,
-           skip_src=None, skip_dst=None, tail_src=None, tail_dst=None, pack_owner=None):
+           skip_src=None, skip_dst=None, tail_src=None, tail_dst=None, pack_owner=None, lay=0):
     """``params=True``: `weight` / `bias` are the layer's leaf nn.Parameters; their gradients are then
     produced on the side stream and published to ``.grad`` at the end of the backward pass (see above).
     ``grad_sum``: an InputGradSum shared by the layers reading the same ``x``.
@@ -1130,8 +1234,8 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
         # the tensor itself -- carries the pack cache, so that the pack is built once instead of at every call
         owner = pack_owner
     if precision.is_bf16():
-        if init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst:
-            raise ValueError("init_gather / signed residuals / SkipGrad belong to fp32 storage")
+        if init_gather is not None or residual_sign != 1.0 or skip_src or skip_dst or lay:
+            raise ValueError("init_gather / signed residuals / SkipGrad / G16 layouts belong to fp32 storage")
         if bw:
             raise ValueError("premasked / mask_dx belong to fp32 storage (bf16 storage uses relu_in on the second layer)")
         from . import hip_linear_bf16 as hb
@@ -1162,6 +1266,6 @@ def linear(x, weight, bias=None, relu_in=False, relu_out=False, residual=None, p
         # the Function sees detached operands for the weights: their gradient does not go through autograd
         return _LinearFn.apply(x, w2.detach(), None if bias is None else bias.detach(), residual, bool(relu_in),
                                bool(relu_out), w_param, b_param, grad_sum, None, bw, init_gather,
-                               float(residual_sign), skip, tail)
+                               float(residual_sign), skip, tail, int(lay))
     return _LinearFn.apply(x, w2, bias, residual, bool(relu_in), bool(relu_out), None, None, grad_sum, owner, bw,
-                           init_gather, float(residual_sign), skip, None)
+                           init_gather, float(residual_sign), skip, None, int(lay))

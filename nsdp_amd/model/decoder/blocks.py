@@ -110,5 +110,9 @@ class ResnetBlockFC(nn.Module):
         pair = ops.PAIR_MASK and torch.is_grad_enabled()                 # backward mask contract of ops.mlp2
         # identity shortcut: the skip connection's gradient joins fc_0's dX inside that GEMM (hip_linear.SkipGrad)
         skip = ops.skip_grad(x) if self.shortcut is None else None
-        h = ops.linear(x, self.fc_0, relu_in=True, relu=True, premasked=pair, skip_dst=skip)      # relu(fc_0(relu(x)))
-        return ops.linear(h, self.fc_1, residual=x_s, mask_dx=pair, skip_src=skip)       # x_s + fc_1(h), fused epilogue
+        # (h is private to the two layers: G16 layout where the kernels have the form -- hip_linear.g16_pair_ok)
+        g16 = not pair and ops.g16_pair(x, self.fc_0, self.fc_1, relu_in0=True)
+        h = ops.linear(x, self.fc_0, relu_in=True, relu=True, premasked=pair, skip_dst=skip,
+                       lay=ops.hip_linear.LAY_Y if g16 else 0)                                    # relu(fc_0(relu(x)))
+        return ops.linear(h, self.fc_1, residual=x_s, mask_dx=pair, skip_src=skip,
+                          lay=ops.hip_linear.LAY_X if g16 else 0)                                 # x_s + fc_1(h), fused epilogue

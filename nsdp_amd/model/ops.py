@@ -185,14 +185,28 @@ def relative_coords(query: torch.Tensor, source: torch.Tensor, idx: torch.Tensor
 def linear(x: torch.Tensor, lin, relu: bool = False, relu_in: bool = False, residual=None, grad_sum=None,
            out_f32: bool = False, premasked: bool = False, mask_dx: bool = False,
            init_gather=None, residual_sign: float = 1.0, skip_src=None, skip_dst=None, tail_src=None,
-           tail_dst=None) -> torch.Tensor:
+           tail_dst=None, lay: int = 0) -> torch.Tensor:
     """nn.Linear / 1x1 nn.Conv1d on channels-last rows, on the fp32 matrix cores (hip_linear):
     relu?( relu_in?(x) @ W^T + b (+ residual) ).  ``grad_sum``: hip_linear.InputGradSum shared by layers that read
     the same ``x`` (their input gradients are then summed inside the dX GEMMs)."""
     return hip_linear.linear(x, lin.weight, lin.bias, relu_in=relu_in, relu_out=relu, residual=residual,
                              params=True, grad_sum=grad_sum, out_f32=out_f32, premasked=premasked, mask_dx=mask_dx,
                              init_gather=init_gather, residual_sign=residual_sign,
-                             skip_src=skip_src, skip_dst=skip_dst, tail_src=tail_src, tail_dst=tail_dst)
+                             skip_src=skip_src, skip_dst=skip_dst, tail_src=tail_src, tail_dst=tail_dst, lay=lay)
+
+
+def g16_pair(x: torch.Tensor, lin0, lin1, relu_in0: bool = False) -> bool:
+    """May the hidden tensor of lin1(relu(lin0(x))) -- which nothing but these two layers reads -- live in the G16 layout of the
+    dense-layer kernels (hip_linear.g16_pair_ok)?  The caller then passes lay=LAY_Y to the first layer and lay=LAY_X to the second."""
+    if not (hip_linear.G16 and x.is_cuda and x.dtype is torch.float32) or precision.is_bf16():
+        return False
+    K = x.shape[-1]
+    w0 = lin0.weight.squeeze(-1) if lin0.weight.dim() == 3 else lin0.weight
+    w1 = lin1.weight.squeeze(-1) if lin1.weight.dim() == 3 else lin1.weight
+    if w0.shape[1] != K or w1.shape[1] != w0.shape[0]:
+        return False
+    train = torch.is_grad_enabled() and (x.requires_grad or lin0.weight.requires_grad or lin1.weight.requires_grad)
+    return hip_linear.g16_pair_ok(x.numel() // K, K, w0.shape[0], w1.shape[0], relu_in0=relu_in0, train=train)
 
 
 def pos_mlp(x: torch.Tensor, seq: nn.Sequential, init_gather=None):
@@ -244,7 +258,9 @@ def mlp2(x: torch.Tensor, seq: nn.Sequential, grad_sum=None) -> torch.Tensor:
         if y is not None:
             return y
     tl = k4_tail(x, seq) if grad_sum is None else None
-    return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, tail_src=tl), seq[2], tail_dst=tl)
+    g16 = tl is None and g16_pair(x, seq[0], seq[2])      # the hidden tensor and its gradient: G16 layout (private to the pair)
+    return linear(linear(x, seq[0], relu=True, grad_sum=grad_sum, tail_src=tl, lay=hip_linear.LAY_Y if g16 else 0), seq[2],
+                  tail_dst=tl, lay=hip_linear.LAY_X if g16 else 0)
 
 
 def batch_norm(x: torch.Tensor, bn: nn.BatchNorm1d, addend=None, relu: bool = False) -> torch.Tensor:

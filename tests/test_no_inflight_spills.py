@@ -23,6 +23,7 @@ from nsdp_amd import build as nsdp_build  # noqa: E402  (the flags under test ar
 
 FILES = {  # translation unit -> kernel-name regex
     "gemm_bf16x3.hip": r"linear_bf16x3_kernel",
+    "gemm_bf16x3_g16.hip": r"linear_bf16x3_kernel",
     "wgrad_bf16x3.hip": r"wgrad_bf16x3_(?:rows_)?kernel",
     "decoder_fused.hip": r"decoder_fused_fwd_kernel",
 }
