@@ -147,6 +147,18 @@ __device__ __forceinline__ u32x4 frag_vec(const unsigned long long (&q)[2]) {
 // H0 (nsdp_linear_wgrad_bf16x3_h0_f32): the X operand is the hidden layer h0 = relu(x4 W0^T + b0) of a position-encoding MLP,
 // recomputed from the 16-byte coordinate rows: a B slot loads its row's float4 instead of four floats of an [M, K] tensor and
 // evaluates the K = 4 layer for its four columns (table rows from LDS: the 4 KiB the two plane buffers leave free hold 204).
+// Producer slot -> (image row, float4 column) of a G16 operand.  64 consecutive slots (one wave instruction) cover the 16 rows of
+// four consecutive channel quads of one row group -- one contiguous KiB of the tensor -- in the order rows 0-7 x 4 quads, then rows
+// 8-15 x 4 quads: the 32 lanes an 8-byte LDS write resolves together then hit 8 rows x 4 quads of the plane image, whose pitch
+// (32 mod 64 bytes) puts rows r and r + 8 into the same banks (all 16 rows of a quad per half-wave: 2-way conflicts, measured
+// +2-5 % on the launch)
+__device__ __forceinline__ void g16_slot(int s, int c4s, int &row, int &c4) {
+  const int chunk = s >> 6, l = s & 63, chunks_per_group = c4s >> 2;
+  const int grp = chunk / chunks_per_group;
+  row = grp * 16 + ((l >> 5) << 3) + (l & 7);
+  c4 = (chunk - grp * chunks_per_group) * 4 + ((l >> 3) & 3);
+}
+
 // LAY (nsdp_linear_wgrad_bf16x3_g16_f32): bit 0 = dY (and the mask), bit 1 = X stored in the G16 layout of gemm_bf16x3_g16.hip
 // ([M / 16][C / 4][16 rows][4 floats]).  Only the producer's slot -> (row, float4 column) map and its addresses change: a slot of a
 // G16 operand walks the rows of one channel quad first (one contiguous KiB per wave instruction), the plane images, the MFMA order
@@ -206,8 +218,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
     } else {
       int s = tid + 256 * r;
       s = s < 32 * kC4A ? s : s - 256;
-      // (G16: 16 consecutive slots = the 16 rows of one channel quad of a row group)
-      const int row = kAG ? (s / (16 * kC4A)) * 16 + (s & 15) : s / kC4A, c4 = kAG ? (s % (16 * kC4A)) >> 4 : s % kC4A;
+      int row = s / kC4A, c4 = s % kC4A;
+      if constexpr (kAG) g16_slot(s, kC4A, row, c4);
       const int col = 4 * c4 + 4 <= N ? 4 * c4 : N - 4;      // padding columns re-read the last real ones (never reduced)
       rowA[r] = row;
       offA[r] = kAG ? static_cast<unsigned>(((mb0 * 32 + (row & 16)) * N + col * 16 + (row & 15) * 4) * 4)
@@ -219,7 +231,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   for (int r = 0; r < RB; ++r) {
     int s = tid + 256 * r;
     s = s < 32 * kC4B ? s : s - 256;
-    const int row = kBG ? (s / (16 * kC4B)) * 16 + (s & 15) : s / kC4B, c4 = kBG ? (s % (16 * kC4B)) >> 4 : s % kC4B;
+    int row = s / kC4B, c4 = s % kC4B;
+    if constexpr (kBG) g16_slot(s, kC4B, row, c4);
     const int col = k_off + (4 * c4 + 4 <= Kpart ? 4 * c4 : Kpart - 4);
     rowB[r] = row;
     if constexpr (H0) {
@@ -502,7 +515,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const int s = tid + 256 * r;
-      const int srow = kAG ? (s / (16 * kC4A)) * 16 + (s & 15) : s / kC4A, sc4 = kAG ? (s % (16 * kC4A)) >> 4 : s % kC4A;
+      int srow = s / kC4A, sc4 = s % kC4A;
+      if constexpr (kAG) g16_slot(s, kC4A, srow, sc4);
       if (s < 32 * kC4A) *reinterpret_cast<f32x4 *>(dbl + srow * kColsA + 4 * sc4) = dbsum[r];
     }
     __syncthreads();
