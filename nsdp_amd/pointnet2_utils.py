@@ -81,15 +81,27 @@ def rel_coords4(query: torch.Tensor, source: torch.Tensor, idx: torch.Tensor, si
 # NSDP_SCATTER_ROWS=atomic keeps the atomic kernel (A/B knob).
 _SCATTER_INVERSE = __import__("os").environ.get("NSDP_SCATTER_ROWS", "inverse") != "atomic"
 _SCATTER_INVERSE_MIN_ROWS = 4096        # rows per launch below which one atomic launch beats invert + segment sum
+# ... which is taken only with NSDP_SCATTER_DETERMINISTIC=0: by default a scatter goes through the lists at every size, so that a
+# train step's result never depends on the order in which fp32 atomics retire (the replay-equals-eager tests hold every model to that)
+_SCATTER_DETERMINISTIC = __import__("os").environ.get("NSDP_SCATTER_DETERMINISTIC", "1") != "0"
 
 
 def scatter_add_rows(grad_out: torch.Tensor, idx: torch.Tensor, N: int) -> torch.Tensor:
     B, S, C = grad_out.shape
     # (average list length S / N <= 64: the list build sorts every list with one thread -- long lists, e.g. 57 344 gathers
     # of 100 anchors, cost more to build than the atomics cost)
-    if (_SCATTER_INVERSE and C % 4 == 0 and 4 <= C <= 256 and 0 < int(N) <= 8192 and B * S >= _SCATTER_INVERSE_MIN_ROWS
-            and S <= 64 * int(N) and grad_out.is_cuda and grad_out.dtype is torch.float32 and grad_out.is_contiguous()):
+    # Rows of any width: a width that is not a multiple of 4 -- the COORDINATE gradients of FlowArbitrary's second network,
+    # whose input points are the first network's predictions (reference model/flow_arbitrary.py:19-27) -- is zero-padded to
+    # float4 rows for the list kernel; through the atomic kernel those three-float rows made the whole step depend on the order
+    # in which atomics retire (two eager runs of one FlowArbitrary step differed in 1589 of 1813 tensors).  _SCATTER_DETERMINISTIC
+    # (default on) also takes the lists below the row count where one atomic launch is faster.
+    if (_SCATTER_INVERSE and 1 <= C <= 256 and 0 < int(N) <= 8192 and S <= 64 * int(N) and S > 0
+            and (B * S >= _SCATTER_INVERSE_MIN_ROWS or _SCATTER_DETERMINISTIC)
+            and grad_out.is_cuda and grad_out.dtype is torch.float32 and grad_out.is_contiguous()):
         from . import hip_attention
+        if C % 4:
+            padded = torch.nn.functional.pad(grad_out, (0, 4 - C % 4))
+            return hip_attention.segment_sum(padded, idx, int(N), 1.0)[:, :, :C].contiguous()
         return hip_attention.segment_sum(grad_out, idx, int(N), 1.0)
     out = torch.empty((B, int(N), C), dtype=torch.float32, device=grad_out.device)
     with on_device(grad_out):

@@ -116,6 +116,87 @@ def test_replayed_step_is_bit_equal_to_the_eager_step(B, npl, ns, nq):
         gs.close()
 
 
+def _make_any(cfg, seed, data, lr=5e-5):
+    """(model, optimizer, step) for either model type: the step is the reference's train_on_batch without the host read-back
+    (train_fn.tensor_step: model/deformation_networks.py:63-77, model/flow_arbitrary.py:30-48)."""
+    from nsdp_amd.model import optimizer_factory
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    model.train()
+    _, opt = optimizer_factory({"optimizer": "Adam", "lr": lr}, model.parameters())
+    return model, opt, (lambda: train_fn.tensor_step(model, opt, data, cfg))
+
+
+@pytest.mark.parametrize("mtype,dtype,B,npl,ns,nq", [
+    ("arbitrary", "f32", 2, [256, 64, 16], 256, 128),            # FlowArbitrary, tiny
+    ("arbitrary", "f32", 8, [2048, 500, 100], 2048, 8192),       # FlowArbitrary at full point counts (config 3's function)
+    ("forward", "bf16", 2, [256, 64, 16], 256, 128),             # bf16 storage, tiny
+    ("forward", "bf16", 16, [2048, 500, 100], 2048, 8192),       # bf16 storage at the shape class bench.py --dtype bf16 times
+    ("arbitrary", "bf16", 2, [256, 64, 16], 256, 128),
+    ("arbitrary", "bf16", 8, [2048, 500, 100], 2048, 8192),      # what bench.py --workload arbitrary_train --dtype bf16 replays
+])
+def test_replayed_arbitrary_and_bf16_steps_are_bit_equal_to_the_eager_step(mtype, dtype, B, npl, ns, nq, monkeypatch):
+    """The launcher of BASELINE config 3 under the same race detector as the fp32 forward model above: a FlowArbitrary step
+    (reference model/flow_arbitrary.py:15-48: two networks, ONE encoder pass per cloud here, BatchNorm buffers updated twice
+    per step -- `num_batches_tracked` advances by 2 --, a coordinate-gradient path through the second network's geometry) and
+    the bf16-storage step, captured and replayed on 1 / 2 / 4 streams, must reproduce the eager step's loss, EVERY gradient,
+    weight and BatchNorm buffer bit for bit over two steps.
+    The eager step takes the weight-gradient side stream here as a captured step always does (NSDP_WGRAD_STREAM=1): below
+    131 072 output rows the eager launcher would keep the weight gradients on the main stream, where their partial sums are
+    split over all 256 compute units instead of 256 - SIDE_RESERVE_CUS -- another, equally valid rounding (measured at B = 8:
+    188 of 521 gradients differ, by <= 2e-9 absolute; no race: with the same stream decision the two are equal)."""
+    from helpers import nondeterministic_knobs
+    if nondeterministic_knobs():
+        pytest.skip("the step is not bit-reproducible under " + ", ".join(nondeterministic_knobs()))
+    from nsdp_amd import hip_linear, precision
+    if hip_linear._OVERLAP_WGRAD == "auto":      # (NSDP_WGRAD_STREAM=0 / 1: eager and captured steps decide alike anyway)
+        monkeypatch.setattr(hip_linear, "_OVERLAP_WGRAD", True)
+    from nsdp_amd.graph_step import GraphedStep, capturable_adam
+    cfg = model_cfg(mtype, npl)
+    data = to_dev(synth.make_batch(193, B, ns, nq), DEV)
+    with precision.storage(dtype):
+        model, opt, step = _make_any(cfg, 193, data)
+        capturable_adam(opt)
+        snap = snapshot_model(model)
+        step()                                     # creates the optimizer state (a capture must find it in place)
+        torch.cuda.synchronize()
+
+        def two_steps(run):
+            restore_model(model, snap, opt)
+            out = []
+            for _ in range(2):
+                loss = run()
+                torch.cuda.synchronize()
+                out.append({"loss": loss.detach().clone(),
+                            "grads": {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                            "state": snapshot_model(model)})
+            return out
+
+        def diff(a, b):
+            bad = []
+            for i, (x, y) in enumerate(zip(a, b)):
+                if not torch.equal(x["loss"], y["loss"]):
+                    bad.append(f"step {i} loss {float(x['loss'])!r} vs {float(y['loss'])!r}")
+                assert x["grads"].keys() == y["grads"].keys()
+                bad += [f"step {i} grad {k}" for k in x["grads"] if not torch.equal(x["grads"][k], y["grads"][k])]
+                bad += [f"step {i} state {k}" for k in x["state"] if not torch.equal(x["state"][k], y["state"][k])]
+            return bad
+
+        eager = two_steps(step)
+        if mtype == "arbitrary":      # every BatchNorm of a network that runs twice per step counts two batches per step
+            nbt = [int(v) - int(snap[k]) for k, v in eager[0]["state"].items() if k.endswith("num_batches_tracked")]
+            assert nbt and set(nbt) <= {1, 2} and 2 in nbt, sorted(set(nbt))
+        again = diff(eager, two_steps(step))
+        assert not again, f"the eager {mtype} / {dtype} step is not deterministic: {len(again)} tensors differ, first {again[:6]}"
+        for streams in (1, 2, 4):
+            restore_model(model, snap, opt)
+            gs = GraphedStep(step, max_streams=streams).capture(warmup=0)      # (a capture executes nothing)
+            if streams > 1:
+                assert gs.info["streams"] >= 2 and gs.info["cross_stream_edges"] >= 2, gs.info
+            bad = diff(eager, two_steps(gs))
+            assert not bad, f"replay on {streams} stream(s) vs eager: {len(bad)} tensors differ, first: {bad[:8]}"
+            gs.close()
+
+
 def test_set_lr_changes_the_update_of_a_replayed_step():
     from nsdp_amd.graph_step import GraphedStep, capturable_adam, set_lr
     cfg = model_cfg("forward", [256, 64, 16])

@@ -256,6 +256,16 @@ def test_full_shape_arbitrary_eval_and_train_step_match_golden():
     assert any(n.startswith("linear_bf16x3<") for n in names), names
 
 
+def test_full_shape_arbitrary_replayed_train_step_matches_golden():
+    """The same FlowArbitrary step as above (B = 2, 2048 + 8192 points, the imported reference's fixture) as bench.py's config-3
+    launcher runs it: captured once, REPLAYED through the multi-stream executor -- loss, None-gradient set, gradient norms,
+    BatchNorm statistics of the replay against the reference (the replay-equals-eager race detector for this model:
+    tests/test_graph_exec_gpu.py::test_replayed_arbitrary_and_bf16_steps_are_bit_equal_to_the_eager_step)."""
+    fx, cfg, seed, data = fixture_setup("full_arbitrary", "arbitrary")
+    model, train_fn, _ = build_product(cfg, seed, DEV)
+    _check_train_step(fx, model, train_fn, cfg, data, chaotic_prefix="model_", replay=True)
+
+
 def test_b8_arbitrary_eval_matches_golden_and_train_step_matches_the_oracle_network_by_network():
     """FlowArbitrary (BASELINE config 3's function) at B = 8 full-size shapes: 458 752 rows in each decoder's attention layers and
     163 840 in the first encoder blocks, i.e. the at-scale bf16x3 forward / dX / weight-gradient kernels, the one-hot scatter and
