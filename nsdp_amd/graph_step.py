@@ -21,6 +21,7 @@ Rules of the capture (the same as for any CUDA / HIP graph):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import gc
 import os
@@ -115,8 +116,11 @@ class GraphedStep:
         from . import hip_adam
         self._pinned = []      # pinned table buffers the captured optimizer step copies from: they live as long as this graph
         hip_adam._capture_hosts = self._pinned
+        from . import hip_batchnorm
+        self._frozen_consts = []      # cached inference constants a frozen-weights graph reads (hip_batchnorm.frozen_capture)
+        frozen = hip_batchnorm.frozen_capture(self._frozen_consts) if not self.weights_change else contextlib.nullcontext()
         try:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with frozen, torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = self.fn()
         finally:
             hip_adam._capture_hosts = None
@@ -250,7 +254,10 @@ class PipelinedGeometry:
         if self.current is None:
             self.current = g
         else:
-            for a, b in zip(_geometry_tensors(self.current), _geometry_tensors(g)):
+            cur, new = _geometry_tensors(self.current), _geometry_tensors(g)
+            if len(cur) != len(new) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(cur, new)):
+                raise RuntimeError("PipelinedGeometry: this batch's index sets do not have the shapes of the buffers in place")
+            for a, b in zip(cur, new):
                 a.copy_(b)
         return self.current
 
@@ -275,7 +282,12 @@ class PipelinedGeometry:
         main = torch.cuda.current_stream(cur[0].device)
         main.wait_stream(self._stream)
         for a, b in zip(cur, nxt):
-            torch.add(b, 0, out=a)      # (a kernel node: a memcpy node is replayed by the executor as a graph of its own)
+            # a kernel node (a memcpy node is replayed by the executor as a graph of its own), on the BITS: an integer add of 0
+            # -- a float add would turn -0.0 into +0.0 in the coordinate tensors
+            if a.dtype.is_floating_point and a.element_size() == 4:
+                torch.add(b.view(torch.int32), 0, out=a.view(torch.int32))
+            else:
+                torch.add(b, 0, out=a)
             b.record_stream(main)
         self._next = None
 
@@ -289,9 +301,11 @@ class GraphedTrainOnBatch:
     like the reference -- that read-back is the one host sync per step the reference has as well.
 
     ``reducer`` (nsdp_amd.parallel.GradAllReducer): this process is one rank of a data-parallel job.  A collective cannot be
-    captured, so the step becomes TWO graphs around the eager gradient exchange -- [zero the flat gradient, forward, loss,
-    backward] and [optimizer.step] -- with the RCCL all-reduce enqueued between them on the same stream; eager steps (the
-    first one, odd shapes) run the exchange as a pre-hook of ``optimizer.step``.  The returned loss is this rank's."""
+    captured, so the step becomes one graph per side of each collective -- [zero the flat gradient, forward, loss, the
+    decoder's backward] | all-reduce of bucket 0, asynchronous | [the encoder's backward] | all-reduce of bucket 1, wait for
+    both | [optimizer.step] -- with the RCCL calls enqueued eagerly between the replays: the decoder's gradients travel under
+    the encoder's backward pass.  Eager steps (the first one, odd shapes) run the same two-pass backward
+    (GradAllReducer.backward).  The returned loss is this rank's."""
 
     def __init__(self, train_on_batch, max_streams: int | None = None, reducer=None, pipeline_geometry=None):
         if not hasattr(train_on_batch, "tensor_step"):
@@ -314,6 +328,7 @@ class GraphedTrainOnBatch:
         self._shapes = None
         self._static = None
         self._step = None
+        self._tail = None
         self._update = None
         self.replays = self.eager_calls = 0
 
@@ -325,8 +340,13 @@ class GraphedTrainOnBatch:
         self.eager_calls += 1
         if self.reducer is None:
             return float(self.eager.tensor_step(model, optimizer, data_dict, config))
-        from .parallel import data_parallel_step
-        return float(data_parallel_step(self.eager.tensor_step, self.reducer)(model, optimizer, data_dict, config))
+        red = self.reducer
+        red.zero_grad(two_pass=True)
+        loss = self.eager.loss_fn(model, data_dict, config)
+        red.backward(loss)
+        red.finish()
+        optimizer.step()
+        return float(loss)
 
     @staticmethod
     def _same_batch(announced, data_dict):
@@ -369,15 +389,26 @@ class GraphedTrainOnBatch:
             else:
                 red = self.reducer
 
-                def fwd_bwd():
-                    red.zero_grad()
-
-                    def inner(g):      # (the hand-over overwrites the index sets the backward pass reads: backward first)
-                        loss = self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {}))
+                def head():
+                    red.zero_grad(two_pass=True)
+                    if piped:
+                        self._pipe.prefetch(self._static_next)
+                    g = self._pipe.current if piped else None
+                    loss = self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {}))
+                    if not red.backward_head(loss):      # (no cut: the whole backward here, an empty tail)
                         loss.backward()
-                        return loss
-                    return piped_fn(inner)
-                self._step = GraphedStep(fwd_bwd, streams).capture(warmup=0)
+                    return loss
+
+                def tail():
+                    red.backward_tail()
+                    if piped:      # (the hand-over overwrites the index sets the backward pass reads: backward first)
+                        self._pipe.rotate()
+                    return red.flat
+                self._step = GraphedStep(head, streams).capture(warmup=0)
+                red.start(0)
+                # (the tail rebuilds no weight pack -- it runs on what the head's forward saved: a frozen-weights capture)
+                self._tail = GraphedStep(tail, streams, weights_change=False).capture(warmup=0)
+                red.finish()
                 self._update = GraphedStep(lambda: optimizer.step(), self.max_streams).capture(warmup=0)
         announced = self._pipe is not None and self._same_batch(self._announced, data_dict)
         for k, v in data_dict.items():
@@ -409,6 +440,8 @@ class GraphedTrainOnBatch:
         self.replays += 1
         loss = self._step()
         if self.reducer is not None:
-            self.reducer.all_reduce_mean()
+            self.reducer.start(0)          # the decoder's gradients: under the encoder's backward
+            self._tail()
+            self.reducer.finish()          # bucket 1, then the wait for both
             self._update()
         return float(loss)

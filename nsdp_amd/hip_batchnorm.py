@@ -14,6 +14,27 @@ _RUNNING_UPDATES = 1
 _stats_epoch = 0        # advanced by every training-mode norm: keys the cached inference constants (batch_norm)
 
 
+_frozen_capture = None      # a list while a GraphedStep(weights_change=False) captures: the cached constants its graph reads
+
+
+class frozen_capture:
+    """Context of a capture over FROZEN weights and buffers: the cached inference constants may be read (their addresses go into
+    the graph); ``keep`` receives the tensors so that the graph's owner keeps them alive."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+    def __enter__(self):
+        global _frozen_capture
+        self._was, _frozen_capture = _frozen_capture, self.keep
+        return self
+
+    def __exit__(self, *exc):
+        global _frozen_capture
+        _frozen_capture = self._was
+        return False
+
+
 def invalidate_inference_constants():
     """Declare every cached 1 / sqrt(running_var + eps) stale.  Training-mode norms do it themselves; a REPLAY of a captured
     train step runs them without any Python (nsdp_amd.graph_step calls this after every replay, next to the weight packs)."""
@@ -153,9 +174,14 @@ def batch_norm(x, bn: torch.nn.BatchNorm1d, addend=None, relu=False):
         if hit is None or hit[0] != key:
             hit = bn.__dict__["_nsdp_invstd"] = (key, torch.rsqrt(rv + float(bn.eps)))
         infer = hit[1]
-    elif not torch.is_grad_enabled():
+    elif not torch.is_grad_enabled() and _frozen_capture is not None:
+        # inside a capture whose owner declared the weights FROZEN (GraphedStep(weights_change=False)): the cached constant's
+        # address goes into the graph, which keeps the tensor alive (_frozen_capture collects it).  Any other capture -- an eval
+        # step replayed while training continues -- computes the rsqrt as a node of the graph: a cached tensor would be frozen
+        # into every replay next to the LIVE running_mean, and freed under the graph by the next eager evaluation.
         hit = bn.__dict__.get("_nsdp_invstd")
         if hit is not None and hit[0] == (rv.data_ptr(), rv._version, _stats_epoch, float(bn.eps)):
             infer = hit[1]
+            _frozen_capture.append(infer)
     return _BatchNormFn.apply(x, addend, bn.weight, bn.bias, rm, rv, training, momentum, float(bn.eps), bool(relu), nbt,
                               updates, infer)

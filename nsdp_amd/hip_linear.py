@@ -619,9 +619,26 @@ def _pack_key(t):
     return (t.data_ptr(), t._version, _weights_epoch)
 
 
+def _param_key(t):
+    """Identity of ONE parameter's values between a forward pass and its backward pass (the position-encoding MLPs and the
+    K = 4 layers recompute from the parameters in backward what forward computed from them): storage pointer, version counter
+    and the number of optimizer steps that touched THIS parameter (`_after_optimizer_step`).  Not the global weights epoch of
+    the pack caches: that one advances with every optimizer step of ANY model of the process and with every replay of a
+    captured step -- a two-model loop that stepped model B between model A's forward and backward would be told that A's
+    first layer had changed."""
+    return (t.data_ptr(), t._version, t.__dict__.get("_nsdp_steps", 0))
+
+
+def _after_optimizer_step(opt):
+    invalidate_weight_packs()
+    for group in opt.param_groups:
+        for prm in group["params"]:
+            prm.__dict__["_nsdp_steps"] = prm.__dict__.get("_nsdp_steps", 0) + 1
+
+
 try:
     from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
-    _reg_post_hook(lambda _opt, _args, _kwargs: invalidate_weight_packs())
+    _reg_post_hook(lambda _opt, _args, _kwargs: _after_optimizer_step(_opt))
 except ImportError:      # (PyTorch without global optimizer hooks: the version counter is all there is)
     pass
 
@@ -938,14 +955,14 @@ class _PosMlpFn(torch.autograd.Function):
         ctx.save_for_backward(x4, w4, b0, wpt)
         ctx.params = (w0_param, b0_param, w1_param, b1_param)
         ctx.k_orig0, ctx.n_out, ctx.hidden = k_orig0, N, K
-        ctx.fwd_key = (_pack_key(w0_param), None if b0_param is None else _pack_key(b0_param))
+        ctx.fwd_key = (_param_key(w0_param), None if b0_param is None else _param_key(b0_param))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x4, w4, b0, wpt = ctx.saved_tensors
         w0_param, b0_param, w1_param, b1_param = ctx.params
-        if ctx.fwd_key != (_pack_key(w0_param), None if b0_param is None else _pack_key(b0_param)):
+        if ctx.fwd_key != (_param_key(w0_param), None if b0_param is None else _param_key(b0_param)):
             raise RuntimeError("position-encoding MLP: its first layer changed between forward and backward; the hidden tensor "
                                "is recomputed from the parameters (NSDP_H0_RECOMPUTE=0 keeps it)")
         N, K = ctx.n_out, ctx.hidden
@@ -1081,7 +1098,7 @@ class _LinearFn(torch.autograd.Function):
                         and res2 is None and grad_sum is None and not bw and N % 4 == 0):
                     tlink.armed = True
                     tlink.x4, tlink.w_param, tlink.b_param, tlink.k_orig = x2, w_param, b_param, K
-                    tlink.fwd_key = _pack_key(w_param)
+                    tlink.fwd_key = _param_key(w_param)
                     ctx.set_materialize_grads(False)      # (a taken link: this node's backward receives None)
             elif (tlink.armed and want_t and not relu_in and not (bw & 2) and grad_sum is None and ctx.skip_dst is None
                   and Kp == K and N % 4 == 0 and M == tlink.x4.shape[0]):
@@ -1100,7 +1117,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
-        ctx.fwd_key = _pack_key(w_param) if w_param is not None else None
+        ctx.fwd_key = _param_key(w_param) if w_param is not None else None
         ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None)
         return y.reshape(*x.shape[:-1], N)
 
@@ -1119,7 +1136,7 @@ class _LinearFn(torch.autograd.Function):
             if lay:      # LAY_Y: dY (and the mask y) arrive in G16; LAY_X: the input x2 is
                 fn = _wgrad_g16_fn(1 if lay == LAY_Y else 2)
             elif (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
-                    and x2.shape[0] >= 4096 and not ctx.has_res and ctx.fwd_key == _pack_key(ctx.w_param)):
+                    and x2.shape[0] >= 4096 and not ctx.has_res and ctx.fwd_key == _param_key(ctx.w_param)):
                 # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates.
                 # Only when the recomputed expression IS the forward one: no residual operand (the mask would be that of
                 # relu(xW+b+res)), and the parameters are still the forward pass's (same pointer / version / epoch; a
@@ -1136,7 +1153,7 @@ class _LinearFn(torch.autograd.Function):
             else:
                 dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         tl = ctx.tail
-        if tl is not None and ctx.needs_input_grad[0] and tl.fwd_key == _pack_key(tl.w_param):
+        if tl is not None and ctx.needs_input_grad[0] and tl.fwd_key == _param_key(tl.w_param):
             # the dX GEMM with the K = 4 layer's weight gradient in its epilogue: no input gradient to report
             # -- and since nothing on the critical chain reads that gradient, the whole GEMM is weight-gradient work: side stream
             tfn = _k4tail_fn(tl, wpt, x2.shape[1], ctx.kind_t, x2)

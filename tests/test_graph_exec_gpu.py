@@ -197,6 +197,40 @@ def test_replayed_arbitrary_and_bf16_steps_are_bit_equal_to_the_eager_step(mtype
             gs.close()
 
 
+def test_an_eval_step_captured_with_changing_weights_follows_the_training_in_between():
+    """GraphedStep(weights_change=True) over an EVAL forward is replay-safe while training continues: weight packs are rebuilt
+    at the head of every replay, and the BatchNorm inference constant 1 / sqrt(running_var + eps) must be a NODE of the graph,
+    not the tensor an earlier eager evaluation cached on the module (that tensor would be frozen into every replay next to
+    the live running_mean, and freed under the graph by the next eager evaluation).  Sequence: eager eval (fills the caches),
+    capture, train steps, replay == eager eval at the new weights and statistics, bit for bit; again after more training."""
+    from nsdp_amd.graph_step import GraphedStep
+    from nsdp_amd.model import optimizer_factory
+    cfg = model_cfg("forward", [256, 64, 16])
+    data = to_dev(synth.make_batch(94, 2, 256, 128), DEV)
+    model, train_fn, _ = build_product(cfg, 94, DEV)
+    _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4}, model.parameters())
+
+    def evaluate():
+        with torch.no_grad():
+            return model(data["space_samples_src"], data["surface_samples_inputs"])
+    model.eval()
+    first = evaluate().clone()
+    gs = GraphedStep(evaluate, weights_change=True).capture(warmup=1)
+    for rounds in range(2):
+        model.train()
+        for _ in range(3):
+            train_fn(model, opt, data, cfg)
+        model.eval()
+        got = gs().clone()
+        torch.cuda.synchronize()
+        want = evaluate()
+        torch.cuda.synchronize()
+        assert not torch.equal(want, first)                     # (training moved the weights and the running statistics)
+        assert torch.equal(got, want), float((got - want).abs().max())
+        evaluate()                                              # (an eager evaluation replaces the modules' cached constants)
+    gs.close()
+
+
 def test_set_lr_changes_the_update_of_a_replayed_step():
     from nsdp_amd.graph_step import GraphedStep, capturable_adam, set_lr
     cfg = model_cfg("forward", [256, 64, 16])

@@ -410,12 +410,18 @@ def test_b16_train_step_matches_golden():
     assert eight_wave, names
     from nsdp_amd.model import ops
     masked = () if ops.PAIR_MASK else ("wgrad_bf16x3<13,13,mask,notail>",)   # (NSDP_PAIR_MASK=1 removes the masked variants)
+    g16 = hip_linear.G16 and not ops.PAIR_MASK
+    if g16:      # the hidden tensors of fc_gamma (and their gradients) in the G16 layout: every form of the pair ran
+        masked = ("wgrad_bf16x3<13,13,mask,notail> g16:dy",)
+        assert any(n.startswith("linear_bf16x3<") and n.endswith(" g16:y") for n in names), sorted(names)
+        assert any(n.startswith("linear_bf16x3<") and n.endswith(" g16:x") for n in names), sorted(names)
     from nsdp_amd import hip_attention
     # (the decoder's anchor-table gradients: scatter as a GEMM + the atomics-free attention backward, or the fp32-atomic
     # kernels under NSDP_ONEHOT_SCATTER_F32=0)
     scatter = (("attn_post_bwd_det", "scatter_rows_onehot_f32<8,13,notail>") if hip_attention.ONEHOT_SCATTER_F32
                else ("attn_post_bwd_lds", "scatter_rows_regtab<8>"))
-    for needed in scatter + ("wgrad_bf16x3<13,13,plain,notail>",) + masked:
+    plain = "wgrad_bf16x3<13,13,plain,notail> g16:x" if g16 else "wgrad_bf16x3<13,13,plain,notail>"
+    for needed in scatter + (plain,) + masked:
         assert needed in names, (needed, sorted(names))
 
 

@@ -84,6 +84,112 @@ def test_grad_allreduce_matches_single_process_world2():
         assert nbytes == 4 * (5 * 4 + 4 + 9 + 4 * 2 + 2)
 
 
+class _ToyDecoder(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(4, 2)
+        self.q = torch.nn.Linear(3, 2, bias=False)
+
+    def forward(self, points, encoding):
+        return self.lin(encoding["anchor_feats"]) * encoding["z"] + self.q(points)
+
+
+class _ToyNet(torch.nn.Module):
+    """The TDNet's shape: an encoder whose outputs (a dict) and the query points are the decoder's inputs."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = torch.nn.Linear(5, 4)
+        self.mid = torch.nn.Linear(4, 2)
+        self.decoder = _ToyDecoder()
+
+    def forward(self, points, x):
+        f = torch.tanh(self.encoder(x))
+        return self.decoder(points, {"z": self.mid(f), "anchor_feats": f, "anchors": x.detach()})
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nsdp_amd.parallel import GradAllReducer
+        g = torch.Generator().manual_seed(100)
+        x_all, p_all, y_all = (torch.randn(world * 6, n, generator=g) for n in (5, 3, 2))
+        sl = slice(rank * 6, (rank + 1) * 6)
+        torch.manual_seed(rank)                   # ranks start DIFFERENT ...
+        model = _ToyNet()
+        for p in model.parameters():              # ... and are made equal by a broadcast, as the harness does
+            dist.broadcast(p.data, src=0)
+        reducer = GradAllReducer(model, world)
+        assert reducer.named[0][0].startswith("decoder.") and 0 < reducer.split < reducer.flat.numel()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        order = []
+        orig_start = reducer.start
+        reducer.start = lambda i: (order.append(("start", i)), orig_start(i))[1]
+        orig_tail = reducer.backward_tail
+        reducer.backward_tail = lambda: (order.append(("tail",)), orig_tail())[1]
+        # reference on this rank: the same model stepped with ONE backward pass and the whole exchange after it
+        ref = _ToyNet()
+        ref.load_state_dict(model.state_dict())
+        ref_red = GradAllReducer(ref, world)
+        ref_opt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+        for _ in range(3):
+            reducer.zero_grad(two_pass=True)
+            loss = ((model(p_all[sl], x_all[sl]) - y_all[sl]) ** 2).mean()
+            reducer.backward(loss)
+            assert reducer._pending[0] is not None                   # bucket 0 is in flight when backward() returns
+            reducer.finish()
+            opt.step()
+            ref_red.zero_grad()
+            ((ref(p_all[sl], x_all[sl]) - y_all[sl]) ** 2).mean().backward()
+            ref_red.all_reduce_mean()
+            ref_opt.step()
+        # bucket 0's collective was enqueued BEFORE the encoder's backward pass, every step
+        # (finish() calls start() again for both buckets: no-ops once started)
+        tails = [i for i, e in enumerate(order) if e == ("tail",)]
+        assert len(tails) == 3 and all(order[i - 1] == ("start", 0) and order[i + 1] == ("start", 1) for i in tails), order
+        assert reducer.enqueued_before_backward_returned == 3
+        same_as_one_pass = all(torch.equal(a, b) for a, b in zip(model.parameters(), ref.parameters()))
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        lo, hi = w.clone(), w.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        # single-process run on the full batch
+        full = _ToyNet()
+        torch.manual_seed(0)
+        full = _ToyNet()
+        fopt = torch.optim.Adam(full.parameters(), lr=1e-2)
+        for _ in range(3):
+            fopt.zero_grad()
+            ((full(p_all, x_all) - y_all) ** 2).mean().backward()
+            fopt.step()
+        err = max(float((a - b).abs().max()) for a, b in zip(model.parameters(), full.parameters()))
+        out.put((rank, same_as_one_pass, bool(torch.equal(lo, hi)), err))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_pass_backward_issues_the_decoder_bucket_before_the_encoder_backward_world2():
+    """GradAllReducer.backward: d(loss) / d(decoder inputs) first, bucket 0's all-reduce enqueued, then the encoder's backward,
+    then bucket 1 -- asserted by the ORDER of the calls, every step; gradients and weights equal the one-pass step's bit for bit,
+    ranks end bit-identical, and the trajectory is the single-process full-batch one."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=100) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, same_as_one_pass, in_sync, err in res:
+        assert same_as_one_pass, rank
+        assert in_sync, rank
+        assert err < 1e-6, (rank, err)
+
+
 def test_flat_bucket_layout_for_tdnet():
     """Forward TDNet: 4 492 267 fp32 parameters = 17.97 MB exchanged per step, decoder first."""
     from helpers import model_cfg
