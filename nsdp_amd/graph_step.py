@@ -307,7 +307,7 @@ class GraphedTrainOnBatch:
     the encoder's backward pass.  Eager steps (the first one, odd shapes) run the same two-pass backward
     (GradAllReducer.backward).  The returned loss is this rank's."""
 
-    def __init__(self, train_on_batch, max_streams: int | None = None, reducer=None, pipeline_geometry=None):
+    def __init__(self, train_on_batch, max_streams: int | None = None, reducer=None, pipeline_geometry=None, overlap=None):
         if not hasattr(train_on_batch, "tensor_step"):
             raise TypeError("train_on_batch has no `tensor_step` form (the step without its loss.item())")
         if reducer is not None and not hasattr(train_on_batch, "loss_fn"):
@@ -316,6 +316,12 @@ class GraphedTrainOnBatch:
         self.max_streams = max_streams
         self.reducer = reducer
         self.exchanges_gradients = reducer is not None      # (nsdp_amd.train.fit: do not wrap me again)
+        # ``overlap``: the decoder bucket's all-reduce under the encoder's backward pass (two autograd passes).  None = NSDP_DP_OVERLAP
+        # or "auto": on for eager steps, OFF for the captured step -- each graph boundary joins the executor's streams, and the
+        # head / tail boundary costs the overlap of the decoder's weight gradients with the encoder's backward chain (measured at
+        # one rank, B = 32: 38.2-38.3 ms plain, 38.75-38.9 with two graphs, 39.5-39.7 with three; the exchange itself is 0.05-0.2 ms)
+        mode = os.environ.get("NSDP_DP_OVERLAP", "auto") if overlap is None else ("on" if overlap else "off")
+        self.overlap_eager, self.overlap_graph = mode != "off", mode == "on"
         # ``pipeline_geometry``: a function data_dict -> (points, surface inputs) -- the replayed step then takes its index sets
         # from a PipelinedGeometry and computes the NEXT batch's (``next_data_dict=`` of the call) beside itself.  A batch that
         # was not announced that way costs one eager geometry pass before its replay; results never depend on it.
@@ -341,7 +347,7 @@ class GraphedTrainOnBatch:
         if self.reducer is None:
             return float(self.eager.tensor_step(model, optimizer, data_dict, config))
         red = self.reducer
-        red.zero_grad(two_pass=True)
+        red.zero_grad(two_pass=self.overlap_eager)
         loss = self.eager.loss_fn(model, data_dict, config)
         red.backward(loss)
         red.finish()
@@ -390,13 +396,15 @@ class GraphedTrainOnBatch:
                 red = self.reducer
 
                 def head():
-                    red.zero_grad(two_pass=True)
+                    red.zero_grad(two_pass=self.overlap_graph)
                     if piped:
                         self._pipe.prefetch(self._static_next)
                     g = self._pipe.current if piped else None
                     loss = self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {}))
-                    if not red.backward_head(loss):      # (no cut: the whole backward here, an empty tail)
+                    if not red.backward_head(loss):      # (no cut: the whole backward here, no tail graph)
                         loss.backward()
+                        if piped:
+                            self._pipe.rotate()
                     return loss
 
                 def tail():
@@ -405,9 +413,10 @@ class GraphedTrainOnBatch:
                         self._pipe.rotate()
                     return red.flat
                 self._step = GraphedStep(head, streams).capture(warmup=0)
-                red.start(0)
-                # (the tail rebuilds no weight pack -- it runs on what the head's forward saved: a frozen-weights capture)
-                self._tail = GraphedStep(tail, streams, weights_change=False).capture(warmup=0)
+                if red._root_grads is not None:      # the forward was cut: the encoder's backward is a graph of its own
+                    red.start(0)
+                    # (the tail rebuilds no weight pack -- it runs on what the head's forward saved: a frozen-weights capture)
+                    self._tail = GraphedStep(tail, streams, weights_change=False).capture(warmup=0)
                 red.finish()
                 self._update = GraphedStep(lambda: optimizer.step(), self.max_streams).capture(warmup=0)
         announced = self._pipe is not None and self._same_batch(self._announced, data_dict)
@@ -440,8 +449,9 @@ class GraphedTrainOnBatch:
         self.replays += 1
         loss = self._step()
         if self.reducer is not None:
-            self.reducer.start(0)          # the decoder's gradients: under the encoder's backward
-            self._tail()
-            self.reducer.finish()          # bucket 1, then the wait for both
+            if self._tail is not None:
+                self.reducer.start(0)      # the decoder's gradients: under the encoder's backward
+                self._tail()
+            self.reducer.finish()          # bucket 1 (or both), then the wait
             self._update()
         return float(loss)

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(*flags):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "2", *flags],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+                         capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, NSDP_BENCH_REQUIRE_GRAPH="1"))      # (a capture that fails must fail the test, not fall back)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -72,4 +73,8 @@ def test_bench_graph_replay_is_the_default_and_eager_is_still_there():
     # (that the two ways of launching the step train alike is tests/test_graph_exec_gpu.py's subject: the runs here differ
     # in their number of set-up steps)
     f = _run("--no-cpu-baseline", "--reps", "1", "--force-reducer", "--backend", "gloo")
-    assert "two graphs around the eager all-reduce" in f["step_launch"] or f["step_launch"].startswith("eager")
+    assert "two graphs around the eager all-reduce" in f["step_launch"], f["step_launch"]
+    # the decoder bucket's all-reduce under the encoder's backward: one graph per side of each collective
+    f3 = _run("--no-cpu-baseline", "--reps", "1", "--force-reducer", "--backend", "gloo", "--dp-overlap", "on")
+    assert "head / tail / update" in f3["step_launch"], f3["step_launch"]
+    assert f3["ranks_in_sync"] and abs(f3["final_loss"] - f["final_loss"]) <= 1e-6 * max(1.0, abs(f["final_loss"])), (f3["final_loss"], f["final_loss"])

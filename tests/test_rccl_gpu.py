@@ -97,24 +97,73 @@ def test_two_graph_step_around_the_exchange_with_pipelined_geometry_equals_the_e
     batches = [{k: v.to(DEV) for k, v in b.items()} for b in train.SyntheticLoader(5, 3, 2, n_surf=256, n_query=128)]
     seq = [batches[i % 3] for i in range(7)]
     losses = []
-    for mode in ("eager", "piped"):
+    for mode in ("eager", "piped", "piped3"):      # piped3: the backward cut at the decoder's inputs, head / tail / update graphs
         train.seed_everything(31)
         model, train_fn, _, _ = build_model(cfg, device=DEV)
         model.train()
         _, opt = optimizer_factory(cfg["training"], model.parameters())
         capturable_adam(opt)
         fn = train_fn
-        if mode == "piped":
+        if mode != "eager":
             red = GradAllReducer(model, 1, always_exchange=True)
-            fn = GraphedTrainOnBatch(train_fn, reducer=red,
+            fn = GraphedTrainOnBatch(train_fn, reducer=red, overlap=(mode == "piped3"),
                                      pipeline_geometry=lambda d: (d["space_samples_src"], d["surface_samples_inputs"]))
         out = []
         for i, b in enumerate(seq):
-            if mode == "piped":
+            if mode != "eager":
                 out.append(fn(model, opt, b, cfg, next_data_dict=seq[i + 1] if i + 1 < len(seq) else None))
             else:
                 out.append(fn(model, opt, b, cfg))
         losses.append(out)
-        if mode == "piped":
+        if mode != "eager":
             assert fn.replays == len(seq) - 1 and fn._pipe is not None and getattr(fn, "unannounced", 0) == 0
-    assert losses[0] == losses[1], losses
+            assert (fn._tail is not None) == (mode == "piped3")
+    assert losses[0] == losses[1] == losses[2], losses
+
+
+@pytest.mark.parametrize("mtype,B,npl,ns,nq", [("forward", 2, [256, 64, 16], 256, 128), ("forward", 16, [2048, 500, 100], 2048, 8192),
+                                             ("arbitrary", 2, [256, 64, 16], 256, 128)])
+def test_two_pass_backward_equals_the_one_pass_backward_and_issues_bucket_0_in_between(rccl_world1, mtype, B, npl, ns, nq):
+    """GradAllReducer.backward on the real networks: the forward pass cut at the (last) decoder's inputs, loss.backward() down to
+    the cut, bucket 0's RCCL all-reduce issued, the encoder's backward from the cut, bucket 1 -- every gradient bit-equal to the
+    one-pass backward's (the cut changes no arithmetic), the early bucket = exactly that decoder's parameters, and its
+    collective in flight before the second pass starts.  FlowArbitrary: the cut also takes the query points, which are the
+    first network's predictions (reference model/flow_arbitrary.py:19-27)."""
+    from helpers import nondeterministic_knobs
+    if nondeterministic_knobs():
+        pytest.skip("the step is not bit-reproducible under " + ", ".join(nondeterministic_knobs()))
+    from nsdp_amd.parallel import GradAllReducer
+    cfg = model_cfg(mtype, npl)
+    data = to_dev(synth.make_batch(23, B, ns, nq), DEV)
+    model, train_fn, _ = build_product(cfg, 23, DEV)
+    model.train()
+    red = GradAllReducer(model, 1, always_exchange=True)
+    prefix = "model_deform.decoder." if mtype == "arbitrary" else "decoder."
+    assert all(n.startswith(prefix) for n, _ in red.named[:3]) and 0 < red.split < red.flat.numel()
+    assert red.split == sum(p.numel() for n, p in model.named_parameters() if n.startswith(prefix))
+    snap = {k: v.detach().clone() for k, v in model.state_dict().items()}      # (train-mode BatchNorm moves its buffers)
+
+    def grads(two_pass):
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(snap[k])
+        red.zero_grad(two_pass=two_pass)
+        loss = train_fn.loss_fn(model, data, cfg)
+        order = []
+        if two_pass:
+            assert red.backward_head(loss)
+            red.start(0)
+            order.append(red._pending[0] is not None)
+            red.backward_tail()
+            red.start(1)
+        else:
+            loss.backward()
+        red.finish()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), red.flat.clone(), order
+    l1, g1, _ = grads(False)
+    l2, g2, order = grads(True)
+    assert order == [True]
+    assert torch.equal(l1, l2)
+    assert float(g1[:red.split].abs().sum()) > 0 and float(g1[red.split:].abs().sum()) > 0
+    assert torch.equal(g1, g2), float((g1 - g2).abs().max())
