@@ -460,7 +460,8 @@ def main():
                     step()
 
                 def head():
-                    if pipe is not None:
+                    # (the search of the next batch's index sets forks a stream that its hand-over joins: both in ONE graph)
+                    if pipe is not None and not (overlap_graph and reducer._can_cut):
                         pipe.prefetch(data_next)
                     reducer.zero_grad(two_pass=overlap_graph)
                     loss = compute_l2_error(forward(), data["space_samples_tgt"])
@@ -471,6 +472,8 @@ def main():
                     return loss
 
                 def tail():
+                    if pipe is not None:
+                        pipe.prefetch(data_next)
                     reducer.backward_tail()
                     if pipe is not None:      # (the hand-over overwrites the index sets the backward pass reads: backward first)
                         pipe.rotate()

@@ -397,7 +397,9 @@ class GraphedTrainOnBatch:
 
                 def head():
                     red.zero_grad(two_pass=self.overlap_graph)
-                    if piped:
+                    # (the search of the next batch's index sets forks a stream that its hand-over joins: both in ONE graph --
+                    # beside the forward pass in the two-graph form, beside the encoder's backward in the tail of the three-graph one)
+                    if piped and not (self.overlap_graph and red._can_cut):
                         self._pipe.prefetch(self._static_next)
                     g = self._pipe.current if piped else None
                     loss = self.eager.loss_fn(model, self._static, config, **({"geometry": g} if g is not None else {}))
@@ -408,6 +410,8 @@ class GraphedTrainOnBatch:
                     return loss
 
                 def tail():
+                    if piped:
+                        self._pipe.prefetch(self._static_next)
                     red.backward_tail()
                     if piped:      # (the hand-over overwrites the index sets the backward pass reads: backward first)
                         self._pipe.rotate()

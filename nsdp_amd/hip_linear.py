@@ -497,6 +497,26 @@ def wgrad_direct(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
                 prm.grad = g if prm.grad is None else prm.grad.add_(g)
 
 
+# A backward pass split in two autograd passes (nsdp_amd.parallel.GradAllReducer.backward: the decoder's, then the encoder's)
+# must decide like ONE pass: the decisions a pass takes at its first weight gradient -- side stream or not, compute units left
+# free -- follow the size of the model's OUTPUT layer, which the second pass never sees (its first weight gradient is
+# fc_middle's, over one row per shape).  `inherit_pass_decisions()` hands the last pass's decisions to the next one.
+_last_decisions = {"overlap": None, "reserve": None}
+_inherited = None
+
+
+class inherit_pass_decisions:
+    def __enter__(self):
+        global _inherited
+        self._was, _inherited = _inherited, dict(_last_decisions)
+        return self
+
+    def __exit__(self, *exc):
+        global _inherited
+        _inherited = self._was
+        return False
+
+
 def _use_side_stream(dy2):
     if not _HAVE_ENGINE_HOOKS:
         return False
@@ -504,11 +524,17 @@ def _use_side_stream(dy2):
         return _OVERLAP_WGRAD
     key = _pass_key(dy2.device)
     use = _overlap_now.get(key)
+    if use is None and _inherited is not None and _inherited["overlap"] is not None:
+        use = _overlap_now[key] = _last_decisions["overlap"] = _inherited["overlap"]
+        if not use:
+            dev = dy2.device
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
     if use is None:          # first weight gradient of this backward pass
         # (under stream capture the host-side price of the second stream is paid once, at capture time, while the replay
         # keeps its concurrency -- and at small batches, where kernels do not fill the chip, that concurrency is worth the
         # most: B = 8 replayed 18.3 -> 15.2 ms in fp32, 14.7 -> 12.5 ms with bf16 storage)
         use = _overlap_now[key] = dy2.shape[0] >= _OVERLAP_MIN_ROWS or torch.cuda.is_current_stream_capturing()
+        _last_decisions["overlap"] = use
         if not use:          # still need the end-of-backward hook to forget the decision
             dev = dy2.device
             torch.autograd.Variable._execution_engine.queue_callback(lambda: _publish(dev, key))
@@ -545,9 +571,12 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
         # workgroups (one 512-register wave per SIMD) leave SIDE_RESERVE_CUS compute units to it
         L = lib()
         reserve = _reserve_now.get(key)
+        if reserve is None and _inherited is not None and _inherited["reserve"] is not None:
+            reserve = _reserve_now[key] = _last_decisions["reserve"] = _inherited["reserve"]
         if reserve is None:          # the pass's first weight gradient: the model's output layer
             reserve = _reserve_now[key] = (SIDE_RESERVE_CUS if SIDE_RESERVE_CUS is not None
                                            else (64 if dy2.shape[0] < _RESERVE_SMALL_ROWS else 48))
+            _last_decisions["reserve"] = reserve
         L.nsdp_debug_set(_ci(9), _ci(reserve))
         global _cur_reduce
         batch = _reduce_batches.get(key)

@@ -209,7 +209,18 @@ class GradAllReducer:
         """Second pass: everything upstream of the cut."""
         pairs, self._root_grads = self._root_grads, None
         if pairs:
-            torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
+            # (the second pass decides like the first -- weight gradients on the side stream, compute units left free -- as ONE
+            # backward pass would: hip_linear.inherit_pass_decisions)
+            try:
+                from . import hip_linear
+                ctx = hip_linear.inherit_pass_decisions() if pairs[0][0].is_cuda else None
+            except Exception:      # (CPU-only use of the reducer, no native library)
+                ctx = None
+            if ctx is None:
+                torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
+            else:
+                with ctx:
+                    torch.autograd.backward([r for r, _ in pairs], [g for _, g in pairs])
 
     def backward(self, loss):
         """``loss.backward()`` with bucket 0's all-reduce issued between the decoder's and the encoder's backward passes and
