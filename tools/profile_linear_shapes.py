@@ -1,127 +1,125 @@
-"""Which dense-layer shapes carry the train step?  Records every (kind, M, N, K, flags) the B=32 forward.yaml
-train step sends to the linear / wgrad kernels, then times each distinct configuration in isolation.
-    python tools/profile_linear_shapes.py [--batch 32]
+"""Which native calls carry the train step?  Every entry point `include/nsdp_hip.h` declares is wrapped at the ctypes boundary
+(the list is PARSED FROM THE HEADER: a new entry point cannot escape), one B = 32 forward.yaml train step runs with a
+synchronisation behind every call, and the library's own per-launch accounting (csrc/prof.h: HIP events on the launch stream,
+flops and ALGORITHMIC bytes as the C side states them in its prof::Scope lines) is read back per call.  Output:
+
+  * per kernel class (the names of bench.py's `kernels` / `roofline`): launches / step, algorithmic GB / step, isolated ms / step
+    -- the `linear_bf16x3_kernel` line must equal the bench line's roofline.launches / 2 and launches x algorithmic_bytes;
+  * per (entry point, integer arguments, operands present): calls / step, launches / call, us / call, TFLOP/s, algorithmic MB / call.
+
+    NSDP_WGRAD_STREAM=0 python tools/profile_linear_shapes.py [--batch 32] [--workload forward|arbitrary] [--all-classes]
 """
-import argparse, collections, os, sys
+import argparse, collections, ctypes, os, re, sys
+os.environ.setdefault("NSDP_WGRAD_STREAM", "0")      # weight gradients on the main stream: every duration is the kernel alone
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-from nsdp_amd import hip_linear, synth
+from nsdp_amd import _lib, hip_linear, synth
 from nsdp_amd.model import build_model, optimizer_factory
-from nsdp_amd.model.utils import compute_l2_error
 
-ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=32); args = ap.parse_args()
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--workload", default="forward", choices=["forward", "arbitrary"])
+ap.add_argument("--all-classes", action="store_true", help="list the calls of every kernel class, not only the dense layers'")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = bench.model_config()
-model, *_ = build_model(cfg, device="cpu")
+if args.workload == "arbitrary":
+    cfg["model"]["type"] = "arbitrary"
+model, train_fn, *_ = build_model(cfg, device="cpu")
 state = synth.procedural_state_dict(model.state_dict(), 2048)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
 model.to(dev).train()
+_, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4}, model.parameters())
 data = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_batch(1000, args.batch, bench.N_SURF, bench.N_QUERY).items()}
 
-calls = collections.Counter()
-orig_fwd, orig_wgrad = hip_linear._run, hip_linear._wgrad
-def rec_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, *a, **kw):
-    calls[("nt-" + kind, x2.shape[0], N, x2.shape[1], b is not None, residual is not None, mask is not None, out_mask is not None, bool(relu_in), bool(relu_out))] += 1
-    return orig_fwd(kind, x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, *a, **kw)
-orig_tail = hip_linear._k4tail_fn
-def rec_tail(link, wpt, n_hidden, kind_t, h0):
-    fn = orig_tail(link, wpt, n_hidden, kind_t, h0)
-    def wrapped(dy2, x4, mask, relu_x, want_db, out=None):
-        M, K = dy2.shape
-        if hip_linear.K4_TAIL and kind_t == "x3" and hip_linear.lib().nsdp_linear_bf16x3_k4tail_ok(hip_linear._ll(M), hip_linear._ci(n_hidden), hip_linear._ci(K)):
-            calls[("tail-x3", M, n_hidden, K)] += 1      # the dX GEMM with the K = 4 weight gradient in its epilogue: no output
-        return fn(dy2, x4, mask, relu_x, want_db, out)
-    return wrapped
-hip_linear._k4tail_fn = rec_tail
-def rec_wgrad(dy2, x2, mask, relu_x, want_db, out=None):
-    calls[("wgrad", dy2.shape[0], dy2.shape[1], x2.shape[1], mask is not None, bool(relu_x), bool(want_db))] += 1
-    return orig_wgrad(dy2, x2, mask, relu_x, want_db, out)
-orig_gather = hip_linear._fwd_x3_gather
-def rec_gather(x2, wp, N, b, gather, relu_in, relu_out):
-    # the position-encoding GEMM whose epilogue adds the gathered q - k rows (nsdp_linear_bf16x3_gather_f32): the same kernel class
-    calls[("gat-x3", x2.shape[0], N, x2.shape[1], b is not None, gather[0] is not None, bool(relu_in), bool(relu_out),
-           int(gather[1]), int(gather[4]), int(gather[5]))] += 1
-    return orig_gather(x2, wp, N, b, gather, relu_in, relu_out)
-hip_linear._run, hip_linear._wgrad, hip_linear._fwd_x3_gather = rec_fwd, rec_wgrad, rec_gather
-for _ in range(2):
-    calls.clear()
-    model.zero_grad(set_to_none=True)
-    loss = compute_l2_error(model(data["space_samples_src"], data["surface_samples_inputs"]), data["space_samples_tgt"])
-    loss.backward()
-torch.cuda.synchronize()
-hip_linear._run, hip_linear._wgrad, hip_linear._k4tail_fn, hip_linear._fwd_x3_gather = orig_fwd, orig_wgrad, orig_tail, orig_gather
+# ---- the header: prototype -> parameter names and which of them are integers / pointers -------------------------------------
+text = re.sub(r"/\*.*?\*/", "", open(_lib.HEADER_PATH).read(), flags=re.S)
+protos = {}
+for m in re.finditer(r"\b(?:int|size_t|long long|void|const char \*)\s*\b(nsdp_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    name, plist = m.group(1), m.group(2)
+    params = []
+    for prm in [p.strip() for p in plist.replace("\n", " ").split(",") if p.strip() and p.strip() != "void"]:
+        pm = re.match(r"(.*?)(\w+)$", prm)
+        ptype, pname = pm.group(1).strip(), pm.group(2)
+        params.append((pname, "ptr" if "*" in ptype else ("int" if re.search(r"\b(int|long long|size_t|unsigned)\b", ptype) else "other")))
+    protos[name] = params
+SKIP = re.compile(r"nsdp_(prof|trace|debug|last_error|abi_version|device_count|graph_exec|.*_supported$|.*_bytes$|.*_ok$|.*_floats$|adam_chunk)")
+L = hip_linear.lib()
+NK = L.nsdp_prof_num_kinds()
+L.nsdp_prof_name.restype = ctypes.c_char_p
+KINDS = [L.nsdp_prof_name(i).decode() for i in range(NK)]
+calls = collections.OrderedDict()      # key -> {"n": calls, kind: [launches, ms, flops, bytes]}
+recording = [False]
 
-def timeit(fn, n=8):
-    for _ in range(2): fn()
+
+def value(a):
+    v = getattr(a, "value", a)
+    return v
+
+
+def wrap(name, fn, params):
+    def wrapper(*a):
+        if not recording[0]:
+            return fn(*a)
+        torch.cuda.synchronize()
+        L.nsdp_prof_enable(1)              # (re-enabling clears the records)
+        rc = fn(*a)
+        torch.cuda.synchronize()
+        ints = tuple((p, int(value(x))) for (p, t), x in zip(params, a) if t == "int" and p not in ("accumulate", "workspace_bytes", "ws_bytes"))
+        ptrs = tuple(p for (p, t), x in zip(params, a) if t == "ptr" and value(x) and p in
+                     ("bias", "residual", "mask", "out_mask", "addend", "gq", "db", "b0", "a_g", "qsub", "desc_out"))
+        ent = calls.setdefault((name, ints, ptrs), {"n": 0})
+        ent["n"] += 1
+        for k in range(NK):
+            n, ms, fl, by = ctypes.c_longlong(0), ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+            L.nsdp_prof_collect(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                acc = ent.setdefault(KINDS[k], [0, 0.0, 0.0, 0.0])
+                acc[0] += n.value; acc[1] += ms.value; acc[2] += fl.value; acc[3] += by.value
+        return rc
+    wrapper.restype = getattr(fn, "restype", None)
+    return wrapper
+
+
+wrapped = 0
+for name, params in protos.items():
+    if SKIP.match(name) or not hasattr(L, name):
+        continue
+    setattr(L, name, wrap(name, getattr(L, name), params))
+    wrapped += 1
+
+STEPS = 2
+for i in range(1 + STEPS):
+    recording[0] = i >= 1
+    train_fn.tensor_step(model, opt, data, cfg)
     torch.cuda.synchronize()
-    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(n): fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / n
+recording[0] = False
+L.nsdp_prof_enable(0)
 
+print(f"# {wrapped} of {len(protos)} entry points of include/nsdp_hip.h wrapped; {len(calls)} distinct (entry point, shape, operands) "
+      f"in {STEPS} {args.workload} train steps at B = {args.batch}; per-step figures below")
+tot = collections.OrderedDict()
+for key, ent in calls.items():
+    for kind, v in ent.items():
+        if kind == "n":
+            continue
+        t = tot.setdefault(kind, [0, 0.0, 0.0, 0.0])
+        for j in range(4):
+            t[j] += v[j]
+print(f"{'class':28s} {'launches/step':>13s} {'algorithmic GB/step':>20s} {'isolated ms/step':>17s} {'GB/s':>7s} {'of 8 TB/s':>9s} {'TFLOP/s':>8s}")
+for kind, (n, ms, fl, by) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
+    print(f"{kind:28s} {n / STEPS:13.1f} {by / STEPS / 1e9:20.3f} {ms / STEPS:17.3f} {by / ms / 1e6 if ms else 0:7.0f} {by / ms / 8e9 if ms else 0:9.3f} "
+          f"{fl / ms / 1e9 if ms else 0:8.1f}")
+dense = ("linear_bf16x3_kernel", "wgrad_bf16x3_kernel", "linear_nt_kernel", "linear_wgrad_kernel", "linear_bf16_kernel", "wgrad_bf16_kernel")
+print(f"\n{'entry point':34s} {'shape / flags (nonzero)':66s} {'operands':26s} {'calls':>5s} {'launches':>8s} {'us/call':>9s} {'ms/step':>8s} {'TF':>6s} {'alg MB':>9s}")
 rows = []
-for key, cnt in calls.items():
-    if key[0] == "tail-x3":
-        _, M, N, K = key
-        x = torch.relu(torch.randn(M, K, device=dev))
-        lin0 = torch.nn.Linear(3, N).to(dev)
-        wpt = hip_linear.pack_weight_x3(torch.randn(K, N, device=dev), True, True)[1]
-        x4 = torch.nn.functional.pad(torch.randn(M, 3, device=dev), (0, 1)).contiguous()
-        link = hip_linear.K4Tail(); link.w_param, link.b_param, link.k_orig = lin0.weight, lin0.bias, 3
-        tfn = orig_tail(link, wpt, N, "x3", None)
-        t = timeit(lambda: tfn(x, x4, None, False, True))
-        flags = "k4"
-    elif key[0] == "gat-x3":
-        _, M, N, K, hb, two, ri, ro, kk, rps, nsrc = key
-        x = torch.randn(M, K, device=dev)
-        wp = hip_linear.pack_weight_x3(torch.randn(N, K, device=dev))[0]
-        b = torch.randn(N, device=dev) if hb else None
-        # the step's own geometry: rows = (shape, centre, neighbour); a per-centre q table + a per-shape k table (two tables), or
-        # one per-shape table of differences (the decoder: one query vector per shape)
-        gidx = torch.randint(0, nsrc, (M,), device=dev, dtype=torch.int32)
-        gk = torch.randn((M // rps) * nsrc, N, device=dev)
-        gq = torch.randn(-(-M // kk), N, device=dev) if two else None
-        t = timeit(lambda: orig_gather(x, wp, N, b, (gq, kk, gk, gidx, rps, nsrc), ri, ro))
-        flags = "".join(c for c, f in zip("b2IO", (hb, two, ri, ro)) if f)
-    elif key[0].startswith("nt"):
-        kname, M, N, K, hb, hr, hm, ho, ri, ro = key
-        kind = kname[3:]
-        x = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev)
-        wp = (hip_linear.pack_weight_x3 if kind == "x3" else hip_linear.pack_weight)(w)[0]
-        b = torch.randn(N, device=dev) if hb else None
-        r = torch.randn(M, N, device=dev) if hr else None
-        m = torch.randn(M, K, device=dev) if hm else None
-        o = torch.randn(M, N, device=dev) if ho else None
-        t = timeit(lambda: orig_fwd(kind, x, wp, N, b, r, m, o, ri, ro))
-        flags = "".join(c for c, f in zip("brmoIO", (hb, hr, hm, ho, ri, ro)) if f)
-    else:
-        _, M, N, K, hm, rx, wdb = key
-        dy = torch.randn(M, N, device=dev); x = torch.randn(M, K, device=dev)
-        m = torch.randn(M, N, device=dev) if hm else None
-        t = timeit(lambda: orig_wgrad(dy, x, m, rx, wdb))
-        flags = "".join(c for c, f in zip("mxb", (hm, rx, wdb)) if f)
-    fl = 2.0 * M * N * K
-    # algorithmic bytes per launch exactly as the C side accounts them (4(M(K+N)+NK); the tail form stores nothing:
-    # 4(M(K+4)+NK); weight gradient 4M(N+K)) -- csrc/gemm_bf16x3.hip, csrc/wgrad_bf16x3.hip prof::Scope lines
-    ab = 4.0 * (M * (K + 4) + N * K) if key[0] == "tail-x3" else 4.0 * M * (N + K) if key[0] == "wgrad" else 4.0 * (M * (K + N) + N * K)
-    rows.append((t * cnt, key[0], M, N, K, flags, cnt, t, fl / t / 1e9, ab))
-    del x
-rows.sort(reverse=True)
-tot = sum(r[0] for r in rows)
-print(f"total isolated GEMM time per step: {tot:.2f} ms  (nt {sum(r[0] for r in rows if r[1].startswith('nt')):.2f}, gather epilogue {sum(r[0] for r in rows if r[1]=='gat-x3'):.2f}, k4 tail {sum(r[0] for r in rows if r[1]=='tail-x3'):.2f}, wgrad {sum(r[0] for r in rows if r[1]=='wgrad'):.2f})")
-# per kernel class: launches, algorithmic bytes, isolated time per step -- `linear_bf16x3_kernel` here must equal the bench line's
-# roofline.launches / 2 (the isolated pass times two steps) and roofline.algorithmic_bytes x launches
-classes = {"linear_bf16x3_kernel": ("nt-x3", "gat-x3", "tail-x3"), "linear_nt_kernel (exact fp32)": ("nt-wp",), "weight gradients (all kernels)": ("wgrad",)}
-print("class                              launches/step  algorithmic GB/step  isolated ms/step  GB/s    frac of 8 TB/s")
-for cname, kinds in classes.items():
-    sel = [r for r in rows if r[1] in kinds]
-    n = sum(r[6] for r in sel); gb = sum(r[9] * r[6] for r in sel) / 1e9; ms = sum(r[0] for r in sel)
-    if n:
-        print(f"{cname:34s} {n:13d}  {gb:19.2f}  {ms:16.2f}  {gb / ms * 1e3:6.0f}  {gb / ms / 8.0:6.3f}")
-print("kind   M        N    K    flags  count  ms/call  TF     ms/step  cum%   alg MB/launch")
-cum = 0.0
-for tt, kind, M, N, K, flags, cnt, t, tf, ab in rows:
-    cum += tt
-    print(f"{kind:6s} {M:8d} {N:4d} {K:4d} {flags:6s} {cnt:5d}  {t:7.3f}  {tf:6.1f} {tt:7.2f}  {100*cum/tot:5.1f}  {ab / 1e6:9.2f}")
+for (name, ints, ptrs), ent in calls.items():
+    kinds = [k for k in ent if k != "n"]
+    if not kinds or (not args.all_classes and not any(k in dense for k in kinds)):
+        continue
+    n_l = sum(ent[k][0] for k in kinds); ms = sum(ent[k][1] for k in kinds); fl = sum(ent[k][2] for k in kinds); by = sum(ent[k][3] for k in kinds)
+    shape = " ".join(f"{p}={v}" for p, v in ints if v != 0 or p in ("M", "N", "K"))      # (zero flags are not printed)
+    rows.append((ms / STEPS, name.replace("nsdp_", ""), shape, ",".join(ptrs), ent["n"] / STEPS, n_l / ent["n"], 1e3 * ms / ent["n"], fl / ms / 1e9 if ms else 0, by / ent["n"] / 1e6))
+for ms_step, name, shape, ptrs, n, nl, us, tf, mb in sorted(rows, reverse=True):
+    print(f"{name[:34]:34s} {shape[:66]:66s} {ptrs[:26]:26s} {n:5.1f} {nl:8.1f} {us:9.1f} {ms_step:8.3f} {tf:6.1f} {mb:9.2f}")
