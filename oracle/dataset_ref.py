@@ -32,6 +32,27 @@ def cano_sample_handle_mask(partial_range, cano, bbox_min, bbox_max):
     return head | tail | foot
 
 
+def create_partial_src(partial_shape_ratio, surface_samples_src, handle_sample_idx, num_seeds=5, seed_choice=None):
+    """dataset/utils.py:79-101: carve `num_seeds` holes into the non-handle region -- seeds = a random permutation prefix of the
+    non-handle samples (``seed_choice``: those positions, when given), each hole = the seed's int(hole_ratio * n // num_seeds)
+    nearest surface samples (handles included; the reference asks scipy's KDTree) -- and return the indices that remain,
+    ascending (the reference builds them through a Python set of small ints, which iterates in ascending order)."""
+    n = len(surface_samples_src)
+    if partial_shape_ratio >= 1.0:
+        return np.arange(n)
+    hole_ratio = 1.0 - partial_shape_ratio
+    per_hole = int(hole_ratio * n // num_seeds)
+    nonhandle = surface_samples_src[~handle_sample_idx]
+    if seed_choice is None:
+        seed_choice = np.random.permutation(nonhandle.shape[0])[:num_seeds]
+    seeds = nonhandle[seed_choice].astype(np.float64)
+    d2 = ((seeds[:, None, :] - surface_samples_src[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    remove = np.argsort(d2, axis=1, kind="stable")[:, :per_hole].reshape(-1)
+    keep = np.ones(n, dtype=bool)
+    keep[remove] = False
+    return np.nonzero(keep)[0]
+
+
 def sample_contract(cfg_data, data_cano, data_src, data_tgt, surf_idxs=None, noise=None):
     """dataset_deform4d_flow.py:190-246 for one sample (without the partial-shape branch, which no shipped config
     enables): returns the data_dict entries that feed the model."""

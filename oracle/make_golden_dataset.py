@@ -30,7 +30,19 @@ np.random.seed(321)
 s_noise = ref.add_noise_to_src(cfg, s)
 np.random.seed(55)
 sc, ss, st = ref.subsample_space_flow(cfg, sp[0], sp[1], sp[2])
+# the partial-shape branch (dataset/utils.py:79-101): the reference's function on the sub-sampled source samples, two ratios; the
+# seeds it drew are recorded by replaying the same first RNG call
+partial = {}
+for tag, ratio, rs in (("a", 0.8, 7), ("b", 0.55, 8)):
+    pcfg = {"data": {"partial_shape_ratio": ratio}}
+    np.random.seed(rs)
+    remain = ref.create_partial_src(pcfg, s, mask)
+    np.random.seed(rs)
+    choice = np.random.permutation(int((~mask).sum()))[:5]
+    partial[f"partial_{tag}_ratio"] = np.float64(ratio)
+    partial[f"partial_{tag}_seed_choice"] = choice
+    partial[f"partial_{tag}_remain"] = np.asarray(remain, dtype=np.int64)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "dataset_contract.npz"),
                     cano=cano, src=src, tgt=tgt, sp0=sp[0], sp1=sp[1], sp2=sp[2], idxs=idxs, sub_cano=c, sub_src=s,
-                    sub_tgt=t, mask=mask, src_noise=s_noise, sc=sc, ss=ss, st=st)
+                    sub_tgt=t, mask=mask, src_noise=s_noise, sc=sc, ss=ss, st=st, **partial)
 print("wrote tests/golden/dataset_contract.npz; handle fraction", mask.mean())

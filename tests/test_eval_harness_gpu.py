@@ -153,6 +153,54 @@ def test_prepare_batch_matches_oracle(inverse, noise_level):
     assert all(len(set(surf_idx[b].tolist())) == 512 for b in range(B))
 
 
+def test_create_partial_src_matches_the_reference_vectors_and_prepare_batch_carves_the_same_holes():
+    """dataset/utils.py:79-101 (the partial-shape branch of the data contract) on the device against the outputs of the IMPORTED
+    reference function (tests/golden/dataset_contract.npz, oracle/make_golden_dataset.py: two ratios, the seeds the reference
+    drew supplied as positions within the non-handle samples), then through prepare_batch at batch 1: every per-sample array
+    keeps exactly the reference's remaining rows.  Without given seeds: seeds are non-handle samples, holes have the size
+    the reference computes, and a batch is deterministic under a seeded generator."""
+    import os
+    from nsdp_amd import dataset
+    from oracle import dataset_ref
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset_contract.npz"))
+    src = torch.from_numpy(fx["sub_src"]).to(DEV)[None]
+    mask = torch.from_numpy(fx["mask"]).to(DEV)[None]
+    for tag in "ab":
+        ratio, choice, want = float(fx[f"partial_{tag}_ratio"]), fx[f"partial_{tag}_seed_choice"], fx[f"partial_{tag}_remain"]
+        keep = dataset.create_partial_src(ratio, src, mask, seed_choice=choice[None])
+        assert np.array_equal(keep[0].nonzero()[:, 0].cpu().numpy(), want)
+        assert np.array_equal(dataset_ref.create_partial_src(ratio, fx["sub_src"], fx["mask"], seed_choice=choice), want)
+    # two samples at once, different seeds per sample
+    both = dataset.create_partial_src(0.8, src.expand(2, -1, -1).contiguous(), mask.expand(2, -1).contiguous(),
+                                      seed_choice=np.stack([fx["partial_a_seed_choice"], fx["partial_a_seed_choice"][::-1]]))
+    assert torch.equal(both[0], both[1])                       # (the same seeds in another order: the same holes)
+    # through prepare_batch (batch 1): rows of every array = the reference's remain_idx
+    cfg = {"arbitrary": False, "inverse": False, "num_surf_samples": 300, "num_space_samples": 10 ** 9, "partial_range": 0.1,
+           "noise_level": 0.0, "partial_shape_ratio": 0.8}
+    d = lambda a: {"surface_samples": torch.from_numpy(fx[a]).to(DEV)[None], "surface_normals": torch.from_numpy(fx[a]).to(DEV)[None],
+                   "space_samples": torch.from_numpy(fx["sp0"]).to(DEV)[None]}
+    idx = torch.from_numpy(fx["idxs"].astype(np.int32)).to(DEV)[None]
+    out = dataset.prepare_batch(cfg, d("cano"), d("src"), d("tgt"), surf_idx=idx, partial_seed_choice=fx["partial_a_seed_choice"][None])
+    want = fx["partial_a_remain"]
+    assert np.array_equal(out["partial_remain_idx"][0].cpu().numpy(), want)
+    np.testing.assert_array_equal(out["surface_samples_src"][0].cpu().numpy(), fx["sub_src"][want])
+    np.testing.assert_array_equal(out["surface_samples_cano"][0].cpu().numpy(), fx["sub_cano"][want])
+    np.testing.assert_array_equal(out["cano_handle_sample_idx"][0, :, 0].cpu().numpy(), fx["mask"][want])
+    inputs = np.concatenate([fx["sub_src"], fx["sub_tgt"] * fx["mask"][:, None], fx["mask"][:, None]], axis=1).astype(np.float32)
+    np.testing.assert_array_equal(out["surface_samples_inputs"][0].cpu().numpy(), inputs[want])
+    # random seeds: non-handle seeds, hole size, reproducible
+    g = torch.Generator(device=DEV).manual_seed(3)
+    big = torch.rand(4, 2048, 3, device=DEV, generator=g) - 0.5
+    hmask = big[..., 1] > 0.3
+    k1 = dataset.create_partial_src(0.8, big, hmask, generator=torch.Generator(device=DEV).manual_seed(9))
+    k2 = dataset.create_partial_src(0.8, big, hmask, generator=torch.Generator(device=DEV).manual_seed(9))
+    assert torch.equal(k1, k2)
+    per_hole = int(0.2 * 2048 // 5)
+    removed = (~k1).sum(dim=1)
+    assert bool(((removed >= per_hole) & (removed <= 5 * per_hole)).all()), removed
+    assert torch.equal(dataset.create_partial_src(1.0, big, hmask), torch.ones_like(hmask))
+
+
 @pytest.mark.gpu
 def test_harness_with_the_next_batch_s_geometry_pipelined_under_the_step(tmp_path):
     """GraphedTrainOnBatch(pipeline_geometry=): every replay takes its index sets (FPS, kNN, inverse lists) from

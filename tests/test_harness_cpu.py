@@ -115,6 +115,15 @@ def test_dataset_contract_oracle_matches_reference_vectors():
     assert np.array_equal(out["surface_samples_src"], fx["src_noise"])          # same RNG stream as the reference's call
     assert out["surface_samples_inputs"].shape == (300, 7) and out["surface_samples_inputs"].dtype == np.float32
     assert np.array_equal(out["surface_samples_inputs"][:, 6] > 0, fx["mask"])
+    # the partial-shape branch (dataset/utils.py:79-101): the restatement against the imported reference function's outputs,
+    # with the seeds the reference drew and with the same RNG call
+    for tag, rs in (("a", 7), ("b", 8)):
+        ratio, want = float(fx[f"partial_{tag}_ratio"]), fx[f"partial_{tag}_remain"]
+        got = dataset_ref.create_partial_src(ratio, fx["sub_src"], fx["mask"], seed_choice=fx[f"partial_{tag}_seed_choice"])
+        assert np.array_equal(got, want)
+        np.random.seed(rs)
+        assert np.array_equal(dataset_ref.create_partial_src(ratio, fx["sub_src"], fx["mask"]), want)
+    assert np.array_equal(dataset_ref.create_partial_src(1.0, fx["sub_src"], fx["mask"]), np.arange(300))
 
 
 def test_initial_weight_files_come_from_the_config_like_the_reference():
