@@ -136,6 +136,7 @@ def bf16_parity(workload, device):
         return float(np.sqrt(np.sort(err, axis=1)[:, :-2].mean(-1)).max())
     return {"bf16": round(l2(out["bf16"]), 6), "f32": round(l2(out["f32"]), 8), "fixture": f"tests/golden/{name}.npz",
             "canonicalize_f32": precision.canonicalize_f32() if mtype == "arbitrary" else None,
+            "canonicalize_mode": precision.canonicalize_mode() if mtype == "arbitrary" else None,
             "chaos_floor_fp32_inputs_x_1p2m8": round(l2_pair(floor_scaled, out["f32"]), 6),
             "chaos_floor_fp32_inputs_rounded_to_bf16": round(l2_pair(floor_rounded, out["f32"]), 6),
             "metric": "max over shapes of sqrt(mean_q |pred - reference|^2) without the 2 worst queries, eval forward, B=%d" % b}
@@ -261,6 +262,9 @@ def main():
                          "captured ones -- every graph boundary joins the executor's streams, and the head / tail boundary costs the "
                          "overlap of the decoder's weight gradients with the encoder's backward chain: measured at ONE rank, B = 32: "
                          "plain 38.2-38.3 ms, two graphs 38.75-38.9, three graphs 39.5-39.7, against an exchange of 0.05-0.2 ms")
+    ap.add_argument("--canonicalize-decoder-f32", action="store_true",
+                    help="with --dtype bf16 --workload arbitrary_train: the middle point -- FlowArbitrary's first network with a bf16 "
+                         "ENCODER and an fp32-storage DECODER (its per-point outputs are the coordinates the second network searches)")
     ap.add_argument("--canonicalize-f32", action="store_true",
                     help="with --dtype bf16 --workload arbitrary_train: FlowArbitrary's first network in fp32 storage (its output "
                          "points are the second network's geometry: eval L2 against the reference 1.0e-2 instead of 1.3e-1)")
@@ -341,6 +345,8 @@ def main():
     precision.set_storage(args.dtype)
     if args.canonicalize_f32:
         precision.set_canonicalize_f32(True)
+    if args.canonicalize_decoder_f32:
+        precision.set_canonicalize_mode("dec32")
     from nsdp_amd.parallel import DataParallel
     from nsdp_amd.model.utils import compute_l2_error
 
@@ -651,7 +657,8 @@ def main():
                                    f"{args.batch} shapes/GPU, {N_SURF} surface + {n_query} query points per shape, "
                                    + ("fp32 (dense layers as bf16x3 split products)" if args.dtype == "f32" else
                                       "bf16 storage / fp32 accumulate / fp32 master weights"
-                                      + (" (network 1 in fp32 storage)" if args.canonicalize_f32 else ""))
+                                      + (" (network 1 in fp32 storage)" if args.canonicalize_f32 else "")
+                                      + (" (network 1: bf16 encoder, fp32-storage decoder)" if args.canonicalize_decoder_f32 else ""))
                                    + ", procedural random-init weights",
                        "global_batch": world * args.batch, "n_surf": N_SURF, "n_query": n_query,
                        "parallelism": f"dp{world}"},

@@ -42,9 +42,16 @@ class FlowArbitrary(nn.Module):
             queries = queries if queries.is_contiguous() else queries.contiguous()
             with hip_batchnorm.running_updates(len(query_sets)):      # (inert on eval-mode norms)
                 encoding = net.encode(surface_samples_src, queries=queries)
+            if precision.is_bf16() and precision.canonicalize_decoder_f32():
+                # the middle point of the mixed storage (precision.py): bf16 encoder, fp32 decoder -- the encoding (one latent
+                # code and 100 anchor features per shape) is cast once, the per-point chain runs in fp32 storage
+                with precision.storage(torch.float32):
+                    enc32 = {k: (v.float() if torch.is_tensor(v) and v.dtype is torch.bfloat16 else v) for k, v in encoding.items()}
+                    out = net.decode(queries, enc32)
+            else:
+                out = net.decode(queries, encoding)
             if len(query_sets) == 1:
-                return [net.decode(queries, encoding)]
-            out = net.decode(queries, encoding)
+                return [out]
             return list(torch.split(out, [q.shape[1] for q in query_sets], dim=1))
 
     def deform_input(self, surf_src2cano, surface_samples_tgt, cano_handle_sample_mask):

@@ -56,16 +56,34 @@ class storage:
 # profiles/r4_bf16_bisect.txt: 1.3e-1 against the reference, the same as the fp32 model's own response to bf16-rounded input
 # coordinates; 1.0e-2 with network 1 in fp32 storage).  "f32" keeps network 1 (model_canonicalize) in fp32 storage (its
 # dense layers on the bf16x3 kernels) and only network 2 in bf16: NSDP_BF16_NET1=f32 / set_canonicalize_f32(True).
-_net1_f32 = os.environ.get("NSDP_BF16_NET1", "bf16") == "f32"
+# "dec32" is the middle point: network 1's ENCODER in bf16 storage (its output is one latent code + 100 anchor features per shape: a
+# smooth function of the cloud), its DECODER -- whose per-point outputs are the coordinates network 2 searches -- in fp32 storage.
+_net1_mode = os.environ.get("NSDP_BF16_NET1", "bf16")
+if _net1_mode not in ("bf16", "f32", "dec32"):
+    raise ValueError("NSDP_BF16_NET1 must be bf16, f32 or dec32")
 
 
 def canonicalize_f32() -> bool:
-    return _net1_f32
+    return _net1_mode == "f32"
+
+
+def canonicalize_decoder_f32() -> bool:
+    return _net1_mode == "dec32"
+
+
+def canonicalize_mode() -> str:
+    return _net1_mode
 
 
 def set_canonicalize_f32(flag: bool):
-    global _net1_f32
-    _net1_f32 = bool(flag)
+    set_canonicalize_mode("f32" if flag else "bf16")
+
+
+def set_canonicalize_mode(mode: str):
+    global _net1_mode
+    if mode not in ("bf16", "f32", "dec32"):
+        raise ValueError("canonicalize mode must be bf16, f32 or dec32")
+    _net1_mode = mode
 
 
 def to_storage(t: torch.Tensor) -> torch.Tensor:
