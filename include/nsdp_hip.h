@@ -378,11 +378,18 @@ int nsdp_layout_g16_f32(const float *src, float *dst, long long M, int C, int to
 int nsdp_linear_bf16x3_g16_supported(long long M, int N, int K, int layout, int has_mask, int relu_in);
 int nsdp_linear_bf16x3_g16_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,
                                const float *out_mask, const float *addend, float *Y, long long M, int N, int K, int relu_in,
-                               int relu_out, int layout, void *stream);
+                               int relu_out, int layout, const unsigned char *mask_bits, unsigned char *bits_out, void *stream);
+/* ReLU bits: the mask [h > 0] of a hidden tensor h [M, C] that lives in the G16 layout, one BIT per element:
+ * [M / 16][ceil(C / 32)][64] bytes, byte (row group, k block kb, 4 * (row % 16) + g) = bits 0-3: channels 32 kb + 4 g .. + 3,
+ * bits 4-7: channels 32 kb + 16 + 4 g .. + 3 (the eight values lane (row, g) of the GEMM's fragment convention holds in block kb).
+ * nsdp_linear_bf16x3_g16_f32 writes them next to a G16 output with an output ReLU (bits_out != NULL) and takes them in place of
+ * `mask` for a G16 input (mask_bits != NULL: the dX GEMM of that layer); nsdp_linear_wgrad_bf16x3_g16_f32 takes them as the mask of
+ * a G16 dY (mask_bits != NULL, layout 1).  28 bytes per row of a 200-wide layer where the fp32 mask stream was 800. */
+size_t nsdp_relu_bits_bytes(long long M, int C);
 int nsdp_linear_wgrad_bf16x3_g16_supported(long long M, int N, int K, int layout, int has_mask);
 int nsdp_linear_wgrad_bf16x3_g16_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
                                      long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
-                                     NsdpWgradReduceDesc *desc_out, int layout, void *stream);
+                                     NsdpWgradReduceDesc *desc_out, int layout, const unsigned char *mask_bits, void *stream);
 
 /* nsdp_linear_wgrad_bf16 in two halves, like nsdp_linear_wgrad_bf16x3_partials_f32 / nsdp_wgrad_bf16x3_reduce_batched: the row
  * kernel now (an all-zero *desc_out -- ws == NULL -- means the call had nothing to do), the fixed-order sums of many layers'

@@ -18,9 +18,9 @@ namespace {
 template <int NT, int PRE, int LAY>
 void launch_g16(const X3Params &p, hipStream_t st) {
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
-  if constexpr (PRE == 1) {
-    if constexpr (NT <= 8) launch_x3_pre<2, NT, 1, 4, true, 2, 0, LAY>(p, st, 2);
-    else launch_x3_pre<MT1, NT, 1, 4, false, 2, 0, LAY>(p, st);
+  if constexpr (PRE == 1 || PRE == 4) {
+    if constexpr (NT <= 8) launch_x3_pre<2, NT, PRE, 4, true, 2, 0, LAY>(p, st, 2);
+    else launch_x3_pre<MT1, NT, PRE, 4, false, 2, 0, LAY>(p, st);
   } else if constexpr (NT <= 8) {
     if (p.K <= 128) launch_x3_pre<2, NT, PRE, 8, false, 4, 0, LAY>(p, st);      // weight planes resident in LDS
     else launch_x3_pre<2, NT, PRE, 4, false, 2, 0, LAY>(p, st, 2);
@@ -37,13 +37,15 @@ void launch_g16(const X3Params &p, hipStream_t st) {
 
 template <int NT>
 int launch_g16_nt(const X3Params &p, int layout, hipStream_t st) {
-  const int pre = p.mask ? 1 : (p.relu_in ? 2 : 0);
+  const int pre = p.bits ? 4 : p.mask ? 1 : (p.relu_in ? 2 : 0);
   nsdp::prof::Scope scope(nsdp::prof::kLinearX3, st, 2.0 * p.M * p.N * p.K,
                           4.0 * (static_cast<double>(p.M) * (p.K + p.N) + static_cast<double>(p.N) * p.K));
   // instantiated: X in G16 with the plain / masked prologue (second layer forward, first layer dX);
-  //               Y in G16 with the plain / ReLU prologue (first layer forward, second layer dX)
+  //               Y in G16 with the plain / ReLU prologue (first layer forward, second layer dX);
+  //               X in G16 masked by ReLU BITS (first layer dX: one byte per row tile and k block instead of a float4 stream)
   if (layout == kLayX && pre == 0) launch_g16<NT, 0, kLayX>(p, st);
   else if (layout == kLayX && pre == 1) launch_g16<NT, 1, kLayX>(p, st);
+  else if (layout == kLayX && pre == 4) launch_g16<NT, 4, kLayX>(p, st);
   else if (layout == kLayY && pre == 0) launch_g16<NT, 0, kLayY>(p, st);
   else if (layout == kLayY && pre == 2) launch_g16<NT, 2, kLayY>(p, st);
   else {
@@ -89,23 +91,32 @@ int nsdp_linear_bf16x3_g16_supported(long long M, int N, int K, int layout, int 
   return 0;
 }
 
+size_t nsdp_relu_bits_bytes(long long M, int C) {
+  if (M <= 0 || C <= 0) return 0;
+  return static_cast<size_t>((M + 15) / 16) * static_cast<size_t>((C + 31) / 32) * 64;
+}
+
 int nsdp_linear_bf16x3_g16_f32(const float *X, const void *Wp, const float *bias, const float *residual, const float *mask,
                                const float *out_mask, const float *addend, float *Y, long long M, int N, int K, int relu_in,
-                               int relu_out, int layout, void *stream) {
+                               int relu_out, int layout, const unsigned char *mask_bits, unsigned char *bits_out, void *stream) {
   if (M <= 0 || N <= 0) return 0;
   NSDP_REQUIRE(X && Wp && Y, "linear_bf16x3_g16: null pointer");
-  NSDP_REQUIRE(nsdp_linear_bf16x3_g16_supported(M, N, K, layout, mask != nullptr, relu_in),
-               "linear_bf16x3_g16: unsupported call M=%lld N=%d K=%d layout=%d mask=%d relu_in=%d", M, N, K, layout, mask != nullptr,
-               relu_in);
+  NSDP_REQUIRE(nsdp_linear_bf16x3_g16_supported(M, N, K, layout, mask != nullptr || mask_bits != nullptr, relu_in),
+               "linear_bf16x3_g16: unsupported call M=%lld N=%d K=%d layout=%d mask=%d relu_in=%d", M, N, K, layout,
+               mask != nullptr || mask_bits != nullptr, relu_in);
   NSDP_REQUIRE(!(layout & kLayY) || (!out_mask && !addend && !residual),
                "linear_bf16x3_g16: a G16 output takes no out_mask / addend / row-major residual");
-  NSDP_REQUIRE(!addend || (mask && out_mask && !relu_in), "linear_bf16x3_g16: an addend needs mask and out_mask, no input ReLU");
+  NSDP_REQUIRE(!addend || ((mask || mask_bits) && out_mask && !relu_in), "linear_bf16x3_g16: an addend needs mask and out_mask, no input ReLU");
+  NSDP_REQUIRE(!mask_bits || (layout == kLayX && !mask && !relu_in), "linear_bf16x3_g16: ReLU bits mask a G16 input (layout 1), instead of `mask`");
+  NSDP_REQUIRE(!bits_out || (layout == kLayY && relu_out), "linear_bf16x3_g16: ReLU bits are written for a G16 output with an output ReLU");
   NSDP_REQUIRE(((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Wp) | reinterpret_cast<uintptr_t>(Y) |
                  reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(mask) |
                  reinterpret_cast<uintptr_t>(out_mask) | reinterpret_cast<uintptr_t>(addend)) & 15) == 0,
                "linear_bf16x3_g16: all operands must be 16-byte aligned");
   X3Params p{X, Wp, bias, residual, mask, out_mask, Y, M, N, K, relu_in, relu_out, nsdp::g_x3_dbg & ~(128 | 1024 | 2048)};
   p.addend = addend;
+  p.bits = mask_bits;
+  p.bits_out = bits_out;
   hipStream_t st = nsdp::as_stream(stream);
   const int nt = (N + 15) / 16;
   if (nt <= 8) return launch_g16_nt<8>(p, layout, st);

@@ -59,6 +59,8 @@ struct WgX3Params {
   // H0 forms: X [M, 4] holds the 16-byte coordinate rows of a position-encoding MLP and the operand is its hidden layer
   // relu(X W0^T + b0) [M, K], recomputed by the producer (k4.h) instead of read; h_w0 [K, 4] row-major zero-padded, h_b0 [K] or NULL
   const float *h_w0 = nullptr, *h_b0 = nullptr;
+  // BITS forms: the mask of a G16 dY as ReLU bits ([M / 16][ceil(N / 32)][64] bytes, x3_kernel.h) instead of an fp32 tensor
+  const unsigned char *bits = nullptr;
 };
 
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
@@ -163,8 +165,9 @@ __device__ __forceinline__ void g16_slot(int s, int c4s, int &row, int &c4) {
 // ([M / 16][C / 4][16 rows][4 floats]).  Only the producer's slot -> (row, float4 column) map and its addresses change: a slot of a
 // G16 operand walks the rows of one channel quad first (one contiguous KiB per wave instruction), the plane images, the MFMA order
 // and the bias sums are the row-major kernel's -- dW and db come out bit-identical.
-template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false, bool H0 = false, int LAY = 0>
+template <int NTA, int KTB, bool MASK, bool TAIL, bool ONEHOT = false, bool H0 = false, int LAY = 0, bool BITS = false>
 __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
+  static_assert(!BITS || (MASK && (LAY & 1) && !TAIL), "ReLU bits: the mask of a G16 dY, whole 32-row blocks");
   static_assert(!ONEHOT || (!MASK && NTA == 8), "one-hot operand: 128 table rows, no mask");
   static_assert(!H0 || (!MASK && !ONEHOT), "H0 operand: plain dY");
   static_assert(!LAY || (!ONEHOT && !H0), "G16 operands: the plain / masked forms");
@@ -198,6 +201,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
 
   // ---- producer slots: s = tid + 256 r -> row s / c4s, float4 column s % c4s (surplus slots alias slot s - 256) ----
   unsigned offA[RA], offB[RB];       // byte offset of the slot's float4 in dY / X for the block loaded next
+  unsigned offM[BITS ? RA : 1];      // (BITS) byte offset of the slot's mask byte; its nibble is mshift[r] bits up
+  int mshift[BITS ? RA : 1];
   unsigned ldsA[RA], ldsB[RB];       // byte offset inside a plane image
   int rowA[RA], rowB[RB];            // image row (TAIL)
   int colB[H0 ? RB : 1];             // (H0) first of the slot's four columns, relative to k_off
@@ -225,6 +230,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
       offA[r] = kAG ? static_cast<unsigned>(((mb0 * 32 + (row & 16)) * N + col * 16 + (row & 15) * 4) * 4)
                     : static_cast<unsigned>(((mb0 * 32 + row) * N + col) * 4);
       ldsA[r] = static_cast<unsigned>(row * kPitchA + c4 * 8);
+      if constexpr (BITS) {      // quad c4 = k block c4 / 8, half (c4 % 8) / 4, lane group c4 % 4 of the GEMM's fragment convention
+        const int kbn = (N + 31) >> 5, cc = col >> 2;
+        offM[r] = static_cast<unsigned>((mb0 * 2 + (row >> 4)) * kbn * 64 + (cc >> 3) * 64 + (row & 15) * 4 + (cc & 3));
+        mshift[r] = ((cc >> 2) & 1) * 4;
+      }
     }
   }
 #pragma unroll
@@ -247,7 +257,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   }
   const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>((lds_ptr_t)(&planes[0])));
 
-  f32x4 rawA[RA], rawM[MASK ? RA : 1], rawB[RB];
+  f32x4 rawA[RA], rawM[(MASK && !BITS) ? RA : 1], rawB[RB];
+  unsigned rawMb[BITS ? RA : 1];
+  const unsigned char *const Bp = p.bits;
   int rawI = -1;                     // (one-hot) table row of image row tid / 8 of the block loaded next
   f32x4 dbsum[RA];
 #pragma unroll
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
       gload_i32(rawI, dYp, off);
     } else {
       gload4(rawA[r], dYp, off);
-      if (MASK) gload4(rawM[r], Mp, off);
+      if constexpr (BITS) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(rawMb[r]) : "v"(offM[r]), "s"(Bp));
+      else if (MASK) gload4(rawM[r], Mp, off);
     }
   };
   auto issue_b = [&](int r, long long mb) {
@@ -290,7 +303,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
   };
   auto advance = [&]() {
 #pragma unroll
-    for (int r = 0; r < RA; ++r) offA[r] += 32u * strideA;
+    for (int r = 0; r < RA; ++r) {
+      offA[r] += 32u * strideA;
+      if constexpr (BITS) offM[r] += 2u * static_cast<unsigned>((N + 31) >> 5) * 64u;
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) offB[r] += 32u * strideB;
   };
@@ -299,7 +315,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
 #pragma unroll
     for (int r = 0; r < (ONEHOT ? 0 : RA); ++r) {
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawA[r]));
-      if (MASK) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawM[r]));
+      if constexpr (BITS) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawMb[r]));
+      else if (MASK) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawM[r]));
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawB[r]));
@@ -329,7 +346,11 @@ __global__ __launch_bounds__(256) void wgrad_bf16x3_rows_kernel(WgX3Params p) {
       return;
     }
     f32x4 v = rawA[r];
-    if (MASK) {
+    if constexpr (BITS) {
+      const unsigned nib = rawMb[r] >> mshift[r];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = ((nib >> c) & 1u) ? v[c] : 0.f;
+    } else if (MASK) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = rawM[r][c] > 0.f ? v[c] : 0.f;
     }
@@ -688,8 +709,9 @@ void launch_wg(const WgX3Params &p, int grid, hipStream_t st) {
 template <int NTA, int KTB>
 bool launch_wg_g16(const WgX3Params &p, int layout, int grid, hipStream_t st) {
   const dim3 g(grid, p.kparts);
-  NSDP_TRACE("wgrad_bf16x3<%d,%d,%s,notail> g16:%s", NTA, KTB, p.mask ? "mask" : "plain", layout == 1 ? "dy" : layout == 2 ? "x" : "dy,x");
-  if (layout == 1 && p.mask) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, false, false, false, 1>), g, dim3(256), 0, st, p);
+  NSDP_TRACE("wgrad_bf16x3<%d,%d,%s,notail> g16:%s", NTA, KTB, p.bits ? "bits" : p.mask ? "mask" : "plain", layout == 1 ? "dy" : layout == 2 ? "x" : "dy,x");
+  if (layout == 1 && p.bits) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, false, false, false, 1, true>), g, dim3(256), 0, st, p);
+  else if (layout == 1 && p.mask) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, true, false, false, false, 1>), g, dim3(256), 0, st, p);
   else if (layout == 1) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false, false, false, 1>), g, dim3(256), 0, st, p);
   else if (layout == 2 && !p.mask) hipLaunchKernelGGL((wgrad_bf16x3_rows_kernel<NTA, KTB, false, false, false, false, 2>), g, dim3(256), 0, st, p);
   else return false;
@@ -879,13 +901,15 @@ int nsdp_linear_wgrad_bf16x3_g16_supported(long long M, int N, int K, int layout
 }
 int nsdp_linear_wgrad_bf16x3_g16_f32(const float *dY, const float *X, const float *mask, int relu_x, float *dW, float *db,
                                      long long M, int N, int K, int accumulate, float *workspace, size_t workspace_bytes,
-                                     NsdpWgradReduceDesc *desc_out, int layout, void *stream) {
-  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_g16_supported(M, N, K, layout, mask != nullptr),
-               "linear_wgrad_bf16x3_g16: unsupported call M=%lld N=%d K=%d layout=%d mask=%d", M, N, K, layout, mask != nullptr);
+                                     NsdpWgradReduceDesc *desc_out, int layout, const unsigned char *mask_bits, void *stream) {
+  NSDP_REQUIRE(nsdp_linear_wgrad_bf16x3_g16_supported(M, N, K, layout, mask != nullptr || mask_bits != nullptr),
+               "linear_wgrad_bf16x3_g16: unsupported call M=%lld N=%d K=%d layout=%d mask=%d", M, N, K, layout, mask != nullptr || mask_bits != nullptr);
+  NSDP_REQUIRE(!mask_bits || (layout == 1 && !mask), "linear_wgrad_bf16x3_g16: ReLU bits mask a G16 dY (layout 1), instead of `mask`");
   NSDP_REQUIRE(dY && X && dW && workspace, "linear_wgrad_bf16x3_g16: null pointer");
   NSDP_REQUIRE(workspace_bytes >= nsdp_linear_wgrad_bf16x3_workspace_bytes(M, N, K), "linear_wgrad_bf16x3_g16: workspace too small");
   const X3Plan pl = plan_x3(M, N, K);
   WgX3Params p{dY, X, mask, relu_x, workspace, M, N, K, pl.blocks_per_wg, db != nullptr, pl.kparts};
+  p.bits = mask_bits;
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kWgradX3, st, 2.0 * M * N * K, 4.0 * (static_cast<double>(M) * (K + N)));
   const bool ok = pl.nta == 8 ? launch_wg_g16<8, 8>(p, layout, pl.grid, st)

@@ -71,6 +71,9 @@ struct X3Params {
   // rows (k4.h: the very expression of the K = 4 forward kernel, so the values are the ones that kernel would have stored)
   // instead of streaming [M, K] floats from HBM.  X is unused.  h_w0 [K, 4] row-major zero-padded, h_b0 [K] or NULL.
   const float *h_x4 = nullptr, *h_w0 = nullptr, *h_b0 = nullptr;
+  // ReLU bits (see below): PRE == 4 reads `bits` as the mask of X; a G16 output with relu_out writes `bits_out` when non-null
+  const unsigned char *bits = nullptr;
+  unsigned char *bits_out = nullptr;
 };
 
 // G16 layout (the LAY template parameter of the kernel; nsdp_linear_bf16x3_g16_f32, gemm_bf16x3_g16.hip): a tensor [M, C]
@@ -80,6 +83,12 @@ struct X3Params {
 // covers are ONE contiguous KiB in lane order li + 16 g (row-major: 16 runs of 64 B, 800 or 1024 B apart -- the address
 // pattern was measured at 14 % (loads) + 15 % (stores) of the 200-wide launches, docs/EXPERIMENTS.md round 4).  The layout of
 // the tensors BETWEEN two of these kernels: hidden layers of the attention MLPs and their gradients, which nothing else reads.
+// ReLU bits (PRE == 4 / X3Params::bits): the mask of a hidden layer h = relu(.) [M, H] as ONE BIT per element instead of the fp32
+// tensor itself -- [M / 16][ceil(H / 32)][64] bytes: the byte of (row group, k block kb, lane (li, g)) holds [h > 0] for row li and
+// the eight channels this kernel's fragment convention gives that lane in block kb (bits 0-3: 32 kb + 4 g .. + 3, bits 4-7:
+// 32 kb + 16 + 4 g .. + 3).  Written by the epilogue of the layer that produces h in G16 (bits_out), read by the masked prologue of
+// its dX GEMM (PRE == 4: one byte load per row tile and k block where PRE == 1 streams two float4) and by its weight gradient:
+// 28 B per row of a 200-wide layer instead of 800.
 constexpr int kLayX = 1;      // X (and the PRE == 1 mask)
 constexpr int kLayY = 2;      // Y: stored straight from the accumulators, one contiguous KiB per tile, no LDS staging
 constexpr int kLayR = 4;      // the residual (it only initialises the accumulators: independent of Y's layout)
@@ -155,6 +164,9 @@ __device__ __forceinline__ void row16_sum20(float (&t)[20]) {
 __device__ __forceinline__ void xload(f32x4 &dst, const float *lane_ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(lane_ptr));
 }
+__device__ __forceinline__ void bload(unsigned &dst, const unsigned char *lane_ptr) {      // one byte of ReLU bits, zero-extended
+  asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(lane_ptr));
+}
 
 
 // weight fragments come back from LDS through hand-placed ds_read_b128 (the compiler sinks ordinary LDS loads
@@ -204,6 +216,8 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr bool kXG = (LAY & kLayX) != 0, kYG = (LAY & kLayY) != 0, kRG = (LAY & kLayR) != 0;
   static_assert(!kYG || (!GATHER && !TAIL), "G16 output: plain epilogue forms");
   static_assert(!kXG || PRE != 3, "G16 input: there is no X in the H0 forms");
+  static_assert(PRE != 4 || kXG, "ReLU bits belong to G16 operands");
+  constexpr bool kMasked = PRE == 1 || PRE == 4;      // the masked prologues keep the raw activations in registers
   static_assert(!GATHER || PRE == 0 || PRE == 3, "the gathered addend belongs to the plain-prologue forms");
   static_assert(!TAIL || (PRE == 0 && !GATHER), "the K = 4 tail belongs to the plain-prologue forms");
   constexpr bool WRES = KBM > 2;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   // PRE != 1: the raw fp32 activations go global -> LDS by DMA as well (wave-private 8 KiB pieces, two k blocks
   // deep): no registers in flight, issued a whole k block earlier.  PRE == 1 (activation + mask) would not fit
   // in LDS next to the weights and keeps the register path.
-  constexpr bool kXLds = PRE != 1 && !XREG && !kH0;
+  constexpr bool kXLds = !kMasked && !XREG && !kH0;
   // LDS: [weight buffer 0][epilogue extension][weight buffer 1] (streaming form) + the activation staging.
   // STAGED EPILOGUE (streaming form): the output tile of a wave goes to HBM through LDS -- accumulators (lane = row li, four
   // columns) are written row-major into a per-wave piece of the weight buffer that the tile's last k block has just released
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 
   // per-lane activation rows of a tile, clamped into the tensor (rows >= M are computed and never stored)
   const float *xa[MT], *xn[MT];
-  const float *ma[MT], *mn[MT];
+  const float *ma[MT], *mn[MT];      // (PRE == 4: byte pointers into the ReLU bits, carried as float pointers)
   auto set_rows = [&](long long t, const float **x, const float **m) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -275,6 +289,8 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       const long long ro = kXG ? (r & ~15LL) * K + (r & 15) * 4 : r * K;
       x[mt] = p.X + ro;
       m[mt] = PRE == 1 ? p.mask + ro : nullptr;
+      if constexpr (PRE == 4)      // byte (row group, kb = 0, lane (li, g)); k block kb is 64 bytes further
+        m[mt] = reinterpret_cast<const float *>(p.bits + (r >> 4) * (static_cast<long long>((K + 31) >> 5) * 64) + (r & 15) * 4 + g);
     }
   };
   set_rows(tile, xa, ma);
@@ -318,6 +334,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 
   // raw activations of one k block: [mt][half] = 4 consecutive k each (k = 32 kb + 16 half + 4 g ..)
   f32x4 raw[kXLds ? 1 : MT][2], rawm[kXLds ? 1 : MT][2];
+  unsigned rawb[PRE == 4 ? MT : 1];      // (PRE == 4) the k block's ReLU bits of this lane's row: bits 0-3 half 0, bits 4-7 half 1
   auto xissue = [&](const float *const *x, const float *const *m, int kb, unsigned xb) {
     if constexpr (kH0) return;
 #pragma unroll
@@ -338,6 +355,9 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         } else {
           xload(raw[mt][hf], x[mt] + ko);
           if constexpr (PRE == 1) xload(rawm[mt][hf], m[mt] + ko);
+          if constexpr (PRE == 4) {
+            if (hf == 0) bload(rawb[mt], reinterpret_cast<const unsigned char *>(m[mt]) + kb * 64);
+          }
         }
       }
   };
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       for (int mt = 0; mt < MT; ++mt) {
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[mt][0]), "+v"(raw[mt][1]));
         if constexpr (PRE == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawm[mt][0]), "+v"(rawm[mt][1]));
+        if constexpr (PRE == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rawb[mt]));
       }
     }
   };
@@ -378,6 +399,11 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         const f32x4 mk = rawm[mt][pr >> 1];
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = mk[c] > 0.f ? v[c] : 0.f;
+      }
+      if constexpr (PRE == 4) {      // (only the pair's two values are used below)
+        const unsigned nib = rawb[mt] >> (4 * (pr >> 1));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = ((nib >> c) & 1u) ? v[c] : 0.f;
       }
     }
     if (PRE == 2) {
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr int kConvFirst = kXLds ? NT - kConvSteps : 0;     // first n-tile step that carries split work
   constexpr int kPairs = MT * 4;
   constexpr int kPerStep = (kPairs + kConvSteps - 1) / kConvSteps;
-  constexpr int kValuPerMfma = (kPerStep * (PRE == 1 ? 13 : PRE == 2 ? 10 : PRE == 3 ? 21 : 9) + 6 * MT - 1) / (6 * MT);
+  constexpr int kValuPerMfma = (kPerStep * ((PRE == 1 || PRE == 4) ? 13 : PRE == 2 ? 10 : PRE == 3 ? 21 : 9) + 6 * MT - 1) / (6 * MT);
 
 #ifdef NSDP_X3_TIMING
   unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -840,9 +866,13 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
       // from the registers, consecutive tiles consecutive KiB.  No out_mask / addend (host contract).
       auto g16_out = [&]() __attribute__((always_inline)) {      // (as a CALL it would spill the accumulators)
         float *ytile = p.Y + row0 * N + (li_e + 16 * g_e) * 4;
+        // ReLU bits of the output (X3Params::bits_out): n tiles 2 j and 2 j + 1 are the two halves of k block j of the NEXT
+        // kernel's fragment convention -- the lane owns both nibbles of byte (row group, j, li * 4 + g)
+        unsigned char *btile = p.bits_out ? p.bits_out + (row0 >> 4) * (static_cast<long long>((N + 31) >> 5) * 64) + li_e * 4 + g_e : nullptr;
         static_for<0, MT>([&](auto MI) __attribute__((always_inline)) {
           constexpr int mt = decltype(MI)::value;
           if (row0 + mt * 16 < p.M) {                                // (M % 16 == 0: a row tile exists or does not)
+            unsigned byte = 0;
             static_for<0, NT>([&](auto NI) __attribute__((always_inline)) {
               constexpr int nt = decltype(NI)::value;
               const float4 bv = bias4[nt];
@@ -851,7 +881,15 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], 0.f);
               }
-              if (nt * 16 + 4 * g_e + 4 <= N) *reinterpret_cast<f32x4 *>(ytile + mt * 16 * N + nt * 256) = v;
+              const bool cv = nt * 16 + 4 * g_e + 4 <= N;
+              if (cv) *reinterpret_cast<f32x4 *>(ytile + mt * 16 * N + nt * 256) = v;
+              if (btile) {
+                const unsigned nib = cv ? ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) : 0u;
+                byte = (nt & 1) ? (byte | (nib << 4)) : nib;
+                if ((nt & 1) || nt == NT - 1) {
+                  if (nt * 16 < ((N + 31) >> 5) * 32) btile[mt * (((N + 31) >> 5) * 64) + (nt >> 1) * 64] = static_cast<unsigned char>(byte);
+                }
+              }
             });
           }
         });
@@ -897,7 +935,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
         }
       };
       if (p.out_mask) {
-        if constexpr (PRE == 1) {
+        if constexpr (kMasked) {
           if (p.addend) epilogue(std::integral_constant<int, 2>{});
           else epilogue(std::true_type{});
         } else {

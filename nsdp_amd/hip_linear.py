@@ -133,16 +133,31 @@ def _fwd_x3_gather(x2, wp, N, b, gather, relu_in, relu_out):
 # anything else (ops.mlp2 / ResnetBlockFC keep it private).  NSDP_G16=0: row-major everywhere (A/B knob).
 G16 = os.environ.get("NSDP_G16", "1") != "0"
 LAY_X, LAY_Y = 1, 2
+# The ReLU mask of a G16 hidden tensor as ONE BIT per element (csrc/x3_kernel.h "ReLU bits": written by the epilogue of the GEMM
+# that produces the tensor, read by the masked prologue of its dX GEMM and by its weight gradient) instead of the fp32 tensor
+# itself: 28 bytes per row of a 200-wide layer where the mask stream was 800 -- a quarter of the bytes of the decoder's masked dX
+# GEMM, a third of its masked weight gradient's.  NSDP_G16_BITS=0: the fp32 tensor as the mask (A/B knob).
+G16_BITS = os.environ.get("NSDP_G16_BITS", "1") != "0"
 
 
-def _fwd_x3_g16(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, layout, addend=None):
-    """_fwd_x3 with X (and mask) or Y in the G16 layout (nsdp_linear_bf16x3_g16_f32)."""
+def relu_bits(M, C, device):
+    """An uninitialised ReLU-bits buffer for a G16 tensor [M, C] (nsdp_relu_bits_bytes)."""
+    L = lib()
+    L.nsdp_relu_bits_bytes.restype = ctypes.c_size_t
+    return torch.empty(int(L.nsdp_relu_bits_bytes(_ll(M), _ci(C))), dtype=torch.uint8, device=device)
+
+
+def _fwd_x3_g16(x2, wp, N, b, residual, mask, out_mask, relu_in, relu_out, layout, addend=None, mask_bits=None, bits_out=None):
+    """_fwd_x3 with X (and mask) or Y in the G16 layout (nsdp_linear_bf16x3_g16_f32).  ``mask_bits``: the mask of a G16 X as ReLU
+    bits (instead of ``mask``); ``bits_out``: a relu_bits() buffer the kernel fills with [Y > 0] (G16 Y with an output ReLU)."""
     M, K = x2.shape
     y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
     with on_device(x2):
         check(lib().nsdp_linear_bf16x3_g16_f32(fptr(x2, "x"), ctypes.c_void_p(wp.data_ptr()), optptr(b), optptr(residual),
                                                optptr(mask), optptr(out_mask), optptr(addend), fptr(y), _ll(M), _ci(N), _ci(K),
-                                               _ci(int(relu_in)), _ci(int(relu_out)), _ci(int(layout)), stream_ptr()),
+                                               _ci(int(relu_in)), _ci(int(relu_out)), _ci(int(layout)),
+                                               ctypes.c_void_p(mask_bits.data_ptr() if mask_bits is not None else None),
+                                               ctypes.c_void_p(bits_out.data_ptr() if bits_out is not None else None), stream_ptr()),
               "nsdp_linear_bf16x3_g16_f32")
     return y
 
@@ -157,10 +172,13 @@ def to_g16(t, back=False):
     return out.reshape(t.shape)
 
 
-def _wgrad_g16_fn(layout):
+def _wgrad_g16_fn(layout, bits=None):
     """Weight-gradient routine (the `fn` protocol of wgrad_direct / _wgrad_deferred) with dY + mask (layout 1) or X (layout 2) in
-    the G16 layout (nsdp_linear_wgrad_bf16x3_g16_f32): the sums of _wgrad_x3, bit for bit."""
+    the G16 layout (nsdp_linear_wgrad_bf16x3_g16_f32): the sums of _wgrad_x3, bit for bit.  ``bits``: dY's mask as ReLU bits
+    (the `mask` argument of the routine is then ignored)."""
     def fn(dy2, x2, mask, relu_x, want_db, out=None):
+        if bits is not None:
+            mask = None
         M, N = dy2.shape
         K = x2.shape[1]
         L = lib()
@@ -177,11 +195,12 @@ def _wgrad_g16_fn(layout):
                     _flush_reduce(batch)
             check(L.nsdp_linear_wgrad_bf16x3_g16_f32(fptr(dy2, "dy"), fptr(x2, "x"), optptr(mask), _ci(int(relu_x)), fptr(dw),
                                                      optptr(db), _ll(M), _ci(N), _ci(K), _ci(acc), fptr(ws), ctypes.c_size_t(nbytes),
-                                                     ctypes.byref(desc) if desc is not None else None, _ci(int(layout)), stream_ptr()),
+                                                     ctypes.byref(desc) if desc is not None else None, _ci(int(layout)),
+                                                     ctypes.c_void_p(bits.data_ptr() if bits is not None else None), stream_ptr()),
                   "nsdp_linear_wgrad_bf16x3_g16_f32")
             if batch is not None:
                 batch["descs"].append(desc)
-                batch["keep"].append((ws, dw, db))
+                batch["keep"].append((ws, dw, db, bits))
                 batch["targets"] |= ptrs
                 if len(batch["descs"]) + len(batch["descs_b16"]) >= BATCH_REDUCE:
                     _flush_reduce(batch)
@@ -792,11 +811,13 @@ def _packs(w, owner, kind, want_t):
     return ent
 
 
-def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None, lay=0):
+def _run(kind, x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, res_sign=1.0, addend=None, lay=0, mask_bits=None,
+         bits_out=None):
     if lay:        # G16 operands (see _fwd_x3_g16): the caller checked the form (g16_pair_ok)
         if kind != "x3" or res_sign != 1.0:
             raise ValueError("G16 layouts belong to the bf16x3 kernels")
-        return _fwd_x3_g16(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, lay, addend=addend)
+        return _fwd_x3_g16(x2, pack, N, b, residual, None if mask_bits is not None else mask, out_mask, relu_in, relu_out, lay,
+                           addend=addend, mask_bits=mask_bits, bits_out=bits_out)
     if addend is not None:
         if kind == "x3" and mask is not None and out_mask is not None and not relu_in:
             return _fwd_x3(x2, pack, N, b, residual, mask, out_mask, relu_in, relu_out, addend=addend)
@@ -1136,25 +1157,31 @@ class _LinearFn(torch.autograd.Function):
         if lay and (kind != "x3" or init_gather is not None or bw or tail is not None or (lay == LAY_Y and res2 is not None)
                     or (lay == LAY_X and (grad_sum is not None or ctx.skip_dst is not None))):
             raise ValueError("G16 layout: a plain bf16x3 layer pair only (g16_pair_ok)")
+        bits = None
         if init_gather is not None:
             if kind != "x3" or res2 is not None:
                 raise ValueError("init_gather needs a layer on the bf16x3 kernel (gather_init_ok) without a residual")
             y = _fwd_x3_gather(x2, wp, N, b, init_gather, relu_in, relu_out)
         else:
-            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, res_sign, lay=lay)
+            # (G16 output behind a ReLU, in a pass that will run backward: its mask as ReLU bits, written by this very launch)
+            if (lay == LAY_Y and G16_BITS and relu_out and not ctx.premasked
+                    and (ctx.needs_input_grad[0] or w_param is not None or ctx.needs_input_grad[1])):
+                bits = relu_bits(M, N, x2.device)
+            y = _run(kind, x2, wp, N, b, res2, None, None, relu_in, relu_out, res_sign, lay=lay, bits_out=bits)
         ctx.res_sign = res_sign
         ctx.relu_in, ctx.relu_out = relu_in, relu_out
         ctx.has_bias, ctx.has_res = b is not None, residual is not None
         ctx.x_shape, ctx.k_orig, ctx.n_out, ctx.kind_t = x.shape, K, N, kind_t
         ctx.fwd_key = _param_key(w_param) if w_param is not None else None
-        ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked) else None)
+        # (the ReLU's mask for the backward pass: the bits where they were written, else the output itself)
+        ctx.save_for_backward(x2, wpt, y if (relu_out and not ctx.premasked and bits is None) else None, bits)
         return y.reshape(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, dy):
         if dy is None:          # (K4Tail: the next layer's dX GEMM produced this layer's weight gradient itself)
             return (None,) * 16
-        x2, wpt, y = ctx.saved_tensors
+        x2, wpt, y, bits = ctx.saved_tensors
         N = ctx.n_out
         dy2 = dy.reshape(-1, N)
         dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
@@ -1162,8 +1189,8 @@ class _LinearFn(torch.autograd.Function):
         lay = ctx.lay
         if ctx.w_param is not None:
             fn = None
-            if lay:      # LAY_Y: dY (and the mask y) arrive in G16; LAY_X: the input x2 is
-                fn = _wgrad_g16_fn(1 if lay == LAY_Y else 2)
+            if lay:      # LAY_Y: dY (and the mask: y, or its ReLU bits) arrive in G16; LAY_X: the input x2 is
+                fn = _wgrad_g16_fn(1 if lay == LAY_Y else 2, bits)
             elif (REMASK_K4 and y is not None and x2.shape[1] == 4 and not ctx.relu_in and N % 4 == 0 and N >= 16
                     and x2.shape[0] >= 4096 and not ctx.has_res and ctx.fwd_key == _param_key(ctx.w_param)):
                 # first layer of a position-encoding MLP: its ReLU mask is cheaper to recompute from the coordinates.
@@ -1178,7 +1205,7 @@ class _LinearFn(torch.autograd.Function):
                 wgrad_direct(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)
         elif ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             if lay:
-                dw, db = _wgrad_g16_fn(1 if lay == LAY_Y else 2)(dy2, x2, y, ctx.relu_in, ctx.has_bias)
+                dw, db = _wgrad_g16_fn(1 if lay == LAY_Y else 2, bits)(dy2, x2, y, ctx.relu_in, ctx.has_bias)
             else:
                 dw, db = _wgrad_sliced(dy2, x2, y, ctx.relu_in, ctx.has_bias, ctx.k_orig)
         tl = ctx.tail
@@ -1206,7 +1233,7 @@ class _LinearFn(torch.autograd.Function):
             # (G16: the gradient of a G16 output arrives in G16 -- this GEMM's X and mask; the gradient of a G16 input leaves in it)
             dx = _run(ctx.kind_t, dyk, wpt, x2.shape[1], None, link.buf if link is not None else None, mk,
                       x2 if (ctx.relu_in or ctx.mask_dx) else None, False, False, addend=addend,
-                      lay=(LAY_X if lay == LAY_Y else LAY_Y if lay == LAY_X else 0))
+                      lay=(LAY_X if lay == LAY_Y else LAY_Y if lay == LAY_X else 0), mask_bits=bits)
             dx = dx[:, :ctx.k_orig].reshape(ctx.x_shape) if ctx.k_orig != dx.shape[1] else dx.reshape(ctx.x_shape)
             if link is not None:         # running sum over the layers that share this input
                 link.pending -= 1

@@ -14,6 +14,20 @@ def _rand(g, *shape, scale=1.0):
     return (torch.randn(*shape, generator=g) * scale).to(DEV)
 
 
+def _bits_ref(h):
+    """ReLU bits of h [M, C] with torch ops (the definition): [M / 16][ceil(C / 32)][64] bytes, byte (group, kb, 4 * row + g) =
+    bits 0-3 [h > 0] at channels 32 kb + 4 g .. + 3, bits 4-7 at 32 kb + 16 + 4 g .. + 3."""
+    M, C = h.shape
+    KB = (C + 31) // 32
+    pos = torch.zeros(M, KB * 32, dtype=torch.bool, device=h.device)
+    pos[:, :C] = h > 0
+    p = pos.reshape(M // 16, 16, KB, 2, 4, 4)                 # group, row, kb, half, g, c
+    w = torch.tensor([1, 2, 4, 8], device=h.device, dtype=torch.int32)
+    nib = (p.to(torch.int32) * w).sum(-1)                     # group, row, kb, half, g
+    byte = nib[:, :, :, 0, :] + 16 * nib[:, :, :, 1, :]       # group, row, kb, g
+    return byte.permute(0, 2, 1, 3).contiguous().reshape(-1).to(torch.uint8)
+
+
 def _g16_ref(t):
     """Row-major [M, C] -> G16 with torch ops (the definition)."""
     M, C = t.shape
@@ -50,6 +64,10 @@ def test_linear_g16_is_bit_equal_to_row_major(M, K, N, form):
         ref = hl._fwd_x3(x, wp, N, b, None, None, None, False, True)
         got = hl._fwd_x3_g16(x, wp, N, b, None, None, None, False, True, hl.LAY_Y)
         assert torch.equal(hl.to_g16(got, back=True), ref)
+        bits = hl.relu_bits(M, N, DEV).fill_(0xAA)             # ... and the ReLU bits the same launch writes on request
+        got = hl._fwd_x3_g16(x, wp, N, b, None, None, None, False, True, hl.LAY_Y, bits_out=bits)
+        assert torch.equal(hl.to_g16(got, back=True), ref)
+        assert torch.equal(bits, _bits_ref(ref))
     elif form == "y_relu_in":    # ResnetBlockFC's fc_0
         if not L.nsdp_linear_bf16x3_g16_supported(hl._ll(M), N, K, 2, 0, 1):
             pytest.skip("form not instantiated")
@@ -74,10 +92,16 @@ def test_linear_g16_is_bit_equal_to_row_major(M, K, N, form):
         ref = hl._fwd_x3(x, wp, N, None, None, mask, omask, False, False, addend=add)
         got = hl._fwd_x3_g16(hl.to_g16(x), wp, N, None, None, hl.to_g16(mask), omask, False, False, hl.LAY_X, addend=add)
         assert torch.equal(got, ref)
+        # ... and the same two with the mask as ReLU bits (one bit per element, the layout of csrc/x3_kernel.h)
+        bits = _bits_ref(mask)
+        got = hl._fwd_x3_g16(hl.to_g16(x), wp, N, None, res, None, None, False, False, hl.LAY_X, mask_bits=bits)
+        assert torch.equal(got, hl._fwd_x3(x, wp, N, None, res, mask, None, False, False))
+        got = hl._fwd_x3_g16(hl.to_g16(x), wp, N, None, None, None, omask, False, False, hl.LAY_X, addend=add, mask_bits=bits)
+        assert torch.equal(got, ref)
 
 
 @pytest.mark.parametrize("M,N,K", [(65536, 128, 128), (32768 + 32, 120, 120), (262144 + 64, 200, 200), (51200, 256, 256), (100000 * 32 // 32 * 32, 200, 200)])
-@pytest.mark.parametrize("layout,masked", [(1, True), (1, False), (2, False)])
+@pytest.mark.parametrize("layout,masked", [(1, True), (1, "bits"), (1, False), (2, False)])
 def test_wgrad_g16_is_bit_equal_to_row_major(M, N, K, layout, masked):
     from nsdp_amd import hip_linear as hl
     if not hl.lib().nsdp_linear_wgrad_bf16x3_g16_supported(hl._ll(M), N, K, layout, int(masked)):
@@ -86,7 +110,7 @@ def test_wgrad_g16_is_bit_equal_to_row_major(M, N, K, layout, masked):
     dy, x = _rand(g, M, N), _rand(g, M, K)
     mask = torch.relu(_rand(g, M, N)) if masked else None
     dw0, db0 = hl._wgrad_x3(dy, x, mask, True, True)
-    fn = hl._wgrad_g16_fn(layout)
+    fn = hl._wgrad_g16_fn(layout, _bits_ref(mask) if masked == "bits" else None)
     if layout == 1:
         dw1, db1 = fn(hl.to_g16(dy), x, hl.to_g16(mask) if masked else None, True, True)
     else:
@@ -153,6 +177,8 @@ def test_layer_pair_with_a_g16_hidden_tensor_is_bit_equal(M, K, H, N, resnet):
     L.nsdp_trace_read(buf, n)
     trace = buf.value.decode()
     assert "g16:y" in trace and "g16:x" in trace and "g16:dy" in trace, trace[:2000]      # the forms ran
+    if hip_linear.G16_BITS:
+        assert ",bits,notail> g16:dy" in trace, trace[:2000]                               # ... with the mask as ReLU bits
     b = _mlp_step(False, M, K, H, N, resnet, 5)
     for sa, sb in zip(a, b):
         for ta, tb in zip(sa, sb):

@@ -412,7 +412,7 @@ def test_b16_train_step_matches_golden():
     masked = () if ops.PAIR_MASK else ("wgrad_bf16x3<13,13,mask,notail>",)   # (NSDP_PAIR_MASK=1 removes the masked variants)
     g16 = hip_linear.G16 and not ops.PAIR_MASK
     if g16:      # the hidden tensors of fc_gamma (and their gradients) in the G16 layout: every form of the pair ran
-        masked = ("wgrad_bf16x3<13,13,mask,notail> g16:dy",)
+        masked = ("wgrad_bf16x3<13,13,bits,notail> g16:dy" if hip_linear.G16_BITS else "wgrad_bf16x3<13,13,mask,notail> g16:dy",)
         assert any(n.startswith("linear_bf16x3<") and n.endswith(" g16:y") for n in names), sorted(names)
         assert any(n.startswith("linear_bf16x3<") and n.endswith(" g16:x") for n in names), sorted(names)
     from nsdp_amd import hip_attention
