@@ -104,7 +104,7 @@ def test_linear_g16_is_bit_equal_to_row_major(M, K, N, form):
 @pytest.mark.parametrize("layout,masked", [(1, True), (1, "bits"), (1, False), (2, False)])
 def test_wgrad_g16_is_bit_equal_to_row_major(M, N, K, layout, masked):
     from nsdp_amd import hip_linear as hl
-    if not hl.lib().nsdp_linear_wgrad_bf16x3_g16_supported(hl._ll(M), N, K, layout, int(masked)):
+    if not hl.lib().nsdp_linear_wgrad_bf16x3_g16_supported(hl._ll(M), N, K, layout, int(bool(masked))):
         pytest.skip("form not instantiated")
     g = torch.Generator(device="cpu").manual_seed(M + 3 * N + 17 * K + layout)
     dy, x = _rand(g, M, N), _rand(g, M, K)

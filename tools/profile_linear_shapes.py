@@ -21,6 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--workload", default="forward", choices=["forward", "arbitrary"])
 ap.add_argument("--all-classes", action="store_true", help="list the calls of every kernel class, not only the dense layers'")
+ap.add_argument("--json", default=None, help="also write, per bf16x3 GEMM kernel TEMPLATE (the name rocprofv3 reports): launches / step and "
+                                              "the algorithmic bytes per launch split by operand -- what tools/pmc_attribution.py joins with the PMC passes")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = bench.model_config()
@@ -51,6 +53,44 @@ L.nsdp_prof_name.restype = ctypes.c_char_p
 KINDS = [L.nsdp_prof_name(i).decode() for i in range(NK)]
 calls = collections.OrderedDict()      # key -> {"n": calls, kind: [launches, ms, flops, bytes]}
 recording = [False]
+templates = collections.OrderedDict()  # rocprof kernel name of a bf16x3 GEMM -> {"launches", operand -> algorithmic bytes (summed)}
+
+
+def template_name(trace):
+    """NSDP_TRACE name of a bf16x3 GEMM launch -> the kernel's C++ template name as rocprofv3 prints it."""
+    m = re.match(r"linear_bf16x3<(\d+),(\d+),(\d+),(\d+),(\d+)>(.*)", trace)
+    if not m:
+        return None
+    mt, nt, pre, wv, xreg, rest = int(m[1]), int(m[2]), int(m[3]), int(m[4]), int(m[5]), m[6]
+    kbm = 4 if " wres" in rest else 2
+    gather = 2 if " gather1" in rest else 1 if " gather" in rest else 0
+    lay = {"x": 1, "y": 2, "xy": 3, "r": 4, "xr": 5, "yr": 6, "xyr": 7}.get((re.search(r" g16:(\w+)", rest) or [None, ""])[1], 0)
+    tail = 0
+    if " k4tail" in rest:
+        tail, kbm = -1, 2      # (k_out decides 1 / 2: filled in by the caller)
+    return [mt, nt, pre, wv, "true" if xreg else "false", kbm, gather, tail, lay]
+
+
+def operand_bytes(name, a, params):
+    """Algorithmic HBM bytes of one bf16x3 GEMM call by operand (the small L2-resident tables and the weights count as `other`)."""
+    v = {p: value(x) for (p, t), x in zip(params, a)}
+    M, N, K = int(v.get("M", 0)), int(v.get("N", 0)), int(v.get("K", 0))
+    out = {"X": 4.0 * M * K, "mask": 0.0, "residual": 0.0, "other": 4.0 * N * K, "Y": 4.0 * M * N}
+    if "h0" in name:
+        out["X"] = 16.0 * M
+    if "k4tail" in name:
+        out["Y"] = 0.0
+        out["other"] += 16.0 * M
+    if v.get("mask_bits"):
+        out["mask"] = float(((M + 15) // 16) * ((K + 31) // 32) * 64)
+    elif v.get("mask"):
+        out["mask"] = 4.0 * M * K
+    for opnd in ("residual", "out_mask", "addend"):
+        if v.get(opnd):
+            out["residual"] += 4.0 * M * N
+    if v.get("bits_out"):
+        out["Y"] += float(((M + 15) // 16) * ((N + 31) // 32) * 64)
+    return out, v
 
 
 def value(a):
@@ -64,8 +104,28 @@ def wrap(name, fn, params):
             return fn(*a)
         torch.cuda.synchronize()
         L.nsdp_prof_enable(1)              # (re-enabling clears the records)
+        x3 = name.startswith("nsdp_linear_bf16x3")
+        if x3:
+            L.nsdp_trace_enable(1)
         rc = fn(*a)
         torch.cuda.synchronize()
+        if x3:
+            L.nsdp_trace_enable(0)
+            nb = L.nsdp_trace_read(None, 0)
+            tb = ctypes.create_string_buffer(nb)
+            L.nsdp_trace_read(tb, nb)
+            ob, v = operand_bytes(name, a, params)
+            for tr in tb.value.decode().split("\n"):
+                tn = template_name(tr)
+                if tn is None:
+                    continue
+                if tn[7] == -1:
+                    tn[7] = 2 if int(v.get("k_out", 4)) == 3 else 1
+                key = "linear_bf16x3_kernel<" + ", ".join(str(t) for t in tn) + ">"
+                ent = templates.setdefault(key, {"launches": 0, "X": 0.0, "mask": 0.0, "residual": 0.0, "other": 0.0, "Y": 0.0})
+                ent["launches"] += 1
+                for kk, bb in ob.items():
+                    ent[kk] += bb
         ints = tuple((p, int(value(x))) for (p, t), x in zip(params, a) if t == "int" and p not in ("accumulate", "workspace_bytes", "ws_bytes"))
         ptrs = tuple(p for (p, t), x in zip(params, a) if t == "ptr" and value(x) and p in
                      ("bias", "residual", "mask", "out_mask", "addend", "gq", "db", "b0", "a_g", "qsub", "desc_out"))
@@ -121,5 +181,10 @@ for (name, ints, ptrs), ent in calls.items():
     n_l = sum(ent[k][0] for k in kinds); ms = sum(ent[k][1] for k in kinds); fl = sum(ent[k][2] for k in kinds); by = sum(ent[k][3] for k in kinds)
     shape = " ".join(f"{p}={v}" for p, v in ints if v != 0 or p in ("M", "N", "K"))      # (zero flags are not printed)
     rows.append((ms / STEPS, name.replace("nsdp_", ""), shape, ",".join(ptrs), ent["n"] / STEPS, n_l / ent["n"], 1e3 * ms / ent["n"], fl / ms / 1e9 if ms else 0, by / ent["n"] / 1e6))
+if args.json:
+    import json
+    json.dump({"steps": STEPS, "batch": args.batch, "workload": args.workload,
+               "templates": {k: {kk: (vv / STEPS) for kk, vv in v.items()} for k, v in templates.items()}},
+              open(args.json, "w"), indent=1)
 for ms_step, name, shape, ptrs, n, nl, us, tf, mb in sorted(rows, reverse=True):
     print(f"{name[:34]:34s} {shape[:66]:66s} {ptrs[:26]:26s} {n:5.1f} {nl:8.1f} {us:9.1f} {ms_step:8.3f} {tf:6.1f} {mb:9.2f}")
