@@ -25,8 +25,15 @@ void launch_g16(const X3Params &p, hipStream_t st) {
     if (p.K <= 128) launch_x3_pre<2, NT, PRE, 8, false, 4, 0, LAY>(p, st);      // weight planes resident in LDS
     else launch_x3_pre<2, NT, PRE, 4, false, 2, 0, LAY>(p, st, 2);
   } else if constexpr (NT == 13) {
-    if (p.M <= (1 << 19)) launch_x3_pre<2, 13, PRE, 4, true, 2, 0, LAY>(p, st, 2);
-    else launch_x3_pre<2, 13, PRE, 8, false, 2, 0, LAY>(p, st);
+    // (launch_x3 takes the register-path two-workgroup form up to 0.5 M rows; its PLAIN-prologue G16 instances are not built:
+    // the compiler parks hand-issued weight-fragment loads in AGPRs there -- tests/test_no_inflight_spills.py -- so those
+    // launches take the 8-wave form, 8-19 % slower at these sizes, which only a B <= 8 decoder reaches)
+    if constexpr (PRE == 2) {
+      if (p.M <= (1 << 19)) launch_x3_pre<2, 13, PRE, 4, true, 2, 0, LAY>(p, st, 2);
+      else launch_x3_pre<2, 13, PRE, 8, false, 2, 0, LAY>(p, st);
+    } else {
+      launch_x3_pre<2, 13, PRE, 8, false, 2, 0, LAY>(p, st);
+    }
   } else {
     const long long cus = nsdp::num_cus();
     const long long r3 = ((p.M + 191) / 192 + cus - 1) / cus * 192, r2 = ((p.M + 127) / 128 + cus - 1) / cus * 128;

@@ -86,7 +86,7 @@ def _asm(item):
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not available")
 def test_nothing_is_spilled_inside_the_mfma_regions():
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         listings = dict(ex.map(_asm, FILES.items()))
     checked = 0
     for src, text in listings.items():
