@@ -206,6 +206,7 @@ def _wgrad_g16_fn(layout, bits=None):
                     _flush_reduce(batch)
         return dw, db
     fn.batched_reduce = True
+    fn.extra_tensors = (bits,) if bits is not None else ()      # (read on whatever stream the routine runs: _wgrad_deferred records it)
     return fn
 
 
@@ -628,7 +629,10 @@ def _wgrad_deferred(dy2, x2, mask, relu_x, k_orig, w_param, b_param, fn=None):
                 else:
                     _flush_reduce(batch)      # (g may still be a pending reduction)
                     ent[1].add_(g)     # (shapes the kernels cannot accumulate in place: the padded K = 3 layers)
-    for t in (dy2, x2, mask):
+    # (everything the side stream's launches read must outlive them for the caching allocator: the operands, and what a routine
+    # carries in its closure -- the ReLU bits of a G16 layer; a freed bit buffer reused by the main stream gave a 16 % wrong
+    # gradient under NSDP_WGRAD_STREAM=1)
+    for t in (dy2, x2, mask) + tuple(getattr(fn, "extra_tensors", ())):
         if t is not None:
             t.record_stream(side)
 

@@ -99,4 +99,6 @@ def nondeterministic_knobs():
     from nsdp_amd.model import ops
     if not ops.FUSE_DPOS:           # (d(pos) summed by the atomic form of attn_pre_bwd)
         out.append("NSDP_FUSE_DPOS=0")
+    if not pointnet2_utils._SCATTER_DETERMINISTIC:      # (small / narrow scatters through the atomic kernel)
+        out.append("NSDP_SCATTER_DETERMINISTIC=0")
     return out

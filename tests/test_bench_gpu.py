@@ -73,8 +73,11 @@ def test_bench_graph_replay_is_the_default_and_eager_is_still_there():
     # (that the two ways of launching the step train alike is tests/test_graph_exec_gpu.py's subject: the runs here differ
     # in their number of set-up steps)
     f = _run("--no-cpu-baseline", "--reps", "1", "--force-reducer", "--backend", "gloo")
-    assert "two graphs around the eager all-reduce" in f["step_launch"], f["step_launch"]
+    forced_on = os.environ.get("NSDP_DP_OVERLAP") == "on"      # (knob matrix: the three-graph form everywhere)
+    assert ("head / tail / update" if forced_on else "two graphs around the eager all-reduce") in f["step_launch"], f["step_launch"]
     # the decoder bucket's all-reduce under the encoder's backward: one graph per side of each collective
     f3 = _run("--no-cpu-baseline", "--reps", "1", "--force-reducer", "--backend", "gloo", "--dp-overlap", "on")
     assert "head / tail / update" in f3["step_launch"], f3["step_launch"]
-    assert f3["ranks_in_sync"] and abs(f3["final_loss"] - f["final_loss"]) <= 1e-6 * max(1.0, abs(f["final_loss"])), (f3["final_loss"], f["final_loss"])
+    from helpers import nondeterministic_knobs
+    tol = 5e-2 if nondeterministic_knobs() else 1e-6      # (with fp32 atomics in the step two runs differ in rounding, amplified by Adam)
+    assert f3["ranks_in_sync"] and abs(f3["final_loss"] - f["final_loss"]) <= tol * max(1.0, abs(f["final_loss"])), (f3["final_loss"], f["final_loss"])

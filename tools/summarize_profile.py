@@ -117,7 +117,8 @@ for name in ("bench_default.json", "bench_b8.json", "bench_arbitrary.json", "ben
              "bench_forward_eval.json", "bench_forward_bf16.json", "bench_arbitrary_bf16.json", "bench_b8_bf16.json",
              "bench_2ranks_gloo.json", "bench_default_eager.json", "bench_b8_eager.json", "bench_forward_bf16_eager.json",
              "bench_arbitrary_bf16_eager.json", "bench_force_reducer_nccl.json", "bench_arbitrary_bf16_net1f32.json",
-             "linear_shapes.txt"):
+             "bench_force_reducer_nccl_overlap.json", "bench_arbitrary_bf16_net1dec32.json", "bench_8ranks_gloo.json",
+             "linear_shapes.txt", "x3_operands.json"):
     src = os.path.join(root, "gpurun_out", f"{tag}_{name}")       # written by tools/profile_round.sh
     if os.path.exists(src) and open(src).read().strip():
         open(os.path.join(out_dir, f"{tag}_{name}"), "w").write(open(src).read())
