@@ -92,6 +92,8 @@ def nondeterministic_knobs():
     out = []
     if not hip_attention.ONEHOT_SCATTER_F32:
         out.append("NSDP_ONEHOT_SCATTER_F32=0")
+    if not hip_attention.ONEHOT_SCATTER:      # (bf16 storage: the decoder's anchor tables by register-table atomics)
+        out.append("NSDP_ONEHOT_SCATTER=0")
     if hip_attention.INVERSE_LISTS == "0":
         out.append("NSDP_INVERSE_LISTS=0")
     if not pointnet2_utils._SCATTER_INVERSE:
