@@ -247,7 +247,12 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   constexpr int kExtWant = WV * NT * 64 - kWTile;                            // whole 16-row tiles for every wave
   constexpr int kExt = !kStage ? 0 : (kExtWant < 0 ? 0 : (kExtFree < 0 ? 0 : (kExtWant < kExtFree ? kExtWant : kExtFree)));
   constexpr int kPerWave = (kWTile + kExt) / WV;                             // u32x4 of epilogue staging per wave
-  constexpr int kTppMax = kPerWave / 64 < NT ? kPerWave / 64 : NT;           // 16-column tiles per pass (1 KiB per tile)
+  // 16-column tiles per pass (1 KiB per tile), at most 8: a pass keeps ~4 float4 per tile in flight (addend / mask chunks, bias,
+  // read-back) next to the accumulators -- the forms with room for a whole 13- or 16-tile row in one pass (the H0 forms: no
+  // activation staging) spilled ~120 registers per lane and tile there, 3 GB of scratch traffic per 1.8 M-row launch
+  // (profiles/r6_pmc_attribution.md: WRITE_SIZE 2.05 x the output)
+  constexpr int kTppFit = kPerWave / 64 < NT ? kPerWave / 64 : NT;
+  constexpr int kTppMax = kTppFit < 8 ? kTppFit : 8;
   constexpr int kPasses = kStage ? (NT + kTppMax - 1) / kTppMax : 1;
   constexpr int kTpp = (NT + kPasses - 1) / kPasses;
   static_assert(!kStage || kTppMax >= 1, "epilogue staging: no room for a 16 x 16 tile per wave");

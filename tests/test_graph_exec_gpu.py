@@ -225,6 +225,7 @@ def test_an_eval_step_captured_with_changing_weights_follows_the_training_in_bet
         torch.cuda.synchronize()
         want = evaluate()
         torch.cuda.synchronize()
+        assert bool(torch.isfinite(want).all()) and bool(torch.isfinite(got).all()), (bool(torch.isfinite(want).all()), bool(torch.isfinite(got).all()))
         assert not torch.equal(want, first)                     # (training moved the weights and the running statistics)
         assert torch.equal(got, want), float((got - want).abs().max())
         evaluate()                                              # (an eager evaluation replaces the modules' cached constants)
