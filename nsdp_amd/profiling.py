@@ -151,8 +151,21 @@ def _pmc_traffic(name, suffix=""):
         if not n:
             return {"traffic": None}
         total = (2.0 * sum(v[1] for v in fetch) + sum(v[1] for v in write)) * 1024.0
-        return {"traffic": round(total / n), "traffic_unit": f"bytes/launch (PMC, profiles/{os.path.basename(path)})",
-                "traffic_writes": round(sum(v[1] for v in write) * 1024.0 / n)}
+        out = {"traffic": round(total / n), "traffic_unit": f"bytes/launch (PMC, profiles/{os.path.basename(path)}; FETCH_SIZE x 2 as the guide prescribes)",
+               "traffic_writes": round(sum(v[1] for v in write) * 1024.0 / n)}
+        # the same passes with FETCH_SIZE CALIBRATED on the launches whose reads are known exactly, and the excess over SURVEY 8d's
+        # X + Y formula attributed by operand (tools/pmc_attribution.py -> profiles/rN_pmc_attribution.json; the bf16x3 class only)
+        att = path.replace("_pmc_hbm" + suffix + ".json", "_pmc_attribution.json")
+        if not suffix and os.path.exists(att):
+            with open(att) as f:
+                a = json.load(f)
+            if name.startswith(a.get("kernel", "?").replace("_kernel", "")):
+                out["traffic_calibrated"] = round(a["read_bytes_per_launch"] + a["write_bytes_per_launch"])
+                out["traffic_calibrated_over_algorithmic_by_operand"] = round(
+                    (a["read_bytes_per_launch"] + a["write_bytes_per_launch"])
+                    / (a["algorithmic_read_bytes_per_launch"] + a["algorithmic_write_bytes_per_launch"]), 3)
+                out["traffic_over_survey_8d"] = {k: round(v, 3) for k, v in a["over_survey_8d"].items()}
+        return out
     except Exception:
         return {"traffic": None}
 

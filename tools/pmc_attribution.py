@@ -65,4 +65,12 @@ out += ["", f"Class totals per step ({tot['n']:.0f} launches): algorithmic {1e-9
         f"by operand, {(tot['pr'] + tot['pw']) / surv:.3f} x SURVEY 8d's X + Y formula (of which masks +{tot['mask'] / surv:.3f}, residuals +{tot['res'] / surv:.3f}, "
         f"write amplification +{(tot['pw'] - tot['aw']) / surv:.3f}, read amplification +{(tot['pr'] - tot['ar']) / surv:.3f})."]
 open(os.path.join(root, f"{tag}_pmc_attribution.md"), "w").write("\n".join(out) + "\n")
+# the class figure bench.py's roofline quotes next to the guide's x2 correction (nsdp_amd/profiling.py::_pmc_traffic)
+json.dump({"kernel": "linear_bf16x3_kernel", "launches_per_step": tot["n"], "fetch_factor_row_major": cal[False], "fetch_factor_g16": cal[True],
+           "read_bytes_per_launch": tot["pr"] / tot["n"], "write_bytes_per_launch": tot["pw"] / tot["n"],
+           "algorithmic_read_bytes_per_launch": tot["ar"] / tot["n"], "algorithmic_write_bytes_per_launch": tot["aw"] / tot["n"],
+           "survey_8d_bytes_per_launch": surv / tot["n"],
+           "over_survey_8d": {"masks": tot["mask"] / surv, "residuals_and_output_masks": tot["res"] / surv,
+                              "write_amplification": (tot["pw"] - tot["aw"]) / surv, "read_amplification": (tot["pr"] - tot["ar"]) / surv}},
+          open(os.path.join(root, f"{tag}_pmc_attribution.json"), "w"), indent=1)
 print("\n".join(out[-2:]))
