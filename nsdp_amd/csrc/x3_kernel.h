@@ -252,7 +252,7 @@ __global__ __launch_bounds__(WV * 64, XREG ? 2 : 1) void linear_bf16x3_kernel(X3
   // activation staging) spilled ~120 registers per lane and tile there, 3 GB of scratch traffic per 1.8 M-row launch
   // (profiles/r6_pmc_attribution.md: WRITE_SIZE 2.05 x the output)
   constexpr int kTppFit = kPerWave / 64 < NT ? kPerWave / 64 : NT;
-  constexpr int kTppCap = (PRE == 3 && WV == 8) ? 5 : 8;      // (the 8-wave H0 forms have 256 registers per lane AND the K = 4 producer's state: 13 = 5 + 4 + 4)
+  constexpr int kTppCap = (NT == 13 && (WV == 8 || XREG)) ? 5 : 8;      // (the 256-register 13-tile forms: 13 = 5 + 4 + 4; the 8-wave H0 forms also hold the K = 4 producer's state)
   constexpr int kTppMax = kTppFit < kTppCap ? kTppFit : kTppCap;
   constexpr int kPasses = kStage ? (NT + kTppMax - 1) / kTppMax : 1;
   constexpr int kTpp = (NT + kPasses - 1) / kPasses;
