@@ -20,7 +20,14 @@ void launch_g16(const X3Params &p, hipStream_t st) {
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   if constexpr (PRE == 1 || PRE == 4) {
     if constexpr (NT <= 8) launch_x3_pre<2, NT, PRE, 4, true, 2, 0, LAY>(p, st, 2);
-    else launch_x3_pre<MT1, NT, PRE, 4, false, 2, 0, LAY>(p, st);
+    else if constexpr (PRE == 4 && NT == 13) {
+      // ReLU bits leave the register path room for 13 n tiles (the fp32 mask's raw float4 did not).  Two 4-wave workgroups per
+      // CU are 7 % faster ALONE (1421 -> 1323 us at 1.8 M rows with a residual, bit-identical) and 0.3 ms SLOWER in the B = 32
+      // step, where this launch runs beside the side stream's weight gradient (three interleaved rounds: 37.53 / 37.60 / 37.65
+      // against 37.25 / 37.33 / 37.33 ms): the one-workgroup form stays; nsdp_debug_set(6, 8192) selects the other (A/B)
+      if (nsdp::g_x3_dbg & 8192) launch_x3_pre<2, 13, 4, 4, true, 2, 0, LAY>(p, st, 2);
+      else launch_x3_pre<MT1, NT, PRE, 4, false, 2, 0, LAY>(p, st);
+    } else launch_x3_pre<MT1, NT, PRE, 4, false, 2, 0, LAY>(p, st);
   } else if constexpr (NT <= 8) {
     if (p.K <= 128) launch_x3_pre<2, NT, PRE, 8, false, 4, 0, LAY>(p, st);      // weight planes resident in LDS
     else launch_x3_pre<2, NT, PRE, 4, false, 2, 0, LAY>(p, st, 2);
