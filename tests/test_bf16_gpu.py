@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import build_product, fixture_setup, l2_err, model_cfg, run_forward, to_dev
+from helpers import batchnorm_three_launch, build_product, fixture_setup, l2_err, model_cfg, restore_model, run_forward, snapshot_model, to_dev
 from nsdp_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -440,8 +440,17 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
             with torch.no_grad():
                 out = run_forward(model, cfg, to_dev(data, DEV)).float().cpu().numpy()
             model.train()
+            snap = snapshot_model(model)
             _, opt = optimizer_factory({"optimizer": "Adam", "lr": 5e-4}, model.parameters())
             loss = train_fn(model, opt, to_dev(data, DEV), cfg)
+            loss_alt = None
+            if loss_bound > 0.05:
+                # the ill-conditioned case: the variant that lands next to the reference (three-launch BatchNorm: the batch mean
+                # summed in another order) keeps the ORIGINAL 5 % bar, so that the 8 % on the default cannot hide a regression
+                restore_model(model, snap)
+                _, opt2 = optimizer_factory({"optimizer": "Adam", "lr": 5e-4}, model.parameters())
+                with batchnorm_three_launch():
+                    loss_alt = train_fn(model, opt2, to_dev(data, DEV), cfg)
         precision.set_canonicalize_f32(False)
         l2 = l2_err(out[:, ::s], fx["eval_out"])
         ref_loss = float(fx["train_loss"])
@@ -449,3 +458,6 @@ def test_bf16_storage_against_the_full_size_reference_fixtures():
               f"train loss {loss:.6f} (reference {ref_loss:.6f}, rel {abs(loss - ref_loss) / ref_loss:.2e})")
         assert l2 <= l2_bound, (name, l2)
         assert abs(loss - ref_loss) <= loss_bound * ref_loss, (name, loss, ref_loss)
+        if loss_alt is not None:
+            print(f"   three-launch BatchNorm: train loss {loss_alt:.6f} (rel {abs(loss_alt - ref_loss) / ref_loss:.2e})")
+            assert abs(loss_alt - ref_loss) <= 0.05 * ref_loss, (name, loss_alt, ref_loss)
