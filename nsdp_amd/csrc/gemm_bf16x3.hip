@@ -417,6 +417,7 @@ int launch_x3(const X3Params &p, hipStream_t st) {
   // one 8-wave workgroup, bit-identical results).  13 n tiles would need 2 x 110 KiB.
   constexpr int MT1 = NT >= 16 ? 2 : NT >= 13 ? 3 : 4;
   const bool two_waves = NT <= 13 && !(g_x3_dbg & 32);
+  constexpr int kNT8 = NT > 8 && NT <= 13 ? NT : 13;      // (the 8-wave form below is reached with 9 ... 13 n tiles only: no 16-tile instances)
   // (the masked prologue as well, up to 8 n tiles: 10-25 % over one 4-wave workgroup with more row tiles)
   // N, K <= 128 (<= 8 n tiles, <= 4 k blocks), unmasked: the weight planes stay resident in LDS for the workgroup's lifetime
   // (96 KiB + 64 KiB of activation staging = the CU's 160 KiB): one 8-wave workgroup per CU, no barrier in the k loop.
@@ -438,8 +439,8 @@ int launch_x3(const X3Params &p, hipStream_t st) {
     if ((g_x3_dbg & 128) && !GATHER && p.res_sign == 1.f && !p.addend) {
       if (pre == 0) launch_x3_ap<13, 0>(p, st);
       else launch_x3_ap<13, 2>(p, st);
-    } else if (pre == 0) launch_x3_pre<2, (NT > 8 ? NT : 13), 0, 8, false, 2, GATHER>(p, st);
-    else launch_x3_pre<2, (NT > 8 ? NT : 13), 2, 8>(p, st);
+    } else if (pre == 0) launch_x3_pre<2, kNT8, 0, 8, false, 2, GATHER>(p, st);
+    else launch_x3_pre<2, kNT8, 2, 8>(p, st);
   } else {
     constexpr int MT0 = NT >= 16 ? 3 : 4;
     // Tile quantisation (16 n tiles): one persistent workgroup per CU walks row blocks of 4 waves x MT0 x 16 = 192 rows;
