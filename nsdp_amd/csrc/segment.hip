@@ -20,15 +20,20 @@ constexpr int kSortMax = 1024;         // longest list that is put into ascendin
 
 // offsets [B][N+1], entries [B][E]: entries[b][offsets[b][s] .. offsets[b][s+1]) = ascending list of e = i*k + j with
 // idx[b][e] == s
+// LDS_ENTRIES: the lists are filled and put into order in LDS (E more ints next to the counters) and written out as one coalesced
+// copy -- the ordering pass is one thread per list walking dependent loads and stores, 20x cheaper per step in LDS than through
+// L2 (the longest list of a 2048-point level, ~30 entries, took 130 us of a 136 us launch in global memory)
+template <bool LDS_ENTRIES>
 __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *__restrict__ idx_all, int E, int N,
                                                                  int32_t *__restrict__ offsets_all,
                                                                  int32_t *__restrict__ entries_all) {
-  extern __shared__ int cnt[];           // [N + 1]
+  extern __shared__ int cnt[];           // [N + 1] (+ [E] list entries)
   __shared__ int part[kInvThreads];
   const int b = blockIdx.x;
   const int32_t *idx = idx_all + static_cast<long long>(b) * E;
   int32_t *offsets = offsets_all + static_cast<long long>(b) * (N + 1);
   int32_t *entries = entries_all + static_cast<long long>(b) * E;
+  int *ent = LDS_ENTRIES ? cnt + (N + 1) : entries;
   for (int s = threadIdx.x; s <= N; s += kInvThreads) cnt[s] = 0;
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += kInvThreads) atomicAdd(&cnt[idx[e]], 1);
@@ -55,24 +60,28 @@ __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *
   }
   if (threadIdx.x == 0) offsets[N] = E;
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += kInvThreads) entries[atomicAdd(&cnt[idx[e]], 1)] = e;
+  for (int e = threadIdx.x; e < E; e += kInvThreads) ent[atomicAdd(&cnt[idx[e]], 1)] = e;
   __syncthreads();                   // (same workgroup: the entries written above are visible below)
   // fixed summation order: ascending entry number inside every list (lists are short: E / N on average)
   for (int s = threadIdx.x; s < N; s += kInvThreads) {
-    const int lo = offsets[s], hi = cnt[s];          // cursor ended at the list's end
+    const int lo = s ? cnt[s - 1] : 0, hi = cnt[s];          // every cursor ended at its list's end = the next list's start
     // (one thread, insertion sort: quadratic -- lists beyond kSortMax entries keep the order the atomics produced, i.e.
     // their sum is correct but its rounding may differ from run to run; kNN index sets stay far below the bound except
     // the decoder's anchor lists, which use the register-table / one-hot forms instead)
     if (hi - lo > kSortMax) continue;
     for (int i = lo + 1; i < hi; ++i) {
-      const int v = entries[i];
+      const int v = ent[i];
       int j = i - 1;
-      while (j >= lo && entries[j] > v) {
-        entries[j + 1] = entries[j];
+      while (j >= lo && ent[j] > v) {
+        ent[j + 1] = ent[j];
         --j;
       }
-      entries[j + 1] = v;
+      ent[j + 1] = v;
     }
+  }
+  if (LDS_ENTRIES) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += kInvThreads) entries[e] = ent[e];
   }
 }
 
@@ -148,12 +157,15 @@ int nsdp_knn_invert(const int32_t *idx, int B, int E, int N, int32_t *offsets, i
   NSDP_REQUIRE(N > 0 && N <= kMaxSources, "knn_invert: N=%d must be in [1, %d]", N, kMaxSources);
   hipStream_t st = nsdp::as_stream(stream);
   nsdp::prof::Scope scope(nsdp::prof::kKnn, st, 0.0, static_cast<double>(B) * (12.0 * E + 4.0 * N));
-  const size_t lds = (static_cast<size_t>(N) + 1) * sizeof(int);
+  const size_t lds_cnt = (static_cast<size_t>(N) + 1) * sizeof(int), lds_all = lds_cnt + static_cast<size_t>(E) * sizeof(int);
+  const bool in_lds = lds_all <= 148 * 1024;      // (+ 4 KiB of scan scratch: the CU's 160 KiB)
+  const size_t lds = in_lds ? lds_all : lds_cnt;
+  const void *fn = in_lds ? reinterpret_cast<const void *>(knn_invert_kernel<true>) : reinterpret_cast<const void *>(knn_invert_kernel<false>);
   if (lds > 60 * 1024) {      // (per call: the attribute belongs to the current device's function object)
-    NSDP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_invert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     static_cast<int>(lds)));
+    NSDP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
   }
-  hipLaunchKernelGGL(knn_invert_kernel, dim3(B), dim3(kInvThreads), lds, st, idx, E, N, offsets, entries);
+  if (in_lds) hipLaunchKernelGGL(knn_invert_kernel<true>, dim3(B), dim3(kInvThreads), lds, st, idx, E, N, offsets, entries);
+  else hipLaunchKernelGGL(knn_invert_kernel<false>, dim3(B), dim3(kInvThreads), lds, st, idx, E, N, offsets, entries);
   return nsdp::launch_status("knn_invert_kernel");
 }
 
