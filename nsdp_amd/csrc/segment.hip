@@ -20,9 +20,9 @@ constexpr int kSortMax = 1024;         // longest list that is put into ascendin
 
 // offsets [B][N+1], entries [B][E]: entries[b][offsets[b][s] .. offsets[b][s+1]) = ascending list of e = i*k + j with
 // idx[b][e] == s
-// LDS_ENTRIES: the lists are filled and put into order in LDS (E more ints next to the counters) and written out as one coalesced
-// copy -- the ordering pass is one thread per list walking dependent loads and stores, 20x cheaper per step in LDS than through
-// L2 (the longest list of a 2048-point level, ~30 entries, took 130 us of a 136 us launch in global memory)
+// LDS_ENTRIES: the lists are filled in LDS (E more ints next to the counters) and ordered from there (the ordering pass in
+// global memory was one thread per list walking dependent loads and stores through L2: the longest list of a 2048-point level,
+// ~30 entries, took 130 us of a 136 us launch)
 template <bool LDS_ENTRIES>
 __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *__restrict__ idx_all, int E, int N,
                                                                  int32_t *__restrict__ offsets_all,
@@ -62,26 +62,36 @@ __global__ __launch_bounds__(kInvThreads) void knn_invert_kernel(const int32_t *
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += kInvThreads) ent[atomicAdd(&cnt[idx[e]], 1)] = e;
   __syncthreads();                   // (same workgroup: the entries written above are visible below)
-  // fixed summation order: ascending entry number inside every list (lists are short: E / N on average)
-  for (int s = threadIdx.x; s < N; s += kInvThreads) {
-    const int lo = s ? cnt[s - 1] : 0, hi = cnt[s];          // every cursor ended at its list's end = the next list's start
-    // (one thread, insertion sort: quadratic -- lists beyond kSortMax entries keep the order the atomics produced, i.e.
-    // their sum is correct but its rounding may differ from run to run; kNN index sets stay far below the bound except
-    // the decoder's anchor lists, which use the register-table / one-hot forms instead)
-    if (hi - lo > kSortMax) continue;
-    for (int i = lo + 1; i < hi; ++i) {
-      const int v = ent[i];
-      int j = i - 1;
-      while (j >= lo && ent[j] > v) {
-        ent[j + 1] = ent[j];
-        --j;
-      }
-      ent[j + 1] = v;
-    }
-  }
+  // fixed summation order: ascending entry number inside every list (lists are short: E / N on average; lists beyond kSortMax
+  // entries keep the order the atomics produced, i.e. their sum is correct but its rounding may differ from run to run; kNN
+  // index sets stay far below the bound except the decoder's anchor lists, which use the register-table / one-hot forms instead)
   if (LDS_ENTRIES) {
-    __syncthreads();
-    for (int e = threadIdx.x; e < E; e += kInvThreads) entries[e] = ent[e];
+    // one thread per ENTRY: its place in the list is the number of smaller entries -- independent LDS reads (a list of 30 is
+    // 900 reads spread over 30 threads, not one thread's chain of 225 dependent moves), written straight to the output
+    for (int i = threadIdx.x; i < E; i += kInvThreads) {
+      const int v = ent[i], s = idx[v];
+      const int lo = s ? cnt[s - 1] : 0, hi = cnt[s];          // every cursor ended at its list's end = the next list's start
+      int rank = i - lo;
+      if (hi - lo <= kSortMax) {
+        rank = 0;
+        for (int j = lo; j < hi; ++j) rank += ent[j] < v ? 1 : 0;
+      }
+      entries[lo + rank] = v;
+    }
+  } else {
+    for (int s = threadIdx.x; s < N; s += kInvThreads) {
+      const int lo = s ? cnt[s - 1] : 0, hi = cnt[s];
+      if (hi - lo > kSortMax) continue;
+      for (int i = lo + 1; i < hi; ++i) {      // (one thread, insertion sort in global memory: the form for E beyond the LDS)
+        const int v = ent[i];
+        int j = i - 1;
+        while (j >= lo && ent[j] > v) {
+          ent[j + 1] = ent[j];
+          --j;
+        }
+        ent[j + 1] = v;
+      }
+    }
   }
 }
 
