@@ -35,9 +35,10 @@ class TransformerBlock(nn.Module):
         self.k = k
         self.group_all = group_all
 
-    def forward(self, xyz, feats=None, idx=None, inv=None):
+    def forward(self, xyz, feats=None, idx=None, inv=None, rel=None):
         """``idx`` [B,n,k] int32: precomputed neighbour indices (geometry pyramid); computed here if None.
-        ``inv``: the inverse lists of ``idx`` when the pyramid built them as well."""
+        ``inv``: the inverse lists of ``idx`` when the pyramid built them as well.  ``rel``: xyz_i - xyz_j over ``idx`` when the
+        caller has it already (blocks that share an index set share their relative coordinates)."""
         B, n, _ = xyz.shape
         if idx is not None:
             pass
@@ -45,7 +46,8 @@ class TransformerBlock(nn.Module):
             idx = torch.arange(n, device=xyz.device, dtype=torch.int32).view(1, 1, n).expand(B, n, n).contiguous()
         else:
             idx = ops.knn_indices(xyz, xyz, self.k)
-        rel = ops.relative_coords(xyz, xyz, idx)                     # xyz_i - xyz_j
+        if rel is None:
+            rel = ops.relative_coords(xyz, xyz, idx)                 # xyz_i - xyz_j
         if self.pos_only:
             res, _ = ops.vector_attention(rel, None, None, None, idx, self.fc_delta, self.fc_gamma)
         else:

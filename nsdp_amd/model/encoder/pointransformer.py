@@ -107,10 +107,24 @@ class PointTransformerEncoder(nn.Module):
         # the final blocks all search the same cloud with the same k: one kNN (and one inverse list) for all
         final_idx = geometry.get("final_idx") if geometry is not None else None
         final_inv = geometry.get("final_inv") if geometry is not None else None
+        # (... also when they attend to the whole cloud, group_all: one arange index tensor and one list instead of one per block --
+        # a list build is a launch on the forward chain, where a kernel's microsecond is a step's microsecond)
+        same = len({(blk.group_all, blk.k) for blk in self.final_transformers}) == 1
+        final_rel = None
         for blk, mlp in zip(self.final_transformers, self.final_elementwise):
-            if final_idx is None and not blk.group_all:
-                final_idx = ops.knn_indices(xyz, xyz, blk.k)
-            feats = mlp(blk(xyz, feats, idx=None if blk.group_all else final_idx, inv=None if blk.group_all else final_inv))
+            if final_idx is None and (same or not blk.group_all):
+                n = xyz.shape[1]
+                if blk.group_all:
+                    final_idx = torch.arange(n, device=xyz.device, dtype=torch.int32).view(1, 1, n).expand(xyz.shape[0], n, n).contiguous()
+                else:
+                    final_idx = ops.knn_indices(xyz, xyz, blk.k)
+                if final_inv is None and same and not blk.pos_only:
+                    final_inv = ops.hip_attention.backward_lists(final_idx, n, n, feats.shape[-1])
+            shared = final_idx is not None and (same or not blk.group_all)
+            if shared and final_rel is None and not xyz.requires_grad:      # (coordinates without a gradient: a constant of the blocks)
+                final_rel = ops.relative_coords(xyz, xyz, final_idx)
+            feats = mlp(blk(xyz, feats, idx=final_idx if shared else None, inv=final_inv if shared else None,
+                            rel=final_rel if shared else None))
         lat_vec = feats.max(dim=1)[0]
         enc = {"z": ops.mlp2(lat_vec, self.fc_middle), "anchors": xyz, "anchor_feats": feats}
         if prefetch is not None:
