@@ -173,7 +173,8 @@ int nsdp_linear_wp_f32(const float *X, const float *Wp, const float *bias, const
  * instruction); sizes from nsdp_packed_weight_bf16x3_bytes(N, K, transposed). */
 /* Every pack of a model in one launch per 64 descriptors (the optimizer rewrites all weights once per train step, so
  * all packs are rebuilt once per step).  `descs` is a HOST array; kind 0 = nsdp_pack_weight_f32 layout, 1 =
- * nsdp_pack_weight_bf16x3 layout; Wp / WpT may be NULL (not both); results are bit-identical to the single calls. */
+ * nsdp_pack_weight_bf16x3 layout, 3 = Wp is the row-major [N, 4] zero-padded copy of a K <= 4 weight (the 16-byte weight rows of the
+ * K = 4 kernels; WpT unused); Wp / WpT may be NULL (not both); results are bit-identical to the single calls. */
 typedef struct {
   const float *W; /* [N, K] row-major, device */
   void *Wp;       /* forward pack or NULL */

@@ -21,6 +21,8 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(Batch b) {
   const long long q = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
   if (e.kind == 0) {
     nsdp::pack::fp32_body(e.W, e.N, e.K, static_cast<float *>(e.Wp), static_cast<float *>(e.WpT), q);
+  } else if (e.kind == 3) {      // row-major [N, 4] copy of a K <= 4 weight, zero-padded (the K = 4 kernels' 16-byte weight rows)
+    if (q < 4LL * e.N) static_cast<float *>(e.Wp)[q] = static_cast<int>(q & 3) < e.K ? e.W[(q >> 2) * e.K + (q & 3)] : 0.f;
   } else {
     if (q < nsdp::pack::x3_threads(e.N, e.K, e.Wp != nullptr, e.WpT != nullptr))
       nsdp::pack::x3_body(e.W, e.N, e.K, static_cast<nsdp::pack::u32x4 *>(e.Wp), static_cast<nsdp::pack::u32x4 *>(e.WpT), q);
@@ -39,11 +41,12 @@ extern "C" int nsdp_pack_weights_batched(const NsdpPackDesc *descs, int count, v
     long long threads = 64;
     for (int i = 0; i < n; ++i) {
       const NsdpPackDesc &e = descs[base + i];
-      NSDP_REQUIRE(e.W && (e.Wp || e.WpT) && e.N > 0 && e.K > 0 && (e.kind == 0 || e.kind == 1),
+      NSDP_REQUIRE(e.W && (e.Wp || e.WpT) && e.N > 0 && e.K > 0 && (e.kind == 0 || e.kind == 1 || (e.kind == 3 && e.Wp && e.K <= 4)),
                    "pack_weights_batched: bad descriptor %d", base + i);
       b.d[i] = e;
-      const long long t = e.kind == 0 ? nsdp::pack::fp32_threads(e.N, e.K)
-                                      : nsdp::pack::x3_threads(e.N, e.K, e.Wp != nullptr, e.WpT != nullptr);
+      const long long t = e.kind == 0   ? nsdp::pack::fp32_threads(e.N, e.K)
+                          : e.kind == 3 ? 4LL * e.N
+                                        : nsdp::pack::x3_threads(e.N, e.K, e.Wp != nullptr, e.WpT != nullptr);
       threads = t > threads ? t : threads;
     }
     for (int i = n; i < kBatch; ++i) b.d[i] = b.d[0];     // never indexed (grid.y = n)
