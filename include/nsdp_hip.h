@@ -436,6 +436,12 @@ int nsdp_segment_sum_rows(const float *src, const int32_t *offsets, const int32_
                           float scale, float *out, void *stream);
 int nsdp_segment_sum_rows_bf16(const void *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
                                float scale, float *out, void *stream);
+/* ... with the caller's next statement folded in: out = scale * sum + addend (addend (B, N, d) fp32; bit-identical to the call above
+ * followed by the addition for scale = +-1). */
+int nsdp_segment_sum_rows_add(const float *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                              float scale, const float *addend, float *out, void *stream);
+int nsdp_segment_sum_rows_add_bf16(const void *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                                   float scale, const float *addend, float *out, void *stream);
 
 /* Scatter as a GEMM (bf16 storage): table[b][a][c] = sum over the rows r of shape b with idx[b][r] == a of src[b][r][c],
  * computed as one-hot(idx)^T x src on the matrix cores (exact: 1.0 x bf16, fp32 accumulation; no atomics, deterministic).
@@ -481,6 +487,14 @@ int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const i
  * elementwise add over the largest tensor of the block. */
 int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
                       int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream);
+/* The dq-only form (the caller scatters dkf itself, through inverse lists) with the caller's next statement folded in:
+ * dq (B,n,d) = sum_j du - dq_sub (dq_sub (B,n,d): the upstream gradient of the block's output, whose share of d(pos) the fused
+ * d(pos) hand-over counted twice -- hip_attention._AttnPre.backward).  Bit-identical to nsdp_attn_pre_bwd followed by the
+ * subtraction. */
+int nsdp_attn_pre_bwd_sub(const float *du, const int32_t *idx, int B, int n, int N, int k, int d, const float *dq_sub, float *dq,
+                          void *stream);
+int nsdp_attn_pre_bwd_sub_bf16(const void *du, const int32_t *idx, int B, int n, int N, int k, int d, const void *dq_sub, float *dq,
+                               void *stream);
 /* y = sum_j softmax_j(a) * (vf[idx] + pos) [+ softmax weight of a_g * v_g] [+ residual];
  * lse (B,n,d) = log-sum-exp of the logits (kept for the backward pass).
  * vf == NULL: values are `pos` alone (pos_only block); a_g/v_g, residual may be NULL. */

@@ -94,7 +94,7 @@ Scope::~Scope() {
 
 extern "C" {
 
-int nsdp_abi_version(void) { return 6; }
+int nsdp_abi_version(void) { return 7; }
 
 const char *nsdp_last_error(void) { return nsdp::g_last_error; }
 

@@ -184,7 +184,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T *__restrict__ du,
                                                            const int32_t *__restrict__ idx,
                                                            float *__restrict__ dq, float *__restrict__ dkf,
-                                                           T *__restrict__ dpos_acc) {
+                                                           T *__restrict__ dpos_acc, const T *__restrict__ dq_sub = nullptr) {
   constexpr bool ST = QuadMap<T>::kStrided;
   const Lane L = lane_setup(s);
   if (!L.active) return;
@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256) void attn_pre_bwd_kernel(AttnShape s, const T 
       }
       qb_acc.x += acc.x; qb_acc.y += acc.y; qb_acc.z += acc.z; qb_acc.w += acc.w;
     } else {
+      if (dq_sub) {      // (the caller's next statement was `dq -= dq_sub`)
+        const Quad o = ldQ<ST>(dq_sub + pt * s.d, cq, lpp);
+        acc.x -= o.x; acc.y -= o.y; acc.z -= o.z; acc.w -= o.w;
+      }
       stQ<ST>(dq + pt * s.d, cq, lpp, acc);
     }
   }
@@ -806,7 +810,7 @@ int attn_pre_fwd_t(const T *q, const T *kf, const T *pos, const int32_t *idx, in
 
 template <typename T>
 int attn_pre_bwd_t(const T *du, const int32_t *idx, int B, int n, int N, int k, int d, int q_per_shape, float *dq,
-                   float *dkf, T *dpos_acc, void *stream) {
+                   float *dkf, T *dpos_acc, void *stream, const T *dq_sub = nullptr) {
   constexpr double kEl = sizeof(T);
   const AttnShape s{B, n, N, k, d, q_per_shape, iters_for(k)};
   hipStream_t st = nsdp::as_stream(stream);
@@ -817,9 +821,10 @@ int attn_pre_bwd_t(const T *du, const int32_t *idx, int B, int n, int N, int k, 
   if (static_cast<long long>(B) * n * k * d <= 0) return 0;
   NSDP_REQUIRE(shape_ok(s), "attn_pre_bwd: unsupported shape (d=%d must be a multiple of 4 in [4, 256])", d);
   NSDP_REQUIRE(du && idx && dq, "attn_pre_bwd: null pointer");
+  NSDP_REQUIRE(!dq_sub || (!dkf && !q_per_shape), "attn_pre_bwd: dq_sub goes with the dq-only form (dkf NULL, per-point queries)");
   if (!dkf) {      // the caller scatters itself (inverse neighbour lists): only dq (+ the optional d(pos) accumulation) here
     NSDP_TRACE("attn_pre_bwd_stream");
-    NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel<T>, s, du, idx, dq, dkf, dpos_acc);
+    NSDP_ATTN_LAUNCH(attn_pre_bwd_kernel<T>, s, du, idx, dq, dkf, dpos_acc, dq_sub);
     return nsdp::launch_status("attn_pre_bwd_kernel");
   }
   nsdp::prof::Scope scope(nsdp::prof::kAttnBwd, st, 0.0,
@@ -983,6 +988,15 @@ int nsdp_attn_pre_fwd(const float *q, const float *kf, const float *pos, const i
 int nsdp_attn_pre_bwd(const float *du, const int32_t *idx, int B, int n, int N, int k, int d,
                       int q_per_shape, float *dq, float *dkf, float *dpos_acc, void *stream) {
   return attn_pre_bwd_t<float>(du, idx, B, n, N, k, d, q_per_shape, dq, dkf, dpos_acc, stream);
+}
+int nsdp_attn_pre_bwd_sub(const float *du, const int32_t *idx, int B, int n, int N, int k, int d, const float *dq_sub, float *dq,
+                          void *stream) {
+  return attn_pre_bwd_t<float>(du, idx, B, n, N, k, d, 0, dq, nullptr, nullptr, stream, dq_sub);
+}
+int nsdp_attn_pre_bwd_sub_bf16(const void *du, const int32_t *idx, int B, int n, int N, int k, int d, const void *dq_sub, float *dq,
+                               void *stream) {
+  return attn_pre_bwd_t<bf16_t>(reinterpret_cast<const bf16_t *>(du), idx, B, n, N, k, d, 0, dq, nullptr, nullptr, stream,
+                                reinterpret_cast<const bf16_t *>(dq_sub));
 }
 int nsdp_attn_post_fwd(const float *a, const float *vf, const float *pos, const int32_t *idx,
                        const float *a_g, const float *v_g, const float *residual, int B, int n, int N,

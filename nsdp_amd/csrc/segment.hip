@@ -109,7 +109,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t *p) {
 template <typename T>
 __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const T *__restrict__ src, const int32_t *__restrict__ offsets,
                                                                const int32_t *__restrict__ entries, int B, int E, int N,
-                                                               int d, float scale, float *__restrict__ out) {
+                                                               int d, float scale, const float *__restrict__ addend,
+                                                               float *__restrict__ out) {
   const int lpp = d >> 2, ppw = 64 / lpp;                  // lanes per point, points per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / lpp, cq = lane - sub * lpp;
@@ -138,12 +139,17 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const T *__restri
     const float4 a = ld4(base + static_cast<long long>(ent[i]) * d);
     acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
   }
-  *reinterpret_cast<float4 *>(out + pt * d + 4 * cq) = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
+  float4 r = make_float4(scale * acc.x, scale * acc.y, scale * acc.z, scale * acc.w);
+  if (addend) {      // (the caller's next statement was `out += addend`: one launch less per attention block's backward)
+    const float4 a = *reinterpret_cast<const float4 *>(addend + pt * d + 4 * cq);
+    r.x += a.x; r.y += a.y; r.z += a.z; r.w += a.w;
+  }
+  *reinterpret_cast<float4 *>(out + pt * d + 4 * cq) = r;
 }
 
 template <typename T>
 int segment_sum_t(const T *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d, float scale,
-                  float *out, void *stream) {
+                  float *out, void *stream, const float *addend = nullptr) {
   if (B <= 0 || N <= 0) return 0;
   NSDP_REQUIRE(src && offsets && entries && out, "segment_sum_rows: null pointer");
   NSDP_REQUIRE(d >= 4 && d % 4 == 0 && d <= 256, "segment_sum_rows: d=%d must be a multiple of 4 in [4, 256]", d);
@@ -153,7 +159,7 @@ int segment_sum_t(const T *src, const int32_t *offsets, const int32_t *entries, 
   const int ppw = 64 / (d >> 2);
   const long long waves = (static_cast<long long>(B) * N + ppw - 1) / ppw;
   hipLaunchKernelGGL(segment_sum_rows_kernel<T>, dim3(static_cast<unsigned>((waves + 3) / 4)), dim3(256), 0, st, src, offsets,
-                     entries, B, E, N, d, scale, out);
+                     entries, B, E, N, d, scale, addend, out);
   return nsdp::launch_status("segment_sum_rows_kernel");
 }
 
@@ -182,6 +188,16 @@ int nsdp_knn_invert(const int32_t *idx, int B, int E, int N, int32_t *offsets, i
 int nsdp_segment_sum_rows(const float *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
                           float scale, float *out, void *stream) {
   return segment_sum_t<float>(src, offsets, entries, B, E, N, d, scale, out, stream);
+}
+
+int nsdp_segment_sum_rows_add(const float *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                              float scale, const float *addend, float *out, void *stream) {
+  return segment_sum_t<float>(src, offsets, entries, B, E, N, d, scale, out, stream, addend);
+}
+
+int nsdp_segment_sum_rows_add_bf16(const void *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,
+                                   float scale, const float *addend, float *out, void *stream) {
+  return segment_sum_t<bf16_t>(reinterpret_cast<const bf16_t *>(src), offsets, entries, B, E, N, d, scale, out, stream, addend);
 }
 
 int nsdp_segment_sum_rows_bf16(const void *src, const int32_t *offsets, const int32_t *entries, int B, int E, int N, int d,

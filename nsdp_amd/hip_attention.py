@@ -52,6 +52,9 @@ def _onehot_ok(dt, qb_or_decoder, N, d):
 # Encoder levels whose source table fits neither LDS nor registers (2048 / 500 source points): scatter through inverse
 # neighbour lists (csrc/segment.hip) instead of global fp32 atomics.  The lists depend on the index tensor only and are
 # cached on it (the two attentions of a set abstraction share one index set; forward builds nothing).
+# the two small corrections of the fused d(pos) hand-over (dkf += dvf, dq -= dy) inside the scatter / reduction kernels ("0": as two
+# elementwise launches behind them, A/B knob)
+FOLD_PRE_BWD = os.environ.get("NSDP_FOLD_PRE_BWD", "1") != "0"
 INVERSE_LISTS = os.environ.get("NSDP_INVERSE_LISTS", "1")         # "0": the global-atomic kernels (A/B knob)
 
 
@@ -93,9 +96,9 @@ def inverse_lists(idx, N):
     return offsets, entries
 
 
-def segment_sum(src, idx, N, scale=1.0, inv=None):
-    """out [B,N,d] fp32 = scale * scatter-add of the rows of src [B,n,k,d] by idx [B,n,k], as a gather-reduce over the
-    inverse lists (deterministic, no atomics).  ``inv``: the lists, when the caller built them already."""
+def segment_sum(src, idx, N, scale=1.0, inv=None, addend=None):
+    """out [B,N,d] fp32 = scale * scatter-add of the rows of src [B,n,k,d] by idx [B,n,k] (+ ``addend`` [B,N,d] fp32), as a
+    gather-reduce over the inverse lists (deterministic, no atomics).  ``inv``: the lists, when the caller built them already."""
     B = src.shape[0]
     d = src.shape[-1]
     E = idx.numel() // B
@@ -103,8 +106,13 @@ def segment_sum(src, idx, N, scale=1.0, inv=None):
     out = torch.empty((B, N, d), dtype=torch.float32, device=src.device)
     dt = src.dtype
     with on_device(src):
-        check(_fn("nsdp_segment_sum_rows", dt)(_p(src, dt, "src"), iptr(offsets), iptr(entries), _ci(B), _ci(E), _ci(N), _ci(d),
-                                               ctypes.c_float(scale), fptr(out), stream_ptr()), "nsdp_segment_sum_rows")
+        if addend is not None:
+            check(_fn("nsdp_segment_sum_rows_add", dt)(_p(src, dt, "src"), iptr(offsets), iptr(entries), _ci(B), _ci(E), _ci(N),
+                                                       _ci(d), ctypes.c_float(scale), fptr(addend, "addend"), fptr(out), stream_ptr()),
+                  "nsdp_segment_sum_rows_add")
+        else:
+            check(_fn("nsdp_segment_sum_rows", dt)(_p(src, dt, "src"), iptr(offsets), iptr(entries), _ci(B), _ci(E), _ci(N), _ci(d),
+                                                   ctypes.c_float(scale), fptr(out), stream_ptr()), "nsdp_segment_sum_rows")
     return out
 
 
@@ -196,11 +204,19 @@ class _AttnPre(torch.autograd.Function):
             acc, link.dpos = link.dpos, None
         if acc is None and _use_inverse(dt, qb, n, N, d):
             # dq from a pure stream over du, dkf = -scatter(du) as a gather-reduce over the inverse neighbour lists
+            fold = fused and not qb and FOLD_PRE_BWD and link.dvf.dtype is torch.float32 and link.dy.dtype is dt
             with on_device(du):
-                check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
-                                                   _ci(qb), fptr(dq), ctypes.c_void_p(0), ctypes.c_void_p(0), stream_ptr()),
-                      "nsdp_attn_pre_bwd")
-            dkf = segment_sum(du, idx, N, -1.0, ctx.inv)
+                if fold:      # (... with the two corrections of the fused d(pos) hand-over below folded into the kernels)
+                    check(_fn("nsdp_attn_pre_bwd_sub", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
+                                                           _p(_c(link.dy), dt, "dy"), fptr(dq), stream_ptr()), "nsdp_attn_pre_bwd_sub")
+                else:
+                    check(_fn("nsdp_attn_pre_bwd", dt)(_p(du, dt, "du"), iptr(idx), _ci(B), _ci(n), _ci(N), _ci(k), _ci(d),
+                                                       _ci(qb), fptr(dq), ctypes.c_void_p(0), ctypes.c_void_p(0), stream_ptr()),
+                          "nsdp_attn_pre_bwd")
+            dkf = segment_sum(du, idx, N, -1.0, ctx.inv, addend=_c(link.dvf) if fold else None)
+            if fold:
+                link.dvf = link.dy = None
+                link.fused = fused = False
         elif fused and acc is None and _onehot_ok(dt, qb, N, d):
             # decoder, bf16: -scatter(du) and the per-shape sum of du from one scatter-as-GEMM pass (no atomics)
             table = onehot_scatter(du.reshape(B, n * k, d), idx.reshape(B, n * k), N)

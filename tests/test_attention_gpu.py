@@ -150,6 +150,33 @@ def test_inverse_lists_and_segment_sum(B, n, N, k, d):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_folded_corrections_of_the_pre_backward_are_the_separate_launches_bit_for_bit(dt):
+    """nsdp_segment_sum_rows_add / nsdp_attn_pre_bwd_sub: `out = -sum + addend` and `dq = sum_j du - dy` inside the kernels against
+    the plain calls followed by the elementwise launches they replace (hip_attention._AttnPre.backward, NSDP_FOLD_PRE_BWD)."""
+    import ctypes
+    from nsdp_amd import hip_attention as ha
+    B, n, N, k, d = 3, 257, 700, 16, 120
+    g = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, N, (B, n, k), generator=g, dtype=torch.int32).to(DEV)
+    du = torch.randn(B, n, k, d, generator=g).to(dt).to(DEV)
+    dvf = torch.randn(B, N, d, generator=g).to(DEV)
+    dy = torch.randn(B, n, d, generator=g).to(dt).to(DEV)
+    want = ha.segment_sum(du, idx, N, -1.0).add_(dvf)
+    assert torch.equal(ha.segment_sum(du, idx, N, -1.0, addend=dvf), want)
+    L = ha.lib()
+    ci = ctypes.c_int
+    dq0 = torch.empty(B, n, d, device=DEV)
+    dq1 = torch.empty(B, n, d, device=DEV)
+    ha.check(ha._fn("nsdp_attn_pre_bwd", dt)(ha._p(du, dt), ha.iptr(idx), ci(B), ci(n), ci(N), ci(k), ci(d), ci(0), ha.fptr(dq0),
+                                              ctypes.c_void_p(0), ctypes.c_void_p(0), ha.stream_ptr()), "nsdp_attn_pre_bwd")
+    dq0.sub_(dy)
+    ha.check(ha._fn("nsdp_attn_pre_bwd_sub", dt)(ha._p(du, dt), ha.iptr(idx), ci(B), ci(n), ci(N), ci(k), ci(d), ha._p(dy, dt),
+                                                  ha.fptr(dq1), ha.stream_ptr()), "nsdp_attn_pre_bwd_sub")
+    assert torch.equal(dq0, dq1)
+    assert L is not None
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_attention_backward_through_inverse_lists_matches_the_atomic_kernels(dt):
     from nsdp_amd import hip_attention as ha
     B, n, N, k, d = 2, 300, 700, 16, 120

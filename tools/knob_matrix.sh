@@ -6,7 +6,7 @@ knobs=("NSDP_WGRAD_STREAM=0" "NSDP_WGRAD_STREAM=1" "NSDP_PARAM_GRADS=autograd" "
        "NSDP_WG16_DBG=8" "NSDP_REMASK_K4=0" "NSDP_X3_DBG=256" "NSDP_GRAPH_STREAMS=4" \
        "NSDP_SCATTER_ROWS=atomic" "NSDP_ONEHOT_SCATTER_F32=0" "NSDP_WGRAD_RESERVE_CUS=0" "NSDP_BF16_NET1=f32" \
        "NSDP_FUSE_PRE=0" "NSDP_COMBINE_TABLES=0" "NSDP_SKIP_GRAD=0" "NSDP_K4_LINK=0" "NSDP_K4_TAIL=0" "NSDP_K4_TAIL_SIDE=0" "NSDP_HIP_ADAM=0" "NSDP_KNN_QUEUE=0" "NSDP_BN_SLAB=0" "NSDP_BN_SLAB=2" "NSDP_ENCODE_ONCE=0" "NSDP_SEARCH_QUAD=0" "NSDP_DECODER_PREFETCH=1" "NSDP_REL4=0" "NSDP_WGRAD_BATCH_REDUCE=0" "NSDP_WGRAD_BATCH_REDUCE=48" "NSDP_PYRAMID_LISTS=0" "NSDP_H0_RECOMPUTE=0" "NSDP_H0_RECOMPUTE=2" "NSDP_WGRAD_DIRECT_ROWS=0" "NSDP_GRAPH_HEIR=0" \
-       "NSDP_G16=0" "NSDP_G16_BITS=0" "NSDP_X3_DBG=8192" "NSDP_DP_OVERLAP=on" "NSDP_DP_OVERLAP=off" "NSDP_BN_DIRECT_GRADS=0" "NSDP_SCATTER_DETERMINISTIC=0")
+       "NSDP_G16=0" "NSDP_G16_BITS=0" "NSDP_X3_DBG=8192" "NSDP_FOLD_PRE_BWD=0" "NSDP_DP_OVERLAP=on" "NSDP_DP_OVERLAP=off" "NSDP_BN_DIRECT_GRADS=0" "NSDP_SCATTER_DETERMINISTIC=0")
 # (NSDP_BF16_TRUNK=f32 is a bisect knob of tools/bf16_bisect.py, not a supported variant: FlowArbitrary's bf16 train loss moves
 # by 8 % under it -- the chaotic amplification the bisect measures)
 [ $# -gt 0 ] && knobs=("$@")
