@@ -462,8 +462,10 @@ def _wgrad_sliced(dy2, x2, mask, relu_x, want_db, k_orig, out=None):
 REMASK_K4 = os.environ.get("NSDP_REMASK_K4", "1") != "0"      # (A/B knob: 0 = the K = 4 weight gradient reads the fp32 mask)
 
 
-def _padded_w4(w_param):
-    """Row-major [N, 4] copy of a K = 3 / 4 weight (zero-padded), cached on the parameter like the packs."""
+def _padded_w4(w_param, batch=True):
+    """Row-major [N, 4] copy of a K = 3 / 4 weight (zero-padded), cached on the parameter like the packs.  ``batch=False`` (the
+    callers inside a backward pass): a stale copy is rebuilt alone -- the batched rebuild rewrites EVERY pack of the device in place,
+    among them the W^T packs this very backward pass saved (a two-graph step advances the weights epoch between its halves)."""
     key = _pack_key(w_param)
     hit = w_param.__dict__.get("_nsdp_w4")
     if hit is not None and hit[0] == key:
@@ -475,8 +477,8 @@ def _padded_w4(w_param):
         # (five K = 3 layers were ten fill / copy launches per step at the head of the forward chain)
         reg = _pack_registry.get(w.device.index)
         ent = reg["entries"].get((id(w_param), "w4")) if reg is not None else None
-        if (hit is not None and ent is not None and ent[0]() is w_param and ent[2] is hit[1] and len(reg["entries"]) >= _BATCH_MIN
-                and _repack_all(w.device)):
+        if (batch and hit is not None and ent is not None and ent[0]() is w_param and ent[2] is hit[1]
+                and len(reg["entries"]) >= _BATCH_MIN and _repack_all(w.device)):
             return w_param.__dict__["_nsdp_w4"][1]
     w4 = (F.pad(w, (0, 4 - w.shape[1])) if w.shape[1] < 4 else w).contiguous()
     w_param.__dict__["_nsdp_w4"] = (key, w4)
@@ -917,7 +919,7 @@ def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
         if not (K4_TAIL and kind_t == "x3" and L.nsdp_linear_bf16x3_k4tail_ok(_ll(M), _ci(n_hidden), _ci(K))):
             dh = _run(kind_t, dy2, wpt, n_hidden, None, None, None, None, False, False)
             if REMASK_K4 and n_hidden % 4 == 0 and n_hidden >= 16 and M >= 4096:
-                return _wgrad_k4_remask(_padded_w4(link.w_param), b0, link.k_orig)(dh, x4, None, False, want_db, out)
+                return _wgrad_k4_remask(_padded_w4(link.w_param, batch=False), b0, link.k_orig)(dh, x4, None, False, want_db, out)
             return _wgrad_sliced(dh, x4, h0, False, want_db, link.k_orig, out)
         L.nsdp_linear_bf16x3_k4tail_workspace_bytes.restype = ctypes.c_size_t
         nbytes = int(L.nsdp_linear_bf16x3_k4tail_workspace_bytes(_ll(M), _ci(n_hidden)))
@@ -927,7 +929,7 @@ def _k4tail_fn(link, wpt, n_hidden, kind_t, h0):
             if K4_TAIL_RESERVE is not None and torch.cuda.current_stream(dy2.device) == _side.get(dy2.device.index):
                 L.nsdp_debug_set(_ci(9), _ci(K4_TAIL_RESERVE))      # (_wgrad_deferred resets the hint after this routine)
             check(L.nsdp_linear_bf16x3_k4tail_f32(fptr(dy2, "dy"), ctypes.c_void_p(wpt.data_ptr()), fptr(x4, "x4"),
-                                                  fptr(_padded_w4(link.w_param), "w0"), optptr(b0), fptr(dw), optptr(db), _ll(M),
+                                                  fptr(_padded_w4(link.w_param, batch=False), "w0"), optptr(b0), fptr(dw), optptr(db), _ll(M),
                                                   _ci(n_hidden), _ci(K), _ci(int(link.k_orig)), _ci(acc), fptr(ws),
                                                   ctypes.c_size_t(nbytes), stream_ptr()), "nsdp_linear_bf16x3_k4tail_f32")
         return dw, db
@@ -1216,7 +1218,7 @@ class _LinearFn(torch.autograd.Function):
                 # Only when the recomputed expression IS the forward one: no residual operand (the mask would be that of
                 # relu(xW+b+res)), and the parameters are still the forward pass's (same pointer / version / epoch; a
                 # changed key falls back to the saved output as the mask)
-                fn = _wgrad_k4_remask(_padded_w4(ctx.w_param), None if ctx.b_param is None else ctx.b_param.detach(),
+                fn = _wgrad_k4_remask(_padded_w4(ctx.w_param, batch=False), None if ctx.b_param is None else ctx.b_param.detach(),
                                       ctx.k_orig)
             if _use_side_stream(dy2):
                 _wgrad_deferred(dy2, x2, y, ctx.relu_in, ctx.k_orig, ctx.w_param, ctx.b_param, fn=fn)   # side stream
